@@ -1,0 +1,183 @@
+"""Seeded synthetic weights and inputs for the encode/decode path.
+
+No checkpoints or datasets are reachable offline (reference README.md:44-56 links only), so
+parity tests, the bench and the golden fixtures use random weights of the released
+architecture.  Everything here is generated with numpy's PCG64 (bit-stable across machines and
+library versions) so that the build container (where the reference runs and the golden vectors
+are made) and the GPU box (where the HIP path runs) see identical tensors.
+
+`path_state_spec` enumerates the reference state_dict keys that belong to the path
+(checked against the reference's own state_dict in
+tests/test_oracle_vs_reference.py).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from .config import OmniTokConfig
+
+
+def _transformer_spec(prefix: str, block: str, cfg: OmniTokConfig, spatial_pos: str, spec: OrderedDict):
+    d, hd, heads = cfg.dim, cfg.dim_head, cfg.heads
+    inner = cfg.ff_inner
+    ws = cfg.window_size
+    for i, c in enumerate(block):
+        p = f"{prefix}.layers.{i}"
+        if c == "t":
+            spec[f"{p}.0.dsconv.weight"] = (d, 1, 3, 3, 3)
+            spec[f"{p}.0.dsconv.bias"] = (d,)
+            spec[f"{p}.1.q_scale"] = (hd,)
+            spec[f"{p}.1.k_scale"] = (hd,)
+            if spatial_pos == "rel":  # reference attention.py:363-364
+                spec[f"{p}.1.spatial_rel_pos_bias.net.0.0.weight"] = (d, 2)
+                spec[f"{p}.1.spatial_rel_pos_bias.net.0.0.bias"] = (d,)
+                spec[f"{p}.1.spatial_rel_pos_bias.net.1.0.weight"] = (d, d)
+                spec[f"{p}.1.spatial_rel_pos_bias.net.1.0.bias"] = (d,)
+                spec[f"{p}.1.spatial_rel_pos_bias.net.2.weight"] = (heads, d)
+                spec[f"{p}.1.spatial_rel_pos_bias.net.2.bias"] = (heads,)
+            spec[f"{p}.1.norm.gamma"] = (d,)
+            spec[f"{p}.1.norm.beta"] = (d,)
+            spec[f"{p}.1.context_norm.gamma"] = (d,)
+            spec[f"{p}.1.context_norm.beta"] = (d,)
+            spec[f"{p}.1.to_q.weight"] = (hd * heads, d)
+            spec[f"{p}.1.to_kv.weight"] = (2 * hd * heads, d)
+            spec[f"{p}.1.to_out.weight"] = (d, hd * heads)
+        elif c == "w":
+            spec[f"{p}.1.relative_position_bias_table"] = ((2 * ws - 1) ** 2, heads)
+            spec[f"{p}.1.relative_position_index"] = (ws * ws, ws * ws)
+            spec[f"{p}.1.norm.gamma"] = (d,)
+            spec[f"{p}.1.norm.beta"] = (d,)
+            spec[f"{p}.1.qkv.weight"] = (3 * d, d)
+            spec[f"{p}.1.proj.weight"] = (d, d)
+            spec[f"{p}.1.proj.bias"] = (d,)
+        else:
+            raise NotImplementedError(c)
+        spec[f"{p}.3.0.weight"] = (d,)
+        spec[f"{p}.3.0.bias"] = (d,)
+        spec[f"{p}.3.1.weight"] = (2 * inner, d)
+        spec[f"{p}.3.4.weight"] = (d, inner)
+    spec[f"{prefix}.norm_out.gamma"] = (d,)
+    spec[f"{prefix}.norm_out.beta"] = (d,)
+
+
+def path_state_spec(cfg: OmniTokConfig) -> "OrderedDict[str, tuple]":
+    """name -> shape for every reference state_dict entry on the encode/decode path."""
+    spec: OrderedDict = OrderedDict()
+    c, p, pt, d = cfg.image_channels, cfg.patch_size, cfg.temporal_patch_size, cfg.dim
+    k0, k1 = c * p * p, c * p * p * pt
+    for name, k in (("to_patch_emb_first_frame", k0), ("to_patch_emb", k1)):
+        spec[f"encoder.{name}.1.weight"] = (k,)
+        spec[f"encoder.{name}.1.bias"] = (k,)
+        spec[f"encoder.{name}.2.weight"] = (d, k)
+        spec[f"encoder.{name}.2.bias"] = (d,)
+        spec[f"encoder.{name}.3.weight"] = (d,)
+        spec[f"encoder.{name}.3.bias"] = (d,)
+    # temporal transformers are always built with the default spatial_pos="rel"
+    # (reference omnitokenizer.py:860-861) and so carry unused spatial_rel_pos_bias weights
+    _transformer_spec("encoder.enc_spatial_transformer", cfg.enc_block, cfg, cfg.spatial_pos, spec)
+    _transformer_spec("encoder.enc_temporal_transformer", "t" * cfg.temporal_depth, cfg, "rel", spec)
+    _transformer_spec("decoder.dec_spatial_transformer", cfg.dec_block, cfg, cfg.spatial_pos, spec)
+    _transformer_spec("decoder.dec_temporal_transformer", "t" * cfg.temporal_depth, cfg, "rel", spec)
+    spec["decoder.to_pixels_first_frame.0.weight"] = (k0, d)
+    spec["decoder.to_pixels_first_frame.0.bias"] = (k0,)
+    spec["decoder.to_pixels.0.weight"] = (k1, d)
+    spec["decoder.to_pixels.0.bias"] = (k1,)
+    spec["codebook.embeddings"] = (cfg.n_codes, cfg.codebook_dim)
+    spec["codebook.N"] = (cfg.n_codes,)
+    spec["codebook.z_avg"] = (cfg.n_codes, cfg.codebook_dim)
+    spec["codebook.codebook_usage"] = (cfg.n_codes,)
+    spec["pre_vq_conv.1.weight"] = (cfg.codebook_dim, d)
+    spec["pre_vq_conv.1.bias"] = (cfg.codebook_dim,)
+    spec["post_vq_conv.1.weight"] = (d, cfg.codebook_dim)
+    spec["post_vq_conv.1.bias"] = (d,)
+    return spec
+
+
+def relative_position_index(ws: int) -> torch.Tensor:
+    """Swin-style index table, same arithmetic as reference attention.py:230-241:
+    index[i,j] = (dy+ws-1)*(2ws-1) + (dx+ws-1), (dy,dx) = pos(i)-pos(j)."""
+    yy, xx = np.divmod(np.arange(ws * ws), ws)
+    dy = yy[:, None] - yy[None, :] + ws - 1
+    dx = xx[:, None] - xx[None, :] + ws - 1
+    return torch.from_numpy((dy * (2 * ws - 1) + dx).astype(np.int64))
+
+
+def _key_seed(seed: int, name: str) -> int:
+    return (seed * 1000003 + zlib.crc32(name.encode())) & 0xFFFFFFFF
+
+
+def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Random but non-degenerate parameters: every gamma/bias/scale is perturbed so that a
+    kernel that drops one of them is caught."""
+    sd: OrderedDict = OrderedDict()
+    for name, shape in path_state_spec(cfg).items():
+        rng = np.random.Generator(np.random.PCG64(_key_seed(seed, name)))
+        leaf = name.rsplit(".", 1)[-1]
+
+        def randn(scale=1.0, mean=0.0):
+            return (rng.standard_normal(shape, dtype=np.float32) * np.float32(scale)
+                    + np.float32(mean)).astype(np.float32)
+
+        if name.endswith("relative_position_index"):
+            sd[name] = relative_position_index(cfg.window_size)
+            continue
+        if name == "codebook.embeddings":
+            v = randn(1.0)  # reference codebook.py:14 torch.randn(n_codes, dim)
+        elif name == "codebook.z_avg":
+            v = sd["codebook.embeddings"].numpy().copy()
+        elif name in ("codebook.N", "codebook.codebook_usage"):
+            v = np.zeros(shape, np.float32)
+        elif "dsconv.weight" in name:
+            v = (rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(1 / np.sqrt(27.0))
+        elif "dsconv.bias" in name:
+            v = randn(0.05)
+        elif leaf in ("q_scale", "k_scale", "gamma"):
+            v = randn(0.1, 1.0)
+        elif leaf == "beta":
+            v = np.zeros(shape, np.float32)  # fixed-zero buffer, reference attention.py:77
+        elif leaf == "relative_position_bias_table":
+            v = randn(0.5)
+        elif "spatial_rel_pos_bias" in name:
+            fan_in = shape[-1] if len(shape) > 1 else 1
+            v = randn(1.0 / np.sqrt(fan_in)) if leaf == "weight" else randn(0.1)
+        elif leaf == "weight" and len(shape) == 1:  # nn.LayerNorm weight
+            v = randn(0.1, 1.0)
+        elif leaf == "bias":
+            v = randn(0.05)
+        elif leaf == "weight":
+            v = np.clip(randn(0.04), -0.08, 0.08)
+        else:
+            raise KeyError(name)
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
+    return sd
+
+
+def synth_video(batch: int, frames: int, resolution: int, seed: int = 1234, smooth: bool = True,
+                channels: int = 3) -> torch.Tensor:
+    """[B,C,F,H,W] fp32 in [-0.5, 0.5] (the reference's preprocess contract, data.py:346).
+    smooth=True low-pass filters the noise so LayerNorm inputs are not white."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    x = rng.random((batch, channels, frames, resolution, resolution), dtype=np.float32)
+    if smooth:
+        for ax in (3, 4):
+            x = (x + np.roll(x, 1, ax) + np.roll(x, -1, ax) + np.roll(x, 2, ax)) * np.float32(0.25)
+        x = (x - x.min()) / (x.max() - x.min())
+    return torch.from_numpy(np.ascontiguousarray((x - np.float32(0.5)).astype(np.float32)))
+
+
+def synth_image(batch: int, resolution: int, seed: int = 1234, smooth: bool = True) -> torch.Tensor:
+    """[B,C,H,W]."""
+    return synth_video(batch, 1, resolution, seed, smooth)[:, :, 0].contiguous()
+
+
+def state_checksum(sd) -> int:
+    """crc32 over all tensors in key order: pins the generator in the golden fixtures."""
+    c = 0
+    for k in sd:
+        c = zlib.crc32(k.encode(), c)
+        c = zlib.crc32(sd[k].detach().cpu().contiguous().numpy().tobytes(), c)
+    return c

@@ -1,0 +1,119 @@
+"""Generates tests/golden/*.npz by running the UNMODIFIED reference (imported read-only from
+/root/reference through oracle/ref_harness.py) on seeded synthetic weights and inputs.
+
+Run in the build container only:   python tests/golden/make_golden.py
+The fixtures are committed; the GPU box has no /root/reference and only reads the .npz files.
+
+Each fixture stores what is needed to regenerate the inputs (config overrides, seeds, shapes),
+a crc32 of the synthetic state_dict (pins omnitokenizer_amd/synth.py) and the reference outputs:
+  ids     encode() token ids                       (int16/int32, exact)
+  z       pre-VQ l2-normalised latents             (fp32)  -- lets the VQ kernel be tested on the
+                                                              reference's own z, bit-exact
+  recon   decode(ids) pixels, optionally strided   (fp32)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle import ref_harness as rh  # noqa: E402
+from omnitokenizer_amd.config import make_args, OmniTokConfig  # noqa: E402
+from omnitokenizer_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+# name, stage, attention mode, overrides, batch, frames (1 = image), pixel stride in the fixture
+CASES = [
+    ("s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64), 2, 1, 1),
+    ("s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64), 2, 5, 1),
+    ("s2_sdpa_r64_vid9", 2, "sdpa", dict(resolution=64), 1, 9, 1),
+    ("s1_legacy_r64_img", 1, "legacy", dict(resolution=64), 2, 1, 1),
+    ("s1_legacy_r64_vid", 1, "legacy", dict(resolution=64), 1, 5, 1),
+    ("s1_sdpa_r64_img", 1, "sdpa", dict(resolution=64), 1, 1, 1),
+    ("s2_sdpa_r128_vid_16k", 2, "sdpa", dict(resolution=128, n_codes=16384), 1, 5, 2),
+    ("s2_sdpa_r256_img", 2, "sdpa", dict(resolution=256), 1, 1, 2),
+    ("s2_sdpa_r256_vid", 2, "sdpa", dict(resolution=256), 1, 5, 4),
+    ("s1_legacy_r256_img", 1, "legacy", dict(resolution=256), 1, 1, 4),  # BASELINE config C1
+]
+
+
+def run_case(name, stage, mode, overrides, batch, frames, stride):
+    args = make_args(stage, **overrides)
+    cfg = OmniTokConfig.from_args(args, attention_mode=mode)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = rh.build_reference_model(args)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    is_image = frames == 1
+    res = cfg.resolution
+    x = synth.synth_image(batch, res, seed=1234) if is_image else synth.synth_video(batch, frames, res, seed=1234)
+    with torch.no_grad(), rh.attention_mode(mode):
+        emb, ids = model.encode(x, is_image, include_embeddings=True)
+        # pre-VQ z exactly as the reference feeds Codebook.forward (omnitokenizer.py:248-252)
+        h = model.pre_vq_conv(model.encoder(x, is_image))
+        z = torch.nn.functional.normalize(h, p=2, dim=1)
+        recon = model.decode(ids, is_image)
+        flat = ids.reshape(ids.shape[0], -1)
+        recon_flat = model.decode(flat, is_image)
+    assert torch.equal(recon, recon_flat)  # flat-id decode == 4-D-id decode
+    assert int(ids.max()) < 32768
+    sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        stage=stage, mode=mode, overrides=repr(overrides), batch=batch, frames=frames,
+        stride=stride, weight_seed=0, input_seed=1234,
+        state_crc=np.uint32(synth.state_checksum(sd)),
+        input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
+        ids=ids.numpy().astype(np.int16),
+        z=z.permute(0, 2, 3, 4, 1).contiguous().numpy(),  # b t h w c
+        emb=emb.permute(0, 2, 3, 4, 1).contiguous().numpy(),
+        recon=recon[sl].contiguous().numpy(),
+        recon_absmax=np.float32(recon.abs().max().item()),
+    )
+    print(f"{name}: ids {tuple(ids.shape)} uniq {ids.unique().numel()} recon {tuple(recon.shape)} "
+          f"absmax {recon.abs().max().item():.3f}")
+
+
+def make_vq_kat():
+    """Known-answer vectors for the quantizer alone, from the reference's Codebook.forward
+    (modules/codebook.py:76-143): random unit-norm z, un-normalised z, exact code rows, and
+    duplicated code rows (ties -> lowest index)."""
+    rh.install_stubs()
+    from OmniTokenizer.modules.codebook import Codebook
+    for n_codes in (8192, 16384):
+        rng = np.random.Generator(np.random.PCG64(77 + n_codes))
+        E = rng.standard_normal((n_codes, 8), dtype=np.float32)
+        E[n_codes // 2] = E[17]          # duplicates: ties must resolve to the lowest index
+        E[n_codes - 1] = E[17]
+        E[5] = E[3]
+        z = rng.standard_normal((6144, 8), dtype=np.float32)
+        z[:4096] /= np.linalg.norm(z[:4096], axis=1, keepdims=True)
+        z[4096:4160] = E[17]             # hits the triple tie
+        z[4160:4200] = E[3]              # hits the double tie
+        z[4200:4300] = E[rng.integers(0, n_codes, 100)]
+        z[4300:4400] *= 1e-3
+        z[4400:4500] *= 30.0
+        cb = Codebook(n_codes, 8).eval()
+        cb._need_init = False
+        cb.embeddings.data.copy_(torch.from_numpy(E))
+        zt = torch.from_numpy(z).reshape(6, 1, 32, 32, 8).permute(0, 4, 1, 2, 3).contiguous()
+        with torch.no_grad():
+            out = cb(zt)
+        ids = out["encodings"].reshape(-1).numpy()
+        assert (ids[4096:4160] == 17).all() and (ids[4160:4200] == 3).all()
+        np.savez_compressed(os.path.join(OUT, f"vq_kat_{n_codes}.npz"), z=z, codebook=E,
+                            ids=ids.astype(np.int16))
+        print(f"vq_kat_{n_codes}: uniq {np.unique(ids).size}")
+
+
+if __name__ == "__main__":
+    assert rh.reference_available(), "run in the build container (needs /root/reference)"
+    make_vq_kat()
+    for c in CASES:
+        run_case(*c)

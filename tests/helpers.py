@@ -1,0 +1,50 @@
+"""Shared helpers for the parity tests: rebuild a golden case's config/weights/inputs from the
+seeds stored in the fixture (tests/golden/make_golden.py wrote them)."""
+import ast
+import os
+import zlib
+
+import numpy as np
+import torch
+
+from omnitokenizer_amd import synth
+from omnitokenizer_amd.config import OmniTokConfig, make_args
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+E2E_CASES = ["s2_sdpa_r64_img", "s2_sdpa_r64_vid", "s2_sdpa_r64_vid9", "s1_legacy_r64_img",
+             "s1_legacy_r64_vid", "s1_sdpa_r64_img", "s2_sdpa_r128_vid_16k", "s2_sdpa_r256_img",
+             "s2_sdpa_r256_vid", "s1_legacy_r256_img"]
+SMALL_CASES = [c for c in E2E_CASES if "r64" in c]
+
+
+class GoldenCase:
+    def __init__(self, name):
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.name = name
+        self.stage = int(g["stage"])
+        self.mode = str(g["mode"])
+        self.overrides = ast.literal_eval(str(g["overrides"]))
+        self.batch = int(g["batch"])
+        self.frames = int(g["frames"])
+        self.stride = int(g["stride"])
+        self.is_image = self.frames == 1
+        self.args = make_args(self.stage, **self.overrides)
+        self.cfg = OmniTokConfig.from_args(self.args, attention_mode=self.mode)
+        self.sd = synth.synth_state_dict(self.cfg, seed=int(g["weight_seed"]))
+        assert synth.state_checksum(self.sd) == int(g["state_crc"]), \
+            "synthetic weight generator drifted from the golden fixtures"
+        res = self.cfg.resolution
+        seed = int(g["input_seed"])
+        self.x = (synth.synth_image(self.batch, res, seed) if self.is_image
+                  else synth.synth_video(self.batch, self.frames, res, seed))
+        assert zlib.crc32(self.x.numpy().tobytes()) == int(g["input_crc"]), "synthetic input drifted"
+        self.ids = torch.from_numpy(g["ids"].astype(np.int64))
+        self.z = torch.from_numpy(g["z"])          # b t h w c
+        self.emb = torch.from_numpy(g["emb"])      # b t h w c
+        self.recon = torch.from_numpy(g["recon"])  # strided
+        self.recon_absmax = float(g["recon_absmax"])
+
+    def strided(self, recon_full):
+        s = self.stride
+        return recon_full[..., ::s, ::s]

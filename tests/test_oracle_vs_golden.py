@@ -1,0 +1,72 @@
+"""CPU: pins the oracle (oracle/omnitok_oracle.py, oracle/vq_argmin.c) against the committed
+outputs of the reference itself (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import omnitok_oracle as orc
+from tests.helpers import GoldenCase, E2E_CASES, GOLDEN
+import os
+
+FAST = [c for c in E2E_CASES if "r256" not in c]
+
+
+@pytest.mark.parametrize("n_codes", [8192, 16384])
+def test_vq_c_oracle_matches_reference_kat(n_codes):
+    g = np.load(os.path.join(GOLDEN, f"vq_kat_{n_codes}.npz"))
+    ids = c_oracle.vq_argmin(g["z"], g["codebook"])
+    assert np.array_equal(ids, g["ids"].astype(np.int64))
+    # ties resolve to the lowest index (reference codebook.py:86, torch.argmin)
+    assert (ids[4096:4160] == 17).all() and (ids[4160:4200] == 3).all()
+
+
+@pytest.mark.parametrize("n_codes", [8192])
+def test_vq_torch_oracle_matches_reference_kat(n_codes):
+    g = np.load(os.path.join(GOLDEN, f"vq_kat_{n_codes}.npz"))
+    ids = orc.vq_argmin(torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"])).numpy()
+    assert np.array_equal(ids, g["ids"].astype(np.int64))
+
+
+@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"])
+def test_oracle_end_to_end_matches_reference(name):
+    c = GoldenCase(name)
+    with torch.no_grad():
+        taps = {}
+        ids = orc.encode(c.sd, c.x, c.is_image, c.cfg, taps=taps)
+        recon = orc.decode(c.sd, c.ids, c.is_image, c.cfg)
+    assert torch.equal(ids, c.ids), f"{(ids != c.ids).sum().item()} ids differ"
+    assert (taps["z"] - c.z).abs().max().item() < 2e-6
+    assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
+    # flat ids decode identically (reference omnitokenizer.py:272-286)
+    if c.cfg.resolution // c.cfg.patch_size == c.ids.shape[-1]:
+        recon_flat = orc.decode(c.sd, c.ids.reshape(c.ids.shape[0], -1), c.is_image, c.cfg)
+        assert torch.equal(recon_flat, recon)
+
+
+def test_oracle_vq_on_golden_z_is_bit_exact():
+    for name in FAST:
+        c = GoldenCase(name)
+        z = c.z.reshape(-1, c.z.shape[-1])
+        ids = c_oracle.vq_argmin(z.numpy(), c.sd["codebook.embeddings"].numpy())
+        assert np.array_equal(ids, c.ids.reshape(-1).numpy()), name
+
+
+def test_include_embeddings_matches_reference():
+    c = GoldenCase("s2_sdpa_r64_vid")
+    with torch.no_grad():
+        emb, ids = orc.encode(c.sd, c.x, c.is_image, c.cfg, include_embeddings=True)
+    assert torch.equal(ids, c.ids)
+    assert (emb.permute(0, 2, 3, 4, 1) - c.emb).abs().max().item() < 1e-6
+
+
+def test_bias_table_equals_pairwise_bias():
+    c = GoldenCase("s1_legacy_r64_img")
+    p = "encoder.enc_spatial_transformer.layers.0.1.spatial_rel_pos_bias"
+    h = w = 8
+    full = orc.continuous_position_bias(c.sd, p, h, w)
+    tab = orc.continuous_position_bias_table(c.sd, p, h, w)
+    ys, xs = np.divmod(np.arange(h * w), w)
+    dy = ys[:, None] - ys[None, :] + h - 1
+    dx = xs[:, None] - xs[None, :] + w - 1
+    assert torch.equal(full, tab[:, dy, dx])
