@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- patches/sec of OmniTokenizer encode+decode on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A step = one pass of the hot path over one batch already resident in HBM:
+    ids = encode(x_local) ; [N > 1: RCCL all-gather of the ids] ; pixels = decode(ids_local)
+Workload (config.workload): BASELINE config C3 -- B = 32 clips of 17x256x256 per GPU, stage-2
+(imagenet_k600) architecture, synthetic pixels + seeded random weights (no checkpoints offline).
+Weak scaling: every rank processes its own 32 clips (C4 = 256 clips on 8 GPUs); value = all
+ranks' patches / max-over-ranks time.  One patch = one latent token = one element of encode()'s id
+tensor (5120 per clip).  dtype f32: the path computes in fp32 like the reference.
+
+Extra objects on the JSON line (rank 0):
+  roofline      dominant kernel family, from HIP events recorded around every launch on the launch
+                stream in a separate profiled pass of the same step
+  kernels       per-family ms / achieved rate of that pass (spatial attention, VQ, ...)
+  cpu_baseline  the CPU oracle (a port of the reference's arithmetic on ATen/MKL) timed on this
+                host on a bounded sample (N = 1 only)
+  parity        id flips / pixel error / PSNR of the GPU path vs the oracle on that sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (C3: 32)")
+    ap.add_argument("--frames", type=int, default=17)
+    ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")  # RCCL on ROCm
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd import dist as od
+    from omnitokenizer_amd.config import OmniTokConfig
+
+    args = make_args(2, resolution=a.resolution)
+    cfg = OmniTokConfig.from_args(args)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = OmniTokenizer_VQGAN(args)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+
+    B = a.batch
+    is_image = a.frames == 1
+    # every rank generates its own shard (distinct seed): the batch is sharded by clip
+    base = (synth.synth_image(min(B, 4), a.resolution, seed=1234 + rank) if is_image
+            else synth.synth_video(min(B, 4), a.frames, a.resolution, seed=1234 + rank))
+    x = torch.cat([base] * (-(-B // base.shape[0])))[:B].cuda().contiguous()
+    n_total = B * world
+
+    def step():
+        ids_local = model.encode(x, is_image)
+        if world > 1:
+            ids_all = od.all_gather_ids(ids_local, n_total)     # the one collective of the path
+            lo, hi = od.shard_range(n_total, rank, world)
+            ids_local = ids_all[lo:hi].contiguous()
+        return ids_local, model.decode(ids_local, is_image)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ids, rec = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    tokens_per_clip = ids.numel() // B
+    value = n_total * tokens_per_clip * a.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- profiled pass: HIP events around every launch, on the launch stream ---------------
+        model.set_timing(True)
+        model.timing_report()
+        nprof = 2
+        for _ in range(nprof):
+            model.encode(x, is_image)
+            model.decode(ids, is_image)
+        rep = model.timing_report()
+        model.set_timing(False)
+        kernels = {}
+        for name, r in rep.items():
+            ms = r["ms"] / nprof
+            kernels[name] = dict(ms_per_step=round(ms, 4), launches_per_step=r["calls"] // nprof,
+                                 work_per_step=r["work"] / nprof)
+        mfma = {"gemm_ff_in", "gemm_ff_out", "gemm_qkv", "gemm_out", "gemm_patch", "gemm_pixels", "attn_spatial",
+                "attn_window", "vq_argmin"}
+        for name, k in kernels.items():
+            if k["ms_per_step"] > 0:
+                if name in mfma:
+                    k["tflops"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2)
+                    k["frac_f32_peak"] = round(k["tflops"] / PEAK_F32_TFLOPS, 4)
+                else:
+                    k["gbs"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9, 1)
+                    k["frac_hbm_peak"] = round(k["gbs"] / PEAK_HBM_GBS, 4)
+        dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+        dk = kernels[dom]
+        if dom in mfma:
+            per_launch_flops = dk["work_per_step"] / dk["launches_per_step"]
+            avg_ms = dk["ms_per_step"] / dk["launches_per_step"]
+            roofline = dict(kernel=dom, bound="mfma", achieved=round(per_launch_flops / (avg_ms * 1e-3) / 1e12, 2),
+                            peak=PEAK_F32_TFLOPS, unit="TFLOP/s", avg_launch_ms=round(avg_ms, 4),
+                            flops_per_launch=per_launch_flops, traffic=None)
+        else:
+            per_launch_bytes = dk["work_per_step"] / dk["launches_per_step"]
+            avg_ms = dk["ms_per_step"] / dk["launches_per_step"]
+            roofline = dict(kernel=dom, bound="hbm", achieved=round(per_launch_bytes / (avg_ms * 1e-3) / 1e9, 1),
+                            peak=PEAK_HBM_GBS, unit="GB/s", avg_launch_ms=round(avg_ms, 4),
+                            bytes_per_launch=per_launch_bytes, traffic=None)
+        roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+        # the two kernels north_star names, with its formulas
+        if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
+            L = B * tokens_per_clip
+            vq_bytes = L * 40 + cfg.n_codes * 32
+            kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3)
+                                                           / 1e9, 2)
+
+        out = {
+            "metric": "patches/sec encode+decode", "value": round(value, 1), "unit": "patches/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"C3: B={B}/GPU {a.frames}x{a.resolution}x{a.resolution} clips, stage-2 "
+                                   f"(imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes=8192), encode + "
+                                   f"{'RCCL id all-gather + ' if world > 1 else ''}decode",
+                       "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
+                       "parallelism": f"clip-sharded x{world}"},
+            "roofline": roofline, "kernels": kernels,
+            "workspace_gb": round(model.workspace_bytes() / 2**30, 2),
+        }
+
+        # ---- CPU baseline + parity on a bounded sample ---------------------------------------------
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import omnitok_oracle as orc
+            ncpu = os.cpu_count() or 1
+            torch.set_num_threads(ncpu)
+            xs = x[:1].cpu()
+            with torch.no_grad():
+                taps = {}
+                t = time.perf_counter()
+                ids_ref = orc.encode(sd, xs, is_image, cfg, taps=taps)
+                rec_ref = orc.decode(sd, ids_ref, is_image, cfg)
+                first = time.perf_counter() - t
+                reps, spent = 0, 0.0
+                while spent < a.cpu_seconds - first and reps < 20:
+                    t = time.perf_counter()
+                    orc.decode(sd, orc.encode(sd, xs, is_image, cfg), is_image, cfg)
+                    spent += time.perf_counter() - t
+                    reps += 1
+            per = spent / reps if reps else first
+            try:
+                cpu_model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+            except Exception:
+                cpu_model = "unknown"
+            out["cpu_baseline"] = {"value": round(tokens_per_clip / per, 1), "unit": "patches/s", "cores": ncpu,
+                                   "kind": "port", "cpu": cpu_model,
+                                   "sample": f"1 clip {a.frames}x{a.resolution}x{a.resolution} encode+decode, "
+                                             f"{reps} timed reps after 1 warm-up, torch CPU fp32 oracle "
+                                             f"(ATen/MKL, {ncpu} threads)"}
+            g_ids, g_z = model.encode(x[:1].contiguous(), is_image, return_latents=True)
+            g_rec = model.decode(ids_ref.cuda(), is_image).cpu()
+            out["parity"] = {"id_flips_vs_oracle": int((g_ids.cpu() != ids_ref).sum()), "ids": int(ids_ref.numel()),
+                             "z_max_abs_err": float((g_z.cpu() - taps["z"]).abs().max()),
+                             "pixel_max_abs_err": float((g_rec - rec_ref).abs().max()),
+                             "psnr_vs_ref_db": round(orc.psnr(g_rec, rec_ref), 2),
+                             "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

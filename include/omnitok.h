@@ -1,0 +1,247 @@
+/*
+ * omnitok.h -- C ABI of the MI355X-native OmniTokenizer encode/decode path.
+ *
+ * The reference (FoundationVision/OmniTokenizer) is pure Python and has no FFI: its boundary is
+ * the class OmniTokenizer_VQGAN (reference OmniTokenizer/omnitokenizer.py:63) with
+ *     encode(x, is_image, include_embeddings=False)   omnitokenizer.py:247-266
+ *     decode(encodings, is_image)                      omnitokenizer.py:268-317
+ * and a PyTorch state_dict as the weight format.  This header is what a binding
+ * for that path binds instead: plain device pointers, sizes and a hipStream_t, no torch types.
+ * omnitokenizer_amd/vqgan.py is the ctypes binding that mirrors the reference class on top of it
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (ids: int64) unless named host_*;
+ *  - all tensors are dense row-major in the layout stated per function;
+ *  - every launch goes to the given stream, no hidden synchronisation (workspace growth inside
+ *    omnitok_encode/decode is the one exception: it may hipMalloc);
+ *  - functions return 0 on success, a negative omnitok_status otherwise, and
+ *    omnitok_last_error() returns a thread-local description (the Python layer raises it as
+ *    RuntimeError/ValueError like the reference's asserts);
+ *  - inference only: no autograd, no training-time codebook updates (codebook.py:95-118).
+ */
+#ifndef OMNITOK_H
+#define OMNITOK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *omnitok_stream_t; /* hipStream_t */
+
+enum omnitok_status {
+    OMNITOK_OK = 0,
+    OMNITOK_ERR_INVALID = -1,     /* bad argument / unsupported shape   */
+    OMNITOK_ERR_HIP = -2,         /* a HIP runtime call failed          */
+    OMNITOK_ERR_STATE = -3,       /* engine not finalised / missing weight */
+    OMNITOK_ERR_UNSUPPORTED = -4  /* configuration outside the built path  */
+};
+
+const char *omnitok_last_error(void);
+/* "omnitok <version> gfx950 ..." */
+const char *omnitok_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-operator entry points (each is one HIP kernel family; the engine below chains them).
+ * They are exported so that every operator is parity-tested against the oracle on its own.
+ * ------------------------------------------------------------------------------------------ */
+
+/* y[out_row(m), :] = LayerNorm(x[m, :]) * gamma + beta   (beta may be NULL = 0; eps 1e-5)
+ * reference attention.py:73-80 (custom LayerNorm) and nn.LayerNorm (attention.py:163,
+ * omnitokenizer.py:809-821).  out_row(m) = (m / rows_per_group) * group_stride + group_offset
+ * + m % rows_per_group; pass rows_per_group = 0 for the identity map. dim % 4 == 0, dim <= 1024. */
+int omnitok_layernorm(const float *x, const float *gamma, const float *beta, float *y,
+                      int64_t rows, int dim, float eps,
+                      int64_t rows_per_group, int64_t group_stride, int64_t group_offset,
+                      omnitok_stream_t stream);
+
+/* Epilogue flags of omnitok_gemm */
+#define OMNITOK_GEMM_BIAS 1      /* + bias[n]                                               */
+#define OMNITOK_GEMM_RESIDUAL 2  /* + residual[m, n] (may alias c)                           */
+#define OMNITOK_GEMM_GEGLU 4     /* c[m, j] = gelu(acc[m, gate j]) * acc[m, value j]; weight  */
+                                 /* rows pre-interleaved by omnitok_pack_geglu_weight         */
+#define OMNITOK_GEMM_LEAKY 8     /* leaky_relu(., 0.1) after bias                              */
+
+/* c[M,N] = a[M,K] . w[N,K]^T (+epilogue), fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ * This is nn.Linear (y = x W^T + b) as used by every projection on the path
+ * (attention.py:164,167,271,287,386-393; omnitokenizer.py:146,158,810,819,1007,1013).
+ * K % 32 == 0; lda, ldw % 4 == 0; pointers 16-byte aligned. With GEGLU, N is the packed width
+ * (2 * padded inner) and c has N/2 columns.
+ * a_row(m) = (m / a_rows_per_group) * a_group_stride + a_group_offset + m % a_rows_per_group
+ * (0 = identity) lets the A operand be read from a strided group of token rows. */
+int omnitok_gemm(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                 const float *residual, int64_t ldr, float *c, int64_t ldc,
+                 int64_t M, int N, int K, int flags,
+                 int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
+                 omnitok_stream_t stream);
+
+/* Packs FeedForward's first Linear weight w1[2*inner, K] (value rows [0,inner), gate rows
+ * [inner, 2*inner), reference attention.py:153-156,164) into out[2*inner_pad, K]: 32-row blocks
+ * alternate value / gate, zero rows beyond inner.  inner_pad % 64 == 0. */
+int omnitok_pack_geglu_weight(const float *w1, int inner, int K, int inner_pad, float *out,
+                              omnitok_stream_t stream);
+
+/* Patch gather + first LayerNorm of the patch embedding (reference omnitokenizer.py:806-809 /
+ * 814-818): video[B,C,F,H,W] frames [f0, f0 + t*pt) -> out[B*t*(H/p)*(W/p), C*pt*p*p] with
+ * feature order (c, pt, p1, p2), each row layer-normalised with gamma/beta. */
+int omnitok_patchify_ln(const float *video, int B, int C, int F, int H, int W, int f0, int t,
+                        int pt, int p, const float *gamma, const float *beta, float eps,
+                        float *out, omnitok_stream_t stream);
+
+/* Inverse rearrange of to_pixels (reference omnitokenizer.py:1008-1009, 1015-1016):
+ * tok[B*t*(H/p)*(W/p), C*pt*p*p] -> video[B,C,F,H,W] frames [f0, f0 + t*pt). */
+int omnitok_unpatchify(const float *tok, int B, int C, int F, int H, int W, int f0, int t, int pt,
+                       int p, float *video, omnitok_stream_t stream);
+
+/* y = depthwise_conv3d_3x3x3(zero-pad(x viewed as [B,T,H,W,D])) + bias + x
+ * reference attention.py:298-338 (PEG) with the caller's residual (attention.py:667) fused.
+ * x is the raw contiguous token buffer whatever order it was written in.
+ * w27 is the conv weight [D,1,3,3,3] repacked to [27, D] by omnitok_pack_peg_weight.
+ * causal: frame padding (2,0) else (1,1).  D % 4 == 0.  y must not alias x. */
+int omnitok_peg3d(const float *x, const float *w27, const float *bias, float *y, int B, int T,
+                  int H, int W, int D, int causal, omnitok_stream_t stream);
+int omnitok_pack_peg_weight(const float *w, int D, float *w27, omnitok_stream_t stream);
+
+/* [B, A, C, D] -> [B, C, A, D] token-order transpose ('(b t)(h w) d' <-> '(b h w) t d',
+ * reference omnitokenizer.py:891-907, 1072-1084). D % 4 == 0. */
+int omnitok_transpose_tokens(const float *x, float *y, int64_t B, int64_t A, int64_t C, int D,
+                             omnitok_stream_t stream);
+
+/* cos/sin[N, dim_head/2] of the 2-D rotary table, reference attention.py:28-43. Host-computed
+ * into host_cos/host_sin (fp32). */
+int omnitok_rope_table(int n_tokens, int dim_head, float theta, float *host_cos, float *host_sin);
+
+/* In-place q/k preparation of Attention (reference attention.py:417-437): optional 2-D RoPE
+ * (cos/sin [N, 32], same table for all heads), l2norm over dim_head=64, * q_scale / k_scale[64];
+ * q additionally * scale (the SDPA scale 8, a power of two, folded exactly).
+ * q: rows x heads*64 (ld ldq), k: rows x heads*64 (ld ldk). cos may be NULL (no RoPE). */
+int omnitok_qk_prep(float *q, int64_t ldq, float *k, int64_t ldk, int64_t rows, int n_tokens,
+                    int heads, const float *cos, const float *sin, const float *q_scale,
+                    const float *k_scale, float scale, omnitok_stream_t stream);
+
+/* Full (non-causal) spatial attention over N tokens per sequence, flash-style on fp32 MFMA:
+ * out[b, n, h*64:(h+1)*64] = softmax(q k^T [+ bias]) v  with q,k already prepared by qk_prep.
+ * q[Bn*N, heads*64] (ldq), k/v rows with ld ldkv. bias_table: NULL (sdpa mode) or
+ * [(2*gh-1)*(2*gw-1), heads] ContinuousPositionBias table (entry (dy+gh-1, dx+gw-1) for query-key
+ * offset (dy,dx)) for legacy mode (attention.py:456-466), N == gh*gw.  N % 64 == 0. */
+int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv,
+                         float *out, int64_t ldo, int Bn, int N, int heads,
+                         const float *bias_table, int gh, int gw, omnitok_stream_t stream);
+
+/* WindowAttention core (reference attention.py:266-286): qkv[Bn*N, 3*heads*64] from LN(x),
+ * ws x ws (ws = 8) non-overlapping windows of the gh x gw grid, softmax(0.125 q k^T + bias) v.
+ * bias_dense[heads, 64(kv), 64(q)] = relative_position_bias_table gathered by
+ * relative_position_index (attention.py:277-281), transposed. out[Bn*N, heads*64]. */
+int omnitok_attn_window(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out,
+                        int64_t ldo, int Bn, int gh, int gw, int heads, omnitok_stream_t stream);
+
+/* Temporal attention (reference attention.py:402-486 with is_spatial=False): per (column, head)
+ * T tokens; l2norm, q/k scales and scale applied inside. causal: is_causal / causal mask;
+ * alibi_slopes: NULL (sdpa) or [heads] (legacy, attention.py:473-474). q[cols*T, heads*64]. */
+int omnitok_attn_temporal(const float *q, int64_t ldq, const float *k, const float *v,
+                          int64_t ldkv, float *out, int64_t ldo, int64_t cols, int T, int heads,
+                          const float *q_scale, const float *k_scale, float scale, int causal,
+                          const float *alibi_slopes, omnitok_stream_t stream);
+
+/* z[n, 0:cdim] = l2norm(x[n, :] . w[cdim, D]^T + b)   (reference omnitokenizer.py:143-148 +
+ * F.normalize :251-252; normalize skipped if l2 == 0).  cdim == 8, D % 64 == 0. */
+int omnitok_pre_vq(const float *x, const float *w, const float *b, float *z, int64_t n, int D,
+                   int cdim, int l2, omnitok_stream_t stream);
+
+/* Codebook preparation: packed[n_codes*8] = MFMA A-fragment order of E[n_codes, 8];
+ * ee[c] = sum_k E[c,k]^2 with sequential separately-rounded adds. */
+int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, float *packed, float *ee,
+                       omnitok_stream_t stream);
+
+/* ids[n] = argmin_c ( (sum_k z[n,k]^2 - sum_k (2 z[n,k]) E[c,k]) + ee[c] ), first minimum.
+ * Bit-exact restatement of reference modules/codebook.py:82-86 (see oracle/vq_argmin.c): the
+ * dot is a k-ordered fp32 FMA chain from 0 on v_mfma_f32_32x32x2_f32, the norms are sequential
+ * adds of rounded squares. n_codes % 32 == 0, cdim == 8. ids int64. */
+int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
+                      int64_t *ids, omnitok_stream_t stream);
+
+/* tok[n, :] = E[ids[n], :] . w[D, cdim]^T + b  (F.embedding + post_vq_conv, reference
+ * omnitokenizer.py:270, 156-160). Returns OMNITOK_ERR_INVALID through the status word
+ * err_flag[0] != 0 if an id is out of range (checked on device, reported at the next sync). */
+int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_codes, int cdim,
+                            const float *w, const float *b, float *tok, int64_t n, int D,
+                            int *err_flag, omnitok_stream_t stream);
+
+/* emb[b, c, t, h, w] = (E[ids] - z) + z  (straight-through value, codebook.py:120), from
+ * z[b,t,h,w,c] / ids[b,t,h,w]; thw = t*h*w. */
+int omnitok_vq_embed_st(const int64_t *ids, const float *z, const float *codebook, int cdim,
+                        int64_t B, int64_t thw, float *emb, omnitok_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: the whole encode()/decode() path behind one handle.
+ * ------------------------------------------------------------------------------------------ */
+
+typedef struct omnitok_engine omnitok_engine;
+
+typedef struct omnitok_config {
+    int resolution;            /* args.resolution (used for flat video ids, omnitokenizer.py:284) */
+    int image_channels;        /* 3 */
+    int patch_size;            /* 8 */
+    int temporal_patch_size;   /* 4 (stage 2) / 2 (stage 1) */
+    int dim;                   /* 512 */
+    int heads;                 /* 8 */
+    int dim_head;              /* 64 */
+    int ff_inner;              /* int(ff_mult * 2/3 * dim) = 1365 */
+    int window_size;           /* 8 */
+    int n_codes;               /* 8192 */
+    int codebook_dim;          /* 8 */
+    int l2_code;               /* 1 */
+    int spatial_rope;          /* 1: spatial_pos == "rope", 0: "rel" */
+    int legacy_attention;      /* 0: SDPA branch, 1: legacy einsum branch (attention.py:439) */
+    int causal_temporal;       /* --causal_in_temporal_transformer */
+    int causal_peg;            /* --causal_in_peg */
+    int temporal_depth;        /* 4 */
+    char enc_block[16];        /* "ttww" */
+    char dec_block[16];        /* "tttt" */
+} omnitok_config;
+
+int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine **out);
+void omnitok_engine_destroy(omnitok_engine *e);
+
+/* Copies one reference state_dict tensor (device fp32, or int64 for relative_position_index)
+ * into the engine under its reference key name, e.g.
+ * "encoder.enc_spatial_transformer.layers.0.1.to_q.weight". Unknown / off-path keys return 1
+ * (ignored), like load_state_dict(strict=False). */
+int omnitok_engine_set_weight(omnitok_engine *e, const char *name, const void *dev_ptr,
+                              const int64_t *shape, int ndim, int is_int64,
+                              omnitok_stream_t stream);
+/* Repacks weights (GEGLU interleave, PEG [27,D], codebook fragments, bias tables) and checks
+ * that every tensor the configuration needs was set. */
+int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t stream);
+/* number of required-but-missing keys; writes a '\n'-separated list into buf */
+int omnitok_engine_missing(omnitok_engine *e, char *buf, int buflen);
+
+/* VQGAN.encode: x[B,C,F,H,W] (is_image: F == 1, i.e. [B,C,H,W]) -> ids[B,T',H/p,W/p] int64,
+ * T' = 1 + (F-1)/pt. emb_out (optional, may be NULL): [B,cdim,T',h,w]. z_out (optional):
+ * pre-VQ latents [B,T',h,w,cdim]. */
+int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W,
+                   int64_t *ids_out, float *emb_out, float *z_out, omnitok_stream_t stream);
+
+/* VQGAN.decode: ids[B,T',h,w] -> pixels[B,C,F,h*p,w*p], F = 1 + (T'-1)*pt. */
+int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int h, int w,
+                   float *pixels_out, omnitok_stream_t stream);
+
+/* decode() checks ids against [0, n_codes) on the device; this reads the flag back
+ * (synchronises the stream) and returns OMNITOK_ERR_INVALID if any id was out of range --
+ * the reference raises IndexError from F.embedding (omnitokenizer.py:270). */
+int omnitok_engine_check_ids(omnitok_engine *e, omnitok_stream_t stream);
+
+int64_t omnitok_engine_workspace_bytes(omnitok_engine *e);
+
+/* Per-kernel timing: when enabled, every launch made by encode/decode is bracketed with HIP
+ * events on its stream; omnitok_engine_timing_report fills a '\n'-separated
+ * "name calls total_ms" list (synchronises). */
+int omnitok_engine_set_timing(omnitok_engine *e, int enabled);
+int omnitok_engine_timing_report(omnitok_engine *e, char *buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMNITOK_H */

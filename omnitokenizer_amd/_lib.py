@@ -1,0 +1,105 @@
+"""ctypes binding of include/omnitok.h (libomnitok.so).
+
+The HIP library is the product: if it is missing or fails to load this module raises -- there is
+no CPU or PyTorch fallback anywhere in the package.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char, c_char_p, c_float, c_int, c_int64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libomnitok.so")
+
+
+class OmnitokConfig(Structure):
+    _fields_ = [
+        ("resolution", c_int), ("image_channels", c_int), ("patch_size", c_int),
+        ("temporal_patch_size", c_int), ("dim", c_int), ("heads", c_int), ("dim_head", c_int),
+        ("ff_inner", c_int), ("window_size", c_int), ("n_codes", c_int), ("codebook_dim", c_int),
+        ("l2_code", c_int), ("spatial_rope", c_int), ("legacy_attention", c_int),
+        ("causal_temporal", c_int), ("causal_peg", c_int), ("temporal_depth", c_int),
+        ("enc_block", c_char * 16), ("dec_block", c_char * 16),
+    ]
+
+
+class OmnitokError(RuntimeError):
+    pass
+
+
+P = c_void_p
+I64 = c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/omnitok.h
+_PROTOS = {
+    "omnitok_layernorm": [P, P, P, P, I64, c_int, c_float, I64, I64, I64, P],
+    "omnitok_gemm": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P],
+    "omnitok_pack_geglu_weight": [P, c_int, c_int, c_int, P, P],
+    "omnitok_patchify_ln": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P],
+    "omnitok_unpatchify": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
+    "omnitok_peg3d": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
+    "omnitok_pack_peg_weight": [P, c_int, P, P],
+    "omnitok_transpose_tokens": [P, P, I64, I64, I64, c_int, P],
+    "omnitok_rope_table": [c_int, c_int, c_float, P, P],
+    "omnitok_qk_prep": [P, I64, P, I64, I64, c_int, c_int, P, P, P, P, c_float, P],
+    "omnitok_attn_spatial": [P, I64, P, P, I64, P, I64, c_int, c_int, c_int, P, c_int, c_int, P],
+    "omnitok_attn_window": [P, I64, P, P, I64, c_int, c_int, c_int, c_int, P],
+    "omnitok_attn_temporal": [P, I64, P, P, I64, P, I64, I64, c_int, c_int, P, P, c_float, c_int, P, P],
+    "omnitok_pre_vq": [P, P, P, P, I64, c_int, c_int, c_int, P],
+    "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
+    "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
+    "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
+    "omnitok_vq_embed_st": [P, P, P, c_int, I64, I64, P, P],
+    "omnitok_engine_create": [POINTER(OmnitokConfig), POINTER(P)],
+    "omnitok_engine_destroy": [P],
+    "omnitok_engine_set_weight": [P, c_char_p, P, POINTER(I64), c_int, c_int, P],
+    "omnitok_engine_finalize": [P, P],
+    "omnitok_engine_missing": [P, c_char_p, c_int],
+    "omnitok_encode": [P, P, c_int, c_int, c_int, c_int, P, P, P, P],
+    "omnitok_decode": [P, P, c_int, c_int, c_int, c_int, P, P],
+    "omnitok_engine_check_ids": [P, P],
+    "omnitok_engine_workspace_bytes": [P],
+    "omnitok_engine_set_timing": [P, c_int],
+    "omnitok_engine_timing_report": [P, c_char_p, c_int],
+    "omnitok_last_error": [],
+    "omnitok_version": [],
+}
+_RESTYPES = {"omnitok_last_error": c_char_p, "omnitok_version": c_char_p,
+             "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS)
+
+_lib = None
+
+
+def load():
+    """Loads libomnitok.so (building nothing: run `python omnitokenizer_amd/build.py` or
+    __graft_entry__.build() first)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmnitokError(
+            f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
+            "Build it with `python omnitokenizer_amd/build.py`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    """Raises on a negative status: ValueError for invalid arguments (the reference's asserts),
+    RuntimeError otherwise."""
+    if rc >= 0:
+        return rc
+    msg = load().omnitok_last_error().decode(errors="replace")
+    if rc == -1:
+        raise ValueError(msg)
+    if rc == -4:
+        raise NotImplementedError(msg)
+    raise OmnitokError(f"{what}: {msg} (status {rc})")

@@ -1,0 +1,408 @@
+// Spatial attention on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950:
+//   * qk_prep        -- RoPE(2-D) + l2norm + q/k scale, in place   (reference attention.py:417-437)
+//   * attn_spatial   -- full attention over N tokens, flash style  (attention.py:439-483)
+//   * attn_window    -- 8x8 window attention with rel-pos bias     (attention.py:254-293)
+//
+// MFMA formulation (both kernels).  Everything is computed TRANSPOSED so that all per-query
+// statistics are lane-local and P feeds the second MFMA without any cross-lane movement:
+//     S^T[kv][q] = K . Q^T        A = K fragment,  B = Q fragment      (32 MFMA per 32x32 tile)
+//     O^T[d][q]  = V^T . P^T      A = V fragment,  B = P = exp(S^T-m)  (32 MFMA per 32 kv x 64 d)
+// In the 32x32 C/D layout lane l owns column q = l&31 and rows (r&3)+8*(r>>2)+4*(l>>5); the B
+// operand of 32x32x2 wants from lane l the element [k = l>>5][j = l&31] -- exactly what the lane
+// already holds in accumulator register r when the two k-slots of that MFMA step are defined to be
+// kv = (r&3)+8*(r>>2) and kv+4.  So P is consumed straight from the S^T accumulators, the running
+// max / sum / rescale are per-lane scalars, and only one exchange with lane^32 per reduction is
+// needed.  The d (=64) contraction of S^T is split lane-wise: lanes 0-31 contribute d in [0,32),
+// lanes 32-63 d in [32,64), so every Q/K fragment is 32 contiguous floats (8 x 16-byte reads).
+// fp32 throughout: the reference computes this path in fp32 and the parity bar (ids bit-exact,
+// pixels 1e-4) does not survive bf16 (SURVEY.md section 7 "Hard parts").
+#include "common.h"
+
+namespace omnitok {
+
+// -------------------------------------------------------------------------------------------
+// qk_prep: one 16-lane row per (token, head); each lane owns 4 consecutive channels, so the RoPE
+// pairs (2j, 2j+1) are lane-local and the l2 norm is a 4-step DPP all-reduce.
+// -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void qk_prep_kernel(float *__restrict__ q, int64_t ldq, float *__restrict__ k,
+                                                      int64_t ldk, int64_t rows, int n_tokens, int heads,
+                                                      const float *__restrict__ cosT,
+                                                      const float *__restrict__ sinT,
+                                                      const float *__restrict__ q_scale,
+                                                      const float *__restrict__ k_scale, float scale) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;  // (row, head)
+    const int64_t ngrp = rows * heads;
+    if (grp >= ngrp) return;  // whole 16-lane rows exit together
+    const int64_t row = grp / heads;
+    const int head = (int)(grp % heads);
+    const int n = (int)(row % n_tokens);
+    float c0 = 1.f, c1 = 1.f, s0 = 0.f, s1 = 0.f;
+    if (cosT) {
+        c0 = cosT[n * 32 + 2 * l16]; c1 = cosT[n * 32 + 2 * l16 + 1];
+        s0 = sinT[n * 32 + 2 * l16]; s1 = sinT[n * 32 + 2 * l16 + 1];
+    }
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+        float *base = which == 0 ? q + row * ldq : k + row * ldk;
+        f32x4 *p = reinterpret_cast<f32x4 *>(base + head * 64 + l16 * 4);
+        f32x4 v = *p;
+        if (cosT) {  // (a + ib)(c + is) = (ac - bs) + i(as + bc), reference attention.py:65-69
+            const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+            v[0] = a0 * c0 - b0 * s0; v[1] = a0 * s0 + b0 * c0;
+            v[2] = a1 * c1 - b1 * s1; v[3] = a1 * s1 + b1 * c1;
+        }
+        float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        ss = row16_allsum(ss);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, attention.py:24-25
+        const f32x4 sc = *reinterpret_cast<const f32x4 *>((which == 0 ? q_scale : k_scale) + l16 * 4);
+        const float mul = which == 0 ? scale : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] * inv * sc[e] * mul;
+        *p = v;
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// Full spatial attention.  Workgroup = 4 waves = 128 queries of one (sequence, head); each wave
+// owns 32 queries.  K/V tiles of 64 keys are staged global -> registers -> LDS (double-buffered,
+// next tile's loads in flight during the current tile's 128 MFMAs).
+// -------------------------------------------------------------------------------------------
+constexpr int AT_KV = 64;        // keys per LDS tile
+constexpr int AT_LDK = 68;       // padded K row (floats): conflict-free ds_read_b128 fragments
+constexpr int AT_LDV = 64;
+constexpr int AT_STAGE_FLOATS = AT_KV * AT_LDK + AT_KV * AT_LDV;
+constexpr int AT_LDS_BYTES = 2 * AT_STAGE_FLOATS * 4;
+
+struct AttnParams {
+    const float *q; const float *k; const float *v; float *out;
+    int64_t ldq, ldkv, ldo;
+    int N, heads;
+    const float *bias_table;  // [(2gh-1)*(2gw-1), heads] or null
+    int gh, gw;
+};
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void attn_spatial_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int qb = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+    const int64_t seq_row0 = (int64_t)seq * p.N;
+    // N % 64 == 0 but not necessarily % 128: the last workgroup may have idle waves, which still
+    // take part in the cooperative K/V staging and barriers but store nothing
+    const bool wave_active = qb * 128 + wave * 32 < p.N;
+    const int q_local = wave_active ? qb * 128 + wave * 32 + r32 : r32;  // this lane's query
+
+    // Q fragment: 32 contiguous floats of this lane's query row, d in [hi*32, hi*32+32)
+    f32x4 qf[8];
+    {
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(p.q + (seq_row0 + q_local) * p.ldq + head * 64 + hi * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[j] = qp[j];
+    }
+    int qy = 0, qx = 0;
+    const float *btab = nullptr;
+    if constexpr (HAS_BIAS) {
+        qy = q_local / p.gw; qx = q_local % p.gw;
+        btab = p.bias_table + head;
+    }
+
+    // loader mapping: 64 rows x 16 float4 per matrix; thread -> row tid/16 + 16*i, col4 tid%16
+    const int lrow = tid >> 4, lc4 = tid & 15;
+    const float *kbase = p.k + seq_row0 * p.ldkv + head * 64 + lc4 * 4;
+    const float *vbase = p.v + seq_row0 * p.ldkv + head * 64 + lc4 * 4;
+    f32x4 rk[4], rv[4];
+    auto gload = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t off = (int64_t)(kv0 + lrow + 16 * i) * p.ldkv;
+            rk[i] = *reinterpret_cast<const f32x4 *>(kbase + off);
+            rv[i] = *reinterpret_cast<const f32x4 *>(vbase + off);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *Ks = smem + buf * AT_STAGE_FLOATS;
+        float *Vs = Ks + AT_KV * AT_LDK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4 *>(Ks + (lrow + 16 * i) * AT_LDK + lc4 * 4) = rk[i];
+            *reinterpret_cast<f32x4 *>(Vs + (lrow + 16 * i) * AT_LDV + lc4 * 4) = rv[i];
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = p.N / AT_KV;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload((t + 1) * AT_KV);
+        const float *Ks = smem + buf * AT_STAGE_FLOATS;
+        const float *Vs = Ks + AT_KV * AT_LDK;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // ---- S^T = K . Q^T for 32 keys x 32 queries -----------------------------------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+            const f32x4 *kp = reinterpret_cast<const f32x4 *>(Ks + (sub * 32 + r32) * AT_LDK + hi * 32);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 kf = kp[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[j][e], st, 0, 0, 0);
+            }
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * AT_KV + sub * 32 + mfma32_row(r, hi);
+                    const int ky = kv / p.gw, kx = kv % p.gw;
+                    st[r] += btab[((qy - ky + p.gh - 1) * (2 * p.gw - 1) + (qx - kx + p.gw - 1)) * p.heads];
+                }
+            }
+            // ---- online softmax (per-lane query) ------------------------------------------
+            float mx = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, swap32(mx));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = expf(st[r] - m_new);
+                ps += st[r];
+            }
+            ps += swap32(ps);
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            // ---- O^T += V^T . P^T -----------------------------------------------------------
+            // step r: k-slot 0 -> key (r&3)+8*(r>>2), k-slot 1 -> that + 4 (lanes 32-63)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *vrow = Vs + (sub * 32 + mfma32_row(r, hi)) * AT_LDV + r32;
+                ot[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], st[r], ot[0], 0, 0, 0);
+                ot[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], st[r], ot[1], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane owns q, d = dblk*32 + 8g + 4hi + (0..3) -----
+    if (!wave_active) return;
+    const float inv_l = 1.0f / l_run;
+    float *orow = p.out + (seq_row0 + q_local) * p.ldo + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[d][g * 4 + e] * inv_l;
+            *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+        }
+}
+
+// -------------------------------------------------------------------------------------------
+// Window attention: one wave per (window, head): 64 queries x 64 keys x 64 channels, operands
+// straight from global memory (each K/V element is used by exactly one wave), no LDS.
+// -------------------------------------------------------------------------------------------
+struct WinParams {
+    const float *qkv; int64_t ldqkv;
+    const float *bias_dense;  // [heads][64 kv][64 q]
+    float *out; int64_t ldo;
+    int gh, gw, heads, nwin_x, nwin;  // windows per row / per image
+};
+
+__device__ __forceinline__ int win_token(int wy, int wx, int idx, int gw) {
+    return (wy * 8 + (idx >> 3)) * gw + wx * 8 + (idx & 7);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_window_kernel(WinParams p, int64_t total_units) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (image, window, head)
+    if (unit >= total_units) return;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int head = (int)(unit % p.heads);
+    const int64_t wi = unit / p.heads;
+    const int win = (int)(wi % p.nwin);
+    const int64_t img = wi / p.nwin;
+    const int wy = win / p.nwin_x, wx = win % p.nwin_x;
+    const int64_t row0 = img * (int64_t)p.gh * p.gw;
+    const int hd = p.heads * 64;
+
+    // Q fragments for the two 32-query blocks
+    f32x4 qf[2][8];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int tok = win_token(wy, wx, qb * 32 + r32, p.gw);
+        const f32x4 *qp = reinterpret_cast<const f32x4 *>(p.qkv + (row0 + tok) * p.ldqkv + head * 64 + hi * 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[qb][j] = qp[j];
+    }
+    // S^T[kb][qb]: 4 tiles
+    f32x16 st[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+        const int tok = win_token(wy, wx, kb * 32 + r32, p.gw);
+        const f32x4 *kp =
+            reinterpret_cast<const f32x4 *>(p.qkv + (row0 + tok) * p.ldqkv + hd + head * 64 + hi * 32);
+        f32x4 kf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = kp[j];
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][qb][r] = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st[kb][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j][e], qf[qb][j][e], st[kb][qb], 0, 0, 0);
+        }
+    }
+    // softmax over the 64 keys of each query: logits = 0.125 * q.k + bias (attention.py:274-282)
+    const float *bh = p.bias_dense + (int64_t)head * 64 * 64;
+    float inv_l[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kb * 32 + mfma32_row(r, hi);
+                const float s = st[kb][qb][r] * 0.125f + bh[kv * 64 + qb * 32 + r32];
+                st[kb][qb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, swap32(mx));
+        float ps = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(st[kb][qb][r] - mx);
+                st[kb][qb][r] = e;
+                ps += e;
+            }
+        ps += swap32(ps);
+        inv_l[qb] = 1.0f / ps;
+    }
+    // O^T[dblk][qb] = V^T . P^T
+    f32x16 ot[2][2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][qb][r] = 0.0f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tok = win_token(wy, wx, kb * 32 + mfma32_row(r, hi), p.gw);
+            const float *vrow = p.qkv + (row0 + tok) * p.ldqkv + 2 * hd + head * 64 + r32;
+            const float v0 = vrow[0], v1 = vrow[32];
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                ot[0][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, st[kb][qb][r], ot[0][qb], 0, 0, 0);
+                ot[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[kb][qb][r], ot[1][qb], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int tok = win_token(wy, wx, qb * 32 + r32, p.gw);
+        float *orow = p.out + (row0 + tok) * p.ldo + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ot[d][qb][g * 4 + e] * inv_l[qb];
+                *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+            }
+    }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+extern "C" int omnitok_qk_prep(float *q, int64_t ldq, float *k, int64_t ldk, int64_t rows, int n_tokens, int heads,
+                               const float *cos, const float *sin, const float *q_scale, const float *k_scale,
+                               float scale, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(q && k && q_scale && k_scale, "qk_prep: null pointer");
+    OT_CHECK_ARG((cos == nullptr) == (sin == nullptr), "qk_prep: cos/sin must both be given or both null");
+    OT_CHECK_ARG(ldq % 4 == 0 && ldk % 4 == 0 && aligned16(q) && aligned16(k), "qk_prep: unaligned");
+    const int64_t threads = rows * heads * 16;
+    if (threads == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(qk_prep_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, q, ldq, k, ldk,
+                       rows, n_tokens, heads, cos, sin, q_scale, k_scale, scale);
+    OT_LAUNCH_CHECK("qk_prep");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv,
+                                    float *out, int64_t ldo, int Bn, int N, int heads, const float *bias_table,
+                                    int gh, int gw, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(q && k && v && out, "attn_spatial: null pointer");
+    OT_CHECK_ARG(N % 64 == 0 && N > 0, "attn_spatial: N=%d must be a multiple of 64 tokens", N);
+    OT_CHECK_ARG(!bias_table || gh * gw == N, "attn_spatial: bias grid %dx%d != N=%d", gh, gw, N);
+    OT_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
+                     aligned16(out), "attn_spatial: unaligned");
+    OT_CHECK_ARG(heads <= 65535 && Bn <= 65535, "attn_spatial: grid too large");
+    if (Bn == 0) return OMNITOK_OK;
+    AttnParams p;
+    p.q = q; p.k = k; p.v = v; p.out = out; p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.N = N; p.heads = heads;
+    p.bias_table = bias_table; p.gh = gh; p.gw = gw;
+    static bool attr_set = false;
+    if (!attr_set) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_spatial_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_spatial_kernel<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
+        attr_set = true;
+    }
+    dim3 grid((N + 127) / 128, heads, Bn);
+    if (bias_table)
+        hipLaunchKernelGGL(attn_spatial_kernel<true>, grid, dim3(256), AT_LDS_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<false>, grid, dim3(256), AT_LDS_BYTES, stream, p);
+    OT_LAUNCH_CHECK("attn_spatial");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_attn_window(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out,
+                                   int64_t ldo, int Bn, int gh, int gw, int heads, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(qkv && bias_dense && out, "attn_window: null pointer");
+    OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "attn_window: grid %dx%d not divisible by the 8x8 window", gh, gw);
+    OT_CHECK_ARG(ldqkv % 4 == 0 && ldo % 4 == 0 && aligned16(qkv) && aligned16(out), "attn_window: unaligned");
+    WinParams p;
+    p.qkv = qkv; p.ldqkv = ldqkv; p.bias_dense = bias_dense; p.out = out; p.ldo = ldo;
+    p.gh = gh; p.gw = gw; p.heads = heads; p.nwin_x = gw / 8; p.nwin = (gh / 8) * (gw / 8);
+    const int64_t total = (int64_t)Bn * p.nwin * heads;
+    if (total == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(attn_window_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, total);
+    OT_LAUNCH_CHECK("attn_window");
+    return OMNITOK_OK;
+}

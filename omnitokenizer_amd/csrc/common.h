@@ -1,0 +1,90 @@
+// Shared helpers for the gfx950 kernels of the OmniTokenizer encode/decode path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/omnitok.h"
+
+namespace omnitok {
+
+void set_error(const char *fmt, ...);
+
+#define OT_CHECK_ARG(cond, ...)                         \
+    do {                                                \
+        if (!(cond)) {                                  \
+            omnitok::set_error(__VA_ARGS__);            \
+            return OMNITOK_ERR_INVALID;                 \
+        }                                               \
+    } while (0)
+
+#define OT_HIP(call)                                                                     \
+    do {                                                                                 \
+        hipError_t _e = (call);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            omnitok::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e),    \
+                               __FILE__, __LINE__);                                      \
+            return OMNITOK_ERR_HIP;                                                      \
+        }                                                                                \
+    } while (0)
+
+#define OT_LAUNCH_CHECK(name)                                                            \
+    do {                                                                                 \
+        hipError_t _e = hipGetLastError();                                               \
+        if (_e != hipSuccess) {                                                          \
+            omnitok::set_error("launch of %s failed: %s", name, hipGetErrorString(_e));  \
+            return OMNITOK_ERR_HIP;                                                      \
+        }                                                                                \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- device helpers -----------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// DPP controls (gfx9): quad_perm 0x00-0xFF, row_half_mirror 0x141, row_mirror 0x140
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(
+        float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// all-reduce (sum) over each 16-lane row of the wave: 4 full-rate DPP adds, no LDS
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror
+    v += dpp_f32<0x140>(v);  // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ float row16_allmax(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+
+// full-wave (64 lanes) all-reduce sum
+__device__ __forceinline__ float wave_allsum(float v) {
+    v = row16_allsum(v);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+
+// value held by the partner lane (lane ^ 32)
+__device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32); }
+
+// row index inside a 32x32 MFMA C/D tile for accumulator register r of a lane in half `hi`
+// (cdna guide section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+#endif  // __HIPCC__
+
+}  // namespace omnitok

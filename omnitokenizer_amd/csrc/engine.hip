@@ -1,0 +1,828 @@
+// Engine: VQGAN.encode() / VQGAN.decode() as one native call each.
+//
+// Holds device copies of the reference state_dict tensors (by reference key name), the repacked
+// derivatives the kernels want (GEGLU-interleaved FF weights, [27,D] PEG weights, A-fragment
+// codebook, dense window bias, K-padded FF-out weight), a grow-only workspace, and chains the
+// per-operator kernels in the reference's order:
+//   encode: patch-embed -> spatial Transformer -> temporal Transformer -> pre_vq -> l2norm -> VQ
+//           (reference omnitokenizer.py:247-258, 919-947, 881-916)
+//   decode: embedding -> post_vq -> temporal Transformer -> spatial Transformer -> to_pixels
+//           (reference omnitokenizer.py:268-291, 1101-1118, 1059-1098)
+// Tokens are kept physically in the layout the reference has at each point ('(b t)(h w) d' for
+// spatial stages, '(b h w) t d' for temporal stages) so that PEG's raw-buffer view
+// (attention.py:319) is reproduced by construction.
+#include "common.h"
+
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+#include <iterator>
+
+namespace omnitok {
+
+struct DevTensor {
+    void *p = nullptr;
+    std::vector<int64_t> shape;
+    bool is_int64 = false;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct Buf {
+    float *p = nullptr;
+    int64_t cap = 0;  // floats
+};
+
+struct LayerT {  // 't' block (+ FF)
+    const float *peg_w27, *peg_b;
+    const float *ng, *nb;
+    const float *wq, *wkv, *wo;
+    const float *q_scale, *k_scale;
+    std::string bias_prefix;  // spatial_rel_pos_bias prefix ("" if none)
+};
+struct LayerW {  // 'w' block
+    const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;
+};
+struct LayerFF {
+    const float *lw, *lb, *w1p, *w2p;
+};
+struct Layer {
+    char kind;
+    LayerT t;
+    LayerW w;
+    LayerFF ff;
+};
+struct TransformerW {
+    std::vector<Layer> layers;
+    const float *og, *ob;
+};
+
+struct TimingRec {
+    std::string name;
+    hipEvent_t a, b;
+    double work;
+};
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+struct omnitok_engine {
+    omnitok_config cfg;
+    std::map<std::string, std::vector<int64_t>> spec;  // required key -> shape
+    std::map<std::string, DevTensor> w;
+    std::vector<void *> owned;  // derived buffers
+    bool finalized = false;
+    int inner_pad = 0;
+    TransformerW enc_s, enc_t, dec_s, dec_t;
+    // derived
+    float *cb_packed = nullptr, *cb_ee = nullptr, *alibi = nullptr;
+    std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
+    std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
+    // workspace
+    Buf X, X2, Y, QKV, AO, HD, Z;
+    int *err_flag = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimingRec> recs;
+    std::vector<hipEvent_t> pool;
+};
+
+namespace omnitok {
+
+static void add_transformer_spec(omnitok_engine *e, const std::string &prefix, const std::string &block,
+                                 bool rel) {
+    const omnitok_config &c = e->cfg;
+    const int64_t d = c.dim, hd = c.dim_head, heads = c.heads, inner = c.ff_inner, ws = c.window_size;
+    for (size_t i = 0; i < block.size(); ++i) {
+        const std::string p = prefix + ".layers." + std::to_string(i);
+        if (block[i] == 't') {
+            e->spec[p + ".0.dsconv.weight"] = {d, 1, 3, 3, 3};
+            e->spec[p + ".0.dsconv.bias"] = {d};
+            e->spec[p + ".1.q_scale"] = {hd};
+            e->spec[p + ".1.k_scale"] = {hd};
+            if (rel) {
+                e->spec[p + ".1.spatial_rel_pos_bias.net.0.0.weight"] = {d, 2};
+                e->spec[p + ".1.spatial_rel_pos_bias.net.0.0.bias"] = {d};
+                e->spec[p + ".1.spatial_rel_pos_bias.net.1.0.weight"] = {d, d};
+                e->spec[p + ".1.spatial_rel_pos_bias.net.1.0.bias"] = {d};
+                e->spec[p + ".1.spatial_rel_pos_bias.net.2.weight"] = {heads, d};
+                e->spec[p + ".1.spatial_rel_pos_bias.net.2.bias"] = {heads};
+            }
+            e->spec[p + ".1.norm.gamma"] = {d};
+            e->spec[p + ".1.norm.beta"] = {d};
+            e->spec[p + ".1.to_q.weight"] = {hd * heads, d};
+            e->spec[p + ".1.to_kv.weight"] = {2 * hd * heads, d};
+            e->spec[p + ".1.to_out.weight"] = {d, hd * heads};
+        } else {
+            e->spec[p + ".1.relative_position_bias_table"] = {(2 * ws - 1) * (2 * ws - 1), heads};
+            e->spec[p + ".1.relative_position_index"] = {ws * ws, ws * ws};
+            e->spec[p + ".1.norm.gamma"] = {d};
+            e->spec[p + ".1.norm.beta"] = {d};
+            e->spec[p + ".1.qkv.weight"] = {3 * d, d};
+            e->spec[p + ".1.proj.weight"] = {d, d};
+            e->spec[p + ".1.proj.bias"] = {d};
+        }
+        e->spec[p + ".3.0.weight"] = {d};
+        e->spec[p + ".3.0.bias"] = {d};
+        e->spec[p + ".3.1.weight"] = {2 * inner, d};
+        e->spec[p + ".3.4.weight"] = {d, inner};
+    }
+    e->spec[prefix + ".norm_out.gamma"] = {d};
+    e->spec[prefix + ".norm_out.beta"] = {d};
+}
+
+// keys that exist in the reference state_dict but are never read on the inference path
+static bool key_unused(const omnitok_engine *e, const std::string &k) {
+    if (k.find("context_norm") != std::string::npos) return true;
+    if (k == "codebook.N" || k == "codebook.z_avg" || k == "codebook.codebook_usage") return true;
+    // temporal transformers never use their spatial_rel_pos_bias; spatial ones only
+    // in legacy mode
+    if (k.find("spatial_rel_pos_bias") != std::string::npos) {
+        if (k.find("temporal_transformer") != std::string::npos) return true;
+        return !e->cfg.legacy_attention;
+    }
+    return false;
+}
+
+static int alloc_f(omnitok_engine *e, float **out, int64_t n) {
+    void *p = nullptr;
+    OT_HIP(hipMalloc(&p, (size_t)n * sizeof(float)));
+    e->owned.push_back(p);
+    *out = static_cast<float *>(p);
+    return OMNITOK_OK;
+}
+
+static int ensure(Buf &b, int64_t n) {
+    if (b.cap >= n) return OMNITOK_OK;
+    if (b.p) OT_HIP(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    void *p = nullptr;
+    OT_HIP(hipMalloc(&p, (size_t)n * sizeof(float)));
+    b.p = static_cast<float *>(p);
+    b.cap = n;
+    return OMNITOK_OK;
+}
+
+static const float *W(omnitok_engine *e, const std::string &k) {
+    auto it = e->w.find(k);
+    return it == e->w.end() ? nullptr : static_cast<const float *>(it->second.p);
+}
+
+// ---- timing -------------------------------------------------------------------------------
+struct Scope {
+    omnitok_engine *e;
+    hipStream_t s;
+    size_t idx;
+    bool on;
+    Scope(omnitok_engine *e_, hipStream_t s_, const char *name, double work) : e(e_), s(s_), on(e_->timing) {
+        if (!on) return;
+        TimingRec r;
+        r.name = name;
+        r.work = work;
+        for (hipEvent_t *ev : {&r.a, &r.b}) {
+            if (!e->pool.empty()) {
+                *ev = e->pool.back();
+                e->pool.pop_back();
+            } else {
+                (void)hipEventCreate(ev);
+            }
+        }
+        (void)hipEventRecord(r.a, s);
+        e->recs.push_back(r);
+        idx = e->recs.size() - 1;
+    }
+    ~Scope() {
+        if (on) (void)hipEventRecord(e->recs[idx].b, s);
+    }
+};
+
+#define OT_RUN(name, work, call)                  \
+    do {                                          \
+        Scope _sc(e, stream, name, (double)(work)); \
+        int _rc = (call);                         \
+        if (_rc != OMNITOK_OK) return _rc;        \
+    } while (0)
+
+__global__ void window_bias_dense_kernel(const float *__restrict__ table, const int64_t *__restrict__ index,
+                                         int heads, int ntok, float *__restrict__ dense) {
+    // dense[h][kv][q] = table[index[q][kv]][h]   (reference attention.py:277-281)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= heads * ntok * ntok) return;
+    const int q = idx % ntok, kv = (idx / ntok) % ntok, h = idx / (ntok * ntok);
+    dense[idx] = table[index[q * ntok + kv] * heads + h];
+}
+
+__global__ void pad_cols_kernel(const float *__restrict__ src, int rows, int cols, int cols_pad,
+                                float *__restrict__ dst) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * cols_pad) return;
+    const int r = (int)(idx / cols_pad), c = (int)(idx % cols_pad);
+    dst[idx] = c < cols ? src[(int64_t)r * cols + c] : 0.0f;
+}
+
+static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &prefix, const std::string &block,
+                             bool spatial, hipStream_t stream) {
+    const omnitok_config &c = e->cfg;
+    tw.layers.clear();
+    for (size_t i = 0; i < block.size(); ++i) {
+        const std::string p = prefix + ".layers." + std::to_string(i);
+        Layer L;
+        L.kind = block[i];
+        if (block[i] == 't') {
+            float *w27;
+            if (int rc = alloc_f(e, &w27, 27 * (int64_t)c.dim)) return rc;
+            if (int rc = omnitok_pack_peg_weight(W(e, p + ".0.dsconv.weight"), c.dim, w27, stream)) return rc;
+            L.t.peg_w27 = w27;
+            L.t.peg_b = W(e, p + ".0.dsconv.bias");
+            L.t.ng = W(e, p + ".1.norm.gamma");
+            L.t.nb = W(e, p + ".1.norm.beta");
+            L.t.wq = W(e, p + ".1.to_q.weight");
+            L.t.wkv = W(e, p + ".1.to_kv.weight");
+            L.t.wo = W(e, p + ".1.to_out.weight");
+            L.t.q_scale = W(e, p + ".1.q_scale");
+            L.t.k_scale = W(e, p + ".1.k_scale");
+            L.t.bias_prefix = (spatial && c.legacy_attention && !c.spatial_rope) ? p + ".1.spatial_rel_pos_bias" : "";
+        } else {
+            const int ntok = c.window_size * c.window_size;
+            float *dense;
+            if (int rc = alloc_f(e, &dense, (int64_t)c.heads * ntok * ntok)) return rc;
+            const int total = c.heads * ntok * ntok;
+            hipLaunchKernelGGL(window_bias_dense_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                               W(e, p + ".1.relative_position_bias_table"),
+                               static_cast<const int64_t *>(e->w[p + ".1.relative_position_index"].p), c.heads, ntok,
+                               dense);
+            OT_LAUNCH_CHECK("window_bias_dense");
+            L.w.ng = W(e, p + ".1.norm.gamma");
+            L.w.nb = W(e, p + ".1.norm.beta");
+            L.w.wqkv = W(e, p + ".1.qkv.weight");
+            L.w.wproj = W(e, p + ".1.proj.weight");
+            L.w.bproj = W(e, p + ".1.proj.bias");
+            L.w.bias_dense = dense;
+        }
+        float *w1p, *w2p;
+        if (int rc = alloc_f(e, &w1p, 2 * (int64_t)e->inner_pad * c.dim)) return rc;
+        if (int rc = omnitok_pack_geglu_weight(W(e, p + ".3.1.weight"), c.ff_inner, c.dim, e->inner_pad, w1p, stream))
+            return rc;
+        if (int rc = alloc_f(e, &w2p, (int64_t)c.dim * e->inner_pad)) return rc;
+        {
+            const int64_t total = (int64_t)c.dim * e->inner_pad;
+            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               W(e, p + ".3.4.weight"), c.dim, c.ff_inner, e->inner_pad, w2p);
+            OT_LAUNCH_CHECK("pad_cols");
+        }
+        L.ff.lw = W(e, p + ".3.0.weight");
+        L.ff.lb = W(e, p + ".3.0.bias");
+        L.ff.w1p = w1p;
+        L.ff.w2p = w2p;
+        tw.layers.push_back(L);
+    }
+    tw.og = W(e, prefix + ".norm_out.gamma");
+    tw.ob = W(e, prefix + ".norm_out.beta");
+    return OMNITOK_OK;
+}
+
+static int get_rope(omnitok_engine *e, int N, const float **cosp, const float **sinp, hipStream_t stream) {
+    auto it = e->rope.find(N);
+    if (it == e->rope.end()) {
+        const int half = e->cfg.dim_head / 2;
+        std::vector<float> hc((size_t)N * half), hs((size_t)N * half);
+        if (int rc = omnitok_rope_table(N, e->cfg.dim_head, 10000.0f, hc.data(), hs.data())) return rc;
+        float *dc, *ds;
+        if (int rc = alloc_f(e, &dc, (int64_t)N * half)) return rc;
+        if (int rc = alloc_f(e, &ds, (int64_t)N * half)) return rc;
+        // synchronous copies: the host vectors die at scope exit
+        OT_HIP(hipMemcpy(dc, hc.data(), hc.size() * 4, hipMemcpyHostToDevice));
+        OT_HIP(hipMemcpy(ds, hs.data(), hs.size() * 4, hipMemcpyHostToDevice));
+        it = e->rope.emplace(N, std::make_pair(dc, ds)).first;
+    }
+    *cosp = it->second.first;
+    *sinp = it->second.second;
+    return OMNITOK_OK;
+}
+
+// ContinuousPositionBias evaluated once per distinct (dy,dx) offset (reference attention.py:535-583;
+// the bias of a token pair depends only on its offset, :567-574): table[(2gh-1)*(2gw-1), heads].
+static int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, int gw, const float **out,
+                          hipStream_t stream) {
+    const std::string key = prefix + "|" + std::to_string(gh) + "|" + std::to_string(gw);
+    auto it = e->bias_tables.find(key);
+    if (it != e->bias_tables.end()) {
+        *out = it->second;
+        return OMNITOK_OK;
+    }
+    const omnitok_config &c = e->cfg;
+    const int P = (2 * gh - 1) * (2 * gw - 1);
+    // input features sign(d)*log(1+|d|), K padded 2 -> 32 for the GEMM's K % 32 rule
+    std::vector<float> feat((size_t)P * 32, 0.0f);
+    for (int dy = -(gh - 1); dy <= gh - 1; ++dy)
+        for (int dx = -(gw - 1); dx <= gw - 1; ++dx) {
+            const int i = (dy + gh - 1) * (2 * gw - 1) + (dx + gw - 1);
+            auto f = [](int d) {
+                const float s = d > 0 ? 1.0f : (d < 0 ? -1.0f : 0.0f);
+                return s * logf((float)std::abs(d) + 1.0f);
+            };
+            feat[(size_t)i * 32 + 0] = f(dy);
+            feat[(size_t)i * 32 + 1] = f(dx);
+        }
+    float *dfeat, *w0p, *h0, *h1, *tab;
+    if (int rc = alloc_f(e, &dfeat, (int64_t)P * 32)) return rc;
+    if (int rc = alloc_f(e, &w0p, (int64_t)c.dim * 32)) return rc;
+    if (int rc = alloc_f(e, &h0, (int64_t)P * c.dim)) return rc;
+    if (int rc = alloc_f(e, &h1, (int64_t)P * c.dim)) return rc;
+    if (int rc = alloc_f(e, &tab, (int64_t)P * c.heads)) return rc;
+    OT_HIP(hipMemcpy(dfeat, feat.data(), feat.size() * 4, hipMemcpyHostToDevice));
+    {
+        const int64_t total = (int64_t)c.dim * 32;
+        hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                           W(e, prefix + ".net.0.0.weight"), c.dim, 2, 32, w0p);
+        OT_LAUNCH_CHECK("pad_cols");
+    }
+    const int BL = OMNITOK_GEMM_BIAS | OMNITOK_GEMM_LEAKY;
+    if (int rc = omnitok_gemm(dfeat, 32, w0p, 32, W(e, prefix + ".net.0.0.bias"), nullptr, 0, h0, c.dim, P, c.dim, 32,
+                              BL, 0, 0, 0, stream))
+        return rc;
+    if (int rc = omnitok_gemm(h0, c.dim, W(e, prefix + ".net.1.0.weight"), c.dim, W(e, prefix + ".net.1.0.bias"),
+                              nullptr, 0, h1, c.dim, P, c.dim, c.dim, BL, 0, 0, 0, stream))
+        return rc;
+    if (int rc = omnitok_gemm(h1, c.dim, W(e, prefix + ".net.2.weight"), c.dim, W(e, prefix + ".net.2.bias"), nullptr,
+                              0, tab, c.heads, P, c.heads, c.dim, OMNITOK_GEMM_BIAS, 0, 0, 0, stream))
+        return rc;
+    e->bias_tables[key] = tab;
+    *out = tab;
+    return OMNITOK_OK;
+}
+
+// One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
+static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int gh, int gw, bool spatial,
+                           hipStream_t stream) {
+    const omnitok_config &c = e->cfg;
+    const int D = c.dim, heads = c.heads;
+    const int64_t L = (int64_t)B * T * gh * gw;
+    const int S = gh * gw;
+    const double gemm_f = 2.0 * (double)L * D;
+    for (const Layer &ly : tw.layers) {
+        if (ly.kind == 't') {
+            OT_RUN("peg3d", 2.0 * L * D * 4.0,
+                   omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
+            std::swap(e->X, e->X2);
+            OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                   omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+            float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
+            // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
+            OT_RUN("gemm_qkv", gemm_f * D,
+                   omnitok_gemm(e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
+            OT_RUN("gemm_qkv", gemm_f * 2 * D,
+                   omnitok_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
+                                stream));
+            if (spatial) {
+                const float *cosp = nullptr, *sinp = nullptr;
+                if (c.spatial_rope)
+                    if (int rc = get_rope(e, S, &cosp, &sinp, stream)) return rc;
+                OT_RUN("qk_prep", 4.0 * L * D * 4.0,
+                       omnitok_qk_prep(Q, D, KV, 2 * D, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
+                                       stream));
+                const float *bias = nullptr;
+                if (!ly.t.bias_prefix.empty())
+                    if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
+                OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
+                       omnitok_attn_spatial(Q, D, KV, KV + D, 2 * D, e->AO.p, D, B * T, S, heads, bias, gh, gw,
+                                            stream));
+            } else {
+                const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
+                OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
+                       omnitok_attn_temporal(Q, D, KV, KV + D, 2 * D, e->AO.p, D, (int64_t)B * S, T, heads,
+                                             ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi, stream));
+            }
+            OT_RUN("gemm_out", gemm_f * D,
+                   omnitok_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
+                                0, 0, 0, stream));
+        } else {
+            OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                   omnitok_layernorm(e->X.p, ly.w.ng, ly.w.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+            OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                   omnitok_gemm(e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                                stream));
+            OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
+                   omnitok_attn_window(e->QKV.p, 3 * D, ly.w.bias_dense, e->AO.p, D, B * T, gh, gw, heads, stream));
+            OT_RUN("gemm_out", gemm_f * D,
+                   omnitok_gemm(e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
+                                OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+        }
+        // FeedForward (reference attention.py:153-168)
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+        OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
+               omnitok_gemm(e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
+                            D, OMNITOK_GEMM_GEGLU, 0, 0, 0, stream));
+        OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
+               omnitok_gemm(e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+                            e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+    }
+    OT_RUN("layernorm", 2.0 * L * D * 4.0,
+           omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
+    std::swap(e->X, e->X2);
+    return OMNITOK_OK;
+}
+
+static int ensure_workspace(omnitok_engine *e, int64_t L) {
+    const omnitok_config &c = e->cfg;
+    const int D = c.dim;
+    const int kmax = c.image_channels * c.patch_size * c.patch_size * c.temporal_patch_size;
+    int64_t hdw = e->inner_pad;
+    if (kmax > hdw) hdw = kmax;
+    if (int rc = ensure(e->X, L * D)) return rc;
+    if (int rc = ensure(e->X2, L * D)) return rc;
+    if (int rc = ensure(e->Y, L * D)) return rc;
+    if (int rc = ensure(e->QKV, L * 3 * D)) return rc;
+    if (int rc = ensure(e->AO, L * D)) return rc;
+    if (int rc = ensure(e->HD, L * hdw)) return rc;
+    if (int rc = ensure(e->Z, L * 8)) return rc;
+    return OMNITOK_OK;
+}
+
+}  // namespace omnitok
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+
+extern "C" int omnitok_rope_table(int n_tokens, int dim_head, float theta, float *host_cos, float *host_sin) {
+    OT_CHECK_ARG(n_tokens > 0 && dim_head % 4 == 0 && host_cos && host_sin, "rope_table: bad arguments");
+    // reference attention.py:28-43: H = int(sqrt(N)); x = pos % H, y = pos // H;
+    // freqs_i = 1 / theta^(4i/dim) (fp32); angles (x*f_i, y*f_i) interleaved; cos/sin via polar
+    const int H = (int)std::sqrt((double)n_tokens);
+    const int nf = dim_head / 4, half = dim_head / 2;
+    std::vector<float> freqs(nf);
+    for (int i = 0; i < nf; ++i) freqs[i] = 1.0f / powf(theta, (float)(4 * i) / (float)dim_head);
+    for (int n = 0; n < n_tokens; ++n) {
+        const float xp = (float)(n % H), yp = (float)(n / H);
+        for (int i = 0; i < nf; ++i) {
+            const float ax = xp * freqs[i], ay = yp * freqs[i];  // fp32 products like torch.outer
+            host_cos[(size_t)n * half + 2 * i] = (float)std::cos((double)ax);
+            host_sin[(size_t)n * half + 2 * i] = (float)std::sin((double)ax);
+            host_cos[(size_t)n * half + 2 * i + 1] = (float)std::cos((double)ay);
+            host_sin[(size_t)n * half + 2 * i + 1] = (float)std::sin((double)ay);
+        }
+    }
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine **out) {
+    OT_CHECK_ARG(cfg && out, "engine_create: null pointer");
+    const omnitok_config &c = *cfg;
+    if (c.dim_head != 64 || c.dim != c.heads * c.dim_head || c.dim % 128 != 0) {
+        set_error("engine_create: kernels are built for dim_head == 64, dim == heads*64, dim %% 128 == 0");
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    if (c.codebook_dim != 8 || c.n_codes % 32 != 0 || c.n_codes > 32768) {
+        set_error("engine_create: need codebook_dim == 8 and n_codes %% 32 == 0 (<= 32768)");
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    if (c.window_size != 8) {
+        set_error("engine_create: window attention is built for twod_window_size == 8 (got %d)", c.window_size);
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    if (c.patch_size % 4 != 0 || (c.image_channels * c.patch_size * c.patch_size) % 32 != 0) {
+        set_error("engine_create: patch_size %d unsupported", c.patch_size);
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    const std::string eb(c.enc_block), db(c.dec_block);
+    for (char ch : eb + db)
+        if (ch != 't' && ch != 'w') {
+            set_error("engine_create: block type '%c' (pooling/upsampling, reference attention.py:631-647) not built", ch);
+            return OMNITOK_ERR_UNSUPPORTED;
+        }
+    omnitok_engine *e = new omnitok_engine();
+    e->cfg = c;
+    e->inner_pad = ((c.ff_inner + 63) / 64) * 64;
+    if (e->inner_pad % 32 != 0) e->inner_pad = ((e->inner_pad + 31) / 32) * 32;
+    const int64_t d = c.dim, k0 = (int64_t)c.image_channels * c.patch_size * c.patch_size,
+                  k1 = k0 * c.temporal_patch_size;
+    const char *names[2] = {"to_patch_emb_first_frame", "to_patch_emb"};
+    const int64_t ks[2] = {k0, k1};
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = std::string("encoder.") + names[i];
+        e->spec[p + ".1.weight"] = {ks[i]};
+        e->spec[p + ".1.bias"] = {ks[i]};
+        e->spec[p + ".2.weight"] = {d, ks[i]};
+        e->spec[p + ".2.bias"] = {d};
+        e->spec[p + ".3.weight"] = {d};
+        e->spec[p + ".3.bias"] = {d};
+    }
+    const std::string tb(c.temporal_depth, 't');
+    add_transformer_spec(e, "encoder.enc_spatial_transformer", eb, !c.spatial_rope);
+    add_transformer_spec(e, "encoder.enc_temporal_transformer", tb, false);
+    add_transformer_spec(e, "decoder.dec_spatial_transformer", db, !c.spatial_rope);
+    add_transformer_spec(e, "decoder.dec_temporal_transformer", tb, false);
+    e->spec["decoder.to_pixels_first_frame.0.weight"] = {k0, d};
+    e->spec["decoder.to_pixels_first_frame.0.bias"] = {k0};
+    e->spec["decoder.to_pixels.0.weight"] = {k1, d};
+    e->spec["decoder.to_pixels.0.bias"] = {k1};
+    e->spec["codebook.embeddings"] = {c.n_codes, c.codebook_dim};
+    e->spec["pre_vq_conv.1.weight"] = {c.codebook_dim, d};
+    e->spec["pre_vq_conv.1.bias"] = {c.codebook_dim};
+    e->spec["post_vq_conv.1.weight"] = {d, c.codebook_dim};
+    e->spec["post_vq_conv.1.bias"] = {d};
+    // drop keys the inference path never reads
+    for (auto it = e->spec.begin(); it != e->spec.end();)
+        it = key_unused(e, it->first) ? e->spec.erase(it) : std::next(it);
+    *out = e;
+    return OMNITOK_OK;
+}
+
+extern "C" void omnitok_engine_destroy(omnitok_engine *e) {
+    if (!e) return;
+    for (auto &kv : e->w)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (void *p : e->owned) (void)hipFree(p);
+    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z})
+        if (b->p) (void)hipFree(b->p);
+    if (e->err_flag) (void)hipFree(e->err_flag);
+    for (auto &r : e->recs) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" int omnitok_engine_set_weight(omnitok_engine *e, const char *name, const void *dev_ptr,
+                                         const int64_t *shape, int ndim, int is_int64, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e && name && dev_ptr && shape, "set_weight: null pointer");
+    auto it = e->spec.find(name);
+    if (it == e->spec.end()) return 1;  // off-path / unused key: ignored like strict=False
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (shp != it->second) {
+        std::string want, got;
+        for (auto s : it->second) want += std::to_string(s) + ",";
+        for (auto s : shp) got += std::to_string(s) + ",";
+        set_error("set_weight: size mismatch for %s: expected [%s] got [%s]", name, want.c_str(), got.c_str());
+        return OMNITOK_ERR_INVALID;
+    }
+    const bool want_i64 = std::string(name).find("relative_position_index") != std::string::npos;
+    OT_CHECK_ARG(want_i64 == (is_int64 != 0), "set_weight: dtype mismatch for %s", name);
+    DevTensor &t = e->w[name];
+    t.shape = shp;
+    t.is_int64 = want_i64;
+    const size_t bytes = (size_t)t.numel() * (want_i64 ? 8 : 4);
+    if (!t.p) OT_HIP(hipMalloc(&t.p, bytes));
+    OT_HIP(hipMemcpyAsync(t.p, dev_ptr, bytes, hipMemcpyDeviceToDevice, stream));
+    e->finalized = false;
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_engine_missing(omnitok_engine *e, char *buf, int buflen) {
+    int n = 0;
+    std::string s;
+    for (auto &kv : e->spec)
+        if (!e->w.count(kv.first)) {
+            ++n;
+            s += kv.first + "\n";
+        }
+    if (buf && buflen > 0) {
+        strncpy(buf, s.c_str(), buflen - 1);
+        buf[buflen - 1] = 0;
+    }
+    return n;
+}
+
+extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e, "finalize: null engine");
+    for (auto &kv : e->spec)
+        if (!e->w.count(kv.first)) {
+            set_error("finalize: missing weight %s", kv.first.c_str());
+            return OMNITOK_ERR_STATE;
+        }
+    // (re)build derived buffers
+    OT_HIP(hipStreamSynchronize(stream));
+    for (void *p : e->owned) (void)hipFree(p);
+    e->owned.clear();
+    e->rope.clear();
+    e->bias_tables.clear();
+    const omnitok_config &c = e->cfg;
+    const std::string tb(c.temporal_depth, 't');
+    if (int rc = build_transformer(e, e->enc_s, "encoder.enc_spatial_transformer", c.enc_block, true, stream)) return rc;
+    if (int rc = build_transformer(e, e->enc_t, "encoder.enc_temporal_transformer", tb, false, stream)) return rc;
+    if (int rc = build_transformer(e, e->dec_s, "decoder.dec_spatial_transformer", c.dec_block, true, stream)) return rc;
+    if (int rc = build_transformer(e, e->dec_t, "decoder.dec_temporal_transformer", tb, false, stream)) return rc;
+    if (int rc = alloc_f(e, &e->cb_packed, (int64_t)c.n_codes * 8)) return rc;
+    if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
+    if (int rc = omnitok_vq_prepare(W(e, "codebook.embeddings"), c.n_codes, 8, e->cb_packed, e->cb_ee, stream)) return rc;
+    {
+        // ALiBi slopes, reference attention.py:506-517 (_get_slopes)
+        std::vector<float> sl;
+        auto pow2 = [](int n) {
+            std::vector<double> v;
+            const double start = std::pow(2.0, -std::pow(2.0, -(std::log2((double)n) - 3.0)));
+            for (int i = 0; i < n; ++i) v.push_back(start * std::pow(start, i));
+            return v;
+        };
+        const int h = c.heads;
+        if ((h & (h - 1)) == 0) {
+            for (double v : pow2(h)) sl.push_back((float)v);
+        } else {
+            int cp = 1;
+            while (cp * 2 <= h) cp *= 2;
+            for (double v : pow2(cp)) sl.push_back((float)v);
+            auto ext = pow2(2 * cp);
+            for (int i = 0; (int)sl.size() < h; i += 2) sl.push_back((float)ext[i]);
+        }
+        if (int rc = alloc_f(e, &e->alibi, h)) return rc;
+        OT_HIP(hipMemcpy(e->alibi, sl.data(), h * 4, hipMemcpyHostToDevice));
+    }
+    if (!e->err_flag) {
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->err_flag), sizeof(int)));
+        OT_HIP(hipMemset(e->err_flag, 0, sizeof(int)));
+    }
+    e->finalized = true;
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int64_t *ids_out,
+                              float *emb_out, float *z_out, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e && x && ids_out, "encode: null pointer");
+    if (!e->finalized) {
+        set_error("encode: engine not finalised (load the weights first)");
+        return OMNITOK_ERR_STATE;
+    }
+    const omnitok_config &c = e->cfg;
+    const int p = c.patch_size, pt = c.temporal_patch_size, D = c.dim, C = c.image_channels;
+    // reference omnitokenizer.py:931-932
+    OT_CHECK_ARG(F >= 1 && (F - 1) % pt == 0,
+                 "number of frames (%d) minus one (%d) must be divisible by temporal patch size (%d)", F, F - 1, pt);
+    OT_CHECK_ARG(H % p == 0 && W_ % p == 0, "image size %dx%d not divisible by patch size %d", H, W_, p);
+    const int gh = H / p, gw = W_ / p, S = gh * gw, T = 1 + (F - 1) / pt;
+    OT_CHECK_ARG(S % 64 == 0, "encode: %d tokens per frame; spatial attention needs a multiple of 64", S);
+    OT_CHECK_ARG(gh == gw, "encode: the reference assumes a square token grid (int(sqrt(N)), attention.py:261)");
+    if (std::string(c.enc_block).find('w') != std::string::npos)
+        OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "encode: token grid %dx%d not divisible by the 8x8 window", gh, gw);
+    if (B == 0) return OMNITOK_OK;
+    const int64_t L = (int64_t)B * T * S;
+    if (int rc = ensure_workspace(e, L)) return rc;
+    const int K0 = C * p * p, K1 = K0 * pt;
+
+    // ---- patch embedding (reference omnitokenizer.py:806-822, 934-945) ----------------------
+    OT_RUN("patchify_ln", ((double)B * S * K0) * 8.0,
+           omnitok_patchify_ln(x, B, C, F, H, W_, 0, 1, 1, p, W(e, "encoder.to_patch_emb_first_frame.1.weight"),
+                               W(e, "encoder.to_patch_emb_first_frame.1.bias"), 1e-5f, e->HD.p, stream));
+    OT_RUN("gemm_patch", 2.0 * B * S * (double)K0 * D,
+           omnitok_gemm(e->HD.p, K0, W(e, "encoder.to_patch_emb_first_frame.2.weight"), K0,
+                        W(e, "encoder.to_patch_emb_first_frame.2.bias"), nullptr, 0, e->AO.p, D, (int64_t)B * S, D, K0,
+                        OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+    OT_RUN("layernorm", 2.0 * B * S * D * 4.0,
+           omnitok_layernorm(e->AO.p, W(e, "encoder.to_patch_emb_first_frame.3.weight"),
+                             W(e, "encoder.to_patch_emb_first_frame.3.bias"), e->X.p, (int64_t)B * S, D, 1e-5f, S,
+                             (int64_t)T * S, 0, stream));
+    if (T > 1) {
+        const int64_t M1 = (int64_t)B * (T - 1) * S;
+        OT_RUN("patchify_ln", ((double)M1 * K1) * 8.0,
+               omnitok_patchify_ln(x, B, C, F, H, W_, 1, T - 1, pt, p, W(e, "encoder.to_patch_emb.1.weight"),
+                                   W(e, "encoder.to_patch_emb.1.bias"), 1e-5f, e->HD.p, stream));
+        OT_RUN("gemm_patch", 2.0 * M1 * (double)K1 * D,
+               omnitok_gemm(e->HD.p, K1, W(e, "encoder.to_patch_emb.2.weight"), K1, W(e, "encoder.to_patch_emb.2.bias"),
+                            nullptr, 0, e->AO.p, D, M1, D, K1, OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+        OT_RUN("layernorm", 2.0 * M1 * D * 4.0,
+               omnitok_layernorm(e->AO.p, W(e, "encoder.to_patch_emb.3.weight"), W(e, "encoder.to_patch_emb.3.bias"),
+                                 e->X.p, M1, D, 1e-5f, (int64_t)(T - 1) * S, (int64_t)T * S, S, stream));
+    }
+    // ---- spatial then temporal transformer (reference omnitokenizer.py:891-903) -------------
+    if (int rc = run_transformer(e, e->enc_s, B, T, gh, gw, true, stream)) return rc;
+    if (T > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    if (int rc = run_transformer(e, e->enc_t, B, T, gh, gw, false, stream)) return rc;
+    if (T > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    // ---- pre_vq + l2norm + nearest code (reference omnitokenizer.py:248-255) ----------------
+    OT_RUN("pre_vq", (double)L * D * 4.0,
+           omnitok_pre_vq(e->X.p, W(e, "pre_vq_conv.1.weight"), W(e, "pre_vq_conv.1.bias"), e->Z.p, L, D, 8, c.l2_code,
+                          stream));
+    OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+           omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
+    if (emb_out)
+        OT_RUN("vq_embed_st", (double)L * 8 * 8.0,
+               omnitok_vq_embed_st(ids_out, e->Z.p, W(e, "codebook.embeddings"), 8, B, (int64_t)T * S, emb_out, stream));
+    if (z_out) OT_HIP(hipMemcpyAsync(z_out, e->Z.p, (size_t)L * 8 * 4, hipMemcpyDeviceToDevice, stream));
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int gh, int gw, float *pixels_out,
+                              omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e && ids && pixels_out, "decode: null pointer");
+    if (!e->finalized) {
+        set_error("decode: engine not finalised (load the weights first)");
+        return OMNITOK_ERR_STATE;
+    }
+    const omnitok_config &c = e->cfg;
+    const int p = c.patch_size, pt = c.temporal_patch_size, D = c.dim, C = c.image_channels;
+    const int S = gh * gw;
+    OT_CHECK_ARG(T >= 1 && S % 64 == 0 && gh == gw, "decode: unsupported token grid %dx%dx%d", T, gh, gw);
+    if (std::string(c.dec_block).find('w') != std::string::npos)
+        OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "decode: token grid %dx%d not divisible by the 8x8 window", gh, gw);
+    if (B == 0) return OMNITOK_OK;
+    const int64_t L = (int64_t)B * T * S;
+    if (int rc = ensure_workspace(e, L)) return rc;
+    const int K0 = C * p * p, K1 = K0 * pt;
+    const int H = gh * p, W_ = gw * p, F = 1 + (T - 1) * pt;
+
+    OT_RUN("dequant_post_vq", (double)L * D * 4.0,
+           omnitok_dequant_post_vq(ids, W(e, "codebook.embeddings"), c.n_codes, 8, W(e, "post_vq_conv.1.weight"),
+                                   W(e, "post_vq_conv.1.bias"), e->X.p, L, D, e->err_flag, stream));
+    // temporal first on decode (reference omnitokenizer.py:1072-1084)
+    if (T > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    if (int rc = run_transformer(e, e->dec_t, B, T, gh, gw, false, stream)) return rc;
+    if (T > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    if (int rc = run_transformer(e, e->dec_s, B, T, gh, gw, true, stream)) return rc;
+    // ---- to_pixels (reference omnitokenizer.py:1006-1017, 1089-1096) -------------------------
+    OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,
+           omnitok_gemm(e->X.p, D, W(e, "decoder.to_pixels_first_frame.0.weight"), D,
+                        W(e, "decoder.to_pixels_first_frame.0.bias"), nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
+                        OMNITOK_GEMM_BIAS, S, (int64_t)T * S, 0, stream));
+    OT_RUN("unpatchify", (double)B * S * K0 * 8.0,
+           omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 0, 1, 1, p, pixels_out, stream));
+    if (T > 1) {
+        const int64_t M1 = (int64_t)B * (T - 1) * S;
+        OT_RUN("gemm_pixels", 2.0 * M1 * (double)K1 * D,
+               omnitok_gemm(e->X.p, D, W(e, "decoder.to_pixels.0.weight"), D, W(e, "decoder.to_pixels.0.bias"), nullptr,
+                            0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS, (int64_t)(T - 1) * S, (int64_t)T * S, S,
+                            stream));
+        OT_RUN("unpatchify", (double)M1 * K1 * 8.0,
+               omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T - 1, pt, p, pixels_out, stream));
+    }
+    return OMNITOK_OK;
+}
+
+extern "C" int64_t omnitok_engine_workspace_bytes(omnitok_engine *e) {
+    int64_t n = 0;
+    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z}) n += b->cap * 4;
+    return n;
+}
+
+extern "C" int omnitok_engine_set_timing(omnitok_engine *e, int enabled) {
+    OT_CHECK_ARG(e, "set_timing: null engine");
+    e->timing = enabled != 0;
+    return OMNITOK_OK;
+}
+
+// returns the decode-side id range check of the last decode calls (1 = an id was out of range)
+extern "C" int omnitok_engine_check_ids(omnitok_engine *e, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int flag = 0;
+    OT_HIP(hipMemcpyAsync(&flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    OT_HIP(hipStreamSynchronize(stream));
+    if (flag) {
+        OT_HIP(hipMemsetAsync(e->err_flag, 0, sizeof(int), stream));
+        set_error("decode: token id out of range [0, %d)", e->cfg.n_codes);
+        return OMNITOK_ERR_INVALID;
+    }
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_engine_timing_report(omnitok_engine *e, char *buf, int buflen) {
+    OT_CHECK_ARG(e && buf && buflen > 0, "timing_report: bad arguments");
+    OT_HIP(hipDeviceSynchronize());
+    struct Acc { int calls = 0; double ms = 0, work = 0; };
+    std::map<std::string, Acc> acc;
+    for (auto &r : e->recs) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        Acc &a = acc[r.name];
+        a.calls++;
+        a.ms += ms;
+        a.work += r.work;
+        e->pool.push_back(r.a);
+        e->pool.push_back(r.b);
+    }
+    e->recs.clear();
+    std::string s;
+    char line[256];
+    for (auto &kv : acc) {
+        snprintf(line, sizeof(line), "%s %d %.6f %.6e\n", kv.first.c_str(), kv.second.calls, kv.second.ms,
+                 kv.second.work);
+        s += line;
+    }
+    strncpy(buf, s.c_str(), buflen - 1);
+    buf[buflen - 1] = 0;
+    return OMNITOK_OK;
+}

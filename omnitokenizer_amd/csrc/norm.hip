@@ -1,0 +1,218 @@
+// HBM-bound row kernels: LayerNorm, patch gather + LayerNorm, un-patchify scatter and the
+// token-order transpose.  One wave64 per row, 16-byte accesses, no LDS.
+#include "common.h"
+
+namespace omnitok {
+
+constexpr int LN_MAX_V4 = 4;  // up to 4 float4 per lane -> dim <= 1024
+
+// mean / rstd of a row held as nv float4 per lane (two-pass: mean, then centred sum of squares)
+__device__ __forceinline__ void row_stats(const f32x4 *v, int nv, int lane, int dim, float eps, float &mean,
+                                          float &rstd) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    s = wave_allsum(s);
+    mean = s / (float)dim;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean, c = v[i][2] - mean, d = v[i][3] - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    q = wave_allsum(q);
+    rstd = 1.0f / sqrtf(q / (float)dim + eps);
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, float *__restrict__ y,
+                                                        int64_t rows, int dim, float eps, int64_t rpg,
+                                                        int64_t gstride, int64_t goff) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = (dim / 4 + 63) / 64;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = xr[lane + 64 * i];
+    float mean, rstd;
+    row_stats(v, nv, lane, dim, eps, mean, rstd);
+    int64_t orow = row;
+    if (rpg > 0) orow = (row / rpg) * gstride + goff + (row % rpg);
+    f32x4 *yr = reinterpret_cast<f32x4 *>(y + orow * dim);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) {
+            const f32x4 g = g4[lane + 64 * i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e];
+            if (beta) {
+                const f32x4 b = b4[lane + 64 * i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += b[e];
+            }
+            yr[lane + 64 * i] = o;
+        }
+}
+
+// one wave per patch: gathers the (c, pt, p1, p2) features (p2 contiguous in memory) and
+// layer-normalises them.  feature f = ((c*pt + j)*p + p1)*p + p2.
+__global__ __launch_bounds__(256) void patchify_ln_kernel(const float *__restrict__ video, int B, int C, int F, int H,
+                                                          int W, int f0, int t, int pt, int p,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps,
+                                                          float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int h = H / p, w = W / p;
+    const int64_t rows = (int64_t)B * t * h * w;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int dim = C * pt * p * p;
+    const int nv = (dim / 4 + 63) / 64;
+    int64_t rr = row;
+    const int pw = (int)(rr % w); rr /= w;
+    const int ph = (int)(rr % h); rr /= h;
+    const int tt = (int)(rr % t); rr /= t;
+    const int b = (int)rr;
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int f = (lane + 64 * i) * 4;
+        if (i < nv && f < dim) {
+            int q = f;
+            const int p2 = q % p; q /= p;
+            const int p1 = q % p; q /= p;
+            const int j = q % pt; q /= pt;
+            const int c = q;
+            const int frame = f0 + tt * pt + j;
+            const int64_t off = (((int64_t)(b * C + c) * F + frame) * H + (ph * p + p1)) * W + pw * p + p2;
+            v[i] = *reinterpret_cast<const f32x4 *>(video + off);
+        }
+    }
+    float mean, rstd;
+    row_stats(v, nv, lane, dim, eps, mean, rstd);
+    f32x4 *yr = reinterpret_cast<f32x4 *>(out + row * dim);
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) {
+            const f32x4 g = g4[lane + 64 * i], bb = b4[lane + 64 * i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            yr[lane + 64 * i] = o;
+        }
+}
+
+__global__ __launch_bounds__(256) void unpatchify_kernel(const float *__restrict__ tok, int B, int C, int F, int H,
+                                                         int W, int f0, int t, int pt, int p,
+                                                         float *__restrict__ video) {
+    const int h = H / p, w = W / p;
+    const int dim4 = C * pt * p * p / 4;
+    const int64_t total = (int64_t)B * t * h * w * dim4;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int f = (int)(idx % dim4) * 4;
+    int64_t rr = idx / dim4;
+    const int pw = (int)(rr % w); rr /= w;
+    const int ph = (int)(rr % h); rr /= h;
+    const int tt = (int)(rr % t); rr /= t;
+    const int b = (int)rr;
+    int q = f;
+    const int p2 = q % p; q /= p;
+    const int p1 = q % p; q /= p;
+    const int j = q % pt; q /= pt;
+    const int c = q;
+    const int frame = f0 + tt * pt + j;
+    const int64_t off = (((int64_t)(b * C + c) * F + frame) * H + (ph * p + p1)) * W + pw * p + p2;
+    *reinterpret_cast<f32x4 *>(video + off) = reinterpret_cast<const f32x4 *>(tok)[idx];
+}
+
+// y[b, c, a, :] = x[b, a, c, :]
+__global__ __launch_bounds__(256) void transpose_tokens_kernel(const f32x4 *__restrict__ x, f32x4 *__restrict__ y,
+                                                               int64_t B, int64_t A, int64_t Cn, int d4) {
+    const int64_t total = B * A * Cn * d4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % d4);
+        int64_t rr = idx / d4;
+        const int64_t a = rr % A; rr /= A;
+        const int64_t c = rr % Cn;
+        const int64_t b = rr / Cn;
+        y[idx] = x[((b * A + a) * Cn + c) * d4 + d];
+    }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+extern "C" int omnitok_layernorm(const float *x, const float *gamma, const float *beta, float *y, int64_t rows,
+                                 int dim, float eps, int64_t rows_per_group, int64_t group_stride,
+                                 int64_t group_offset, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && gamma && y, "layernorm: null pointer");
+    OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4, "layernorm: dim=%d unsupported", dim);
+    OT_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && (!beta || aligned16(beta)),
+                 "layernorm: pointers must be 16-byte aligned");
+    if (rows == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y,
+                       rows, dim, eps, rows_per_group, group_stride, group_offset);
+    OT_LAUNCH_CHECK("layernorm");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_patchify_ln(const float *video, int B, int C, int F, int H, int W, int f0, int t, int pt,
+                                   int p, const float *gamma, const float *beta, float eps, float *out,
+                                   omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(video && gamma && beta && out, "patchify_ln: null pointer");
+    OT_CHECK_ARG(p % 4 == 0 && H % p == 0 && W % p == 0, "patchify_ln: patch size %d / image %dx%d unsupported", p,
+                 H, W);
+    OT_CHECK_ARG(f0 >= 0 && f0 + t * pt <= F, "patchify_ln: frame range out of bounds");
+    const int dim = C * pt * p * p;
+    OT_CHECK_ARG(dim <= 256 * LN_MAX_V4, "patchify_ln: feature dim %d too large", dim);
+    const int64_t rows = (int64_t)B * t * (H / p) * (W / p);
+    if (rows == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(patchify_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, video, B, C, F, H,
+                       W, f0, t, pt, p, gamma, beta, eps, out);
+    OT_LAUNCH_CHECK("patchify_ln");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_unpatchify(const float *tok, int B, int C, int F, int H, int W, int f0, int t, int pt, int p,
+                                  float *video, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(tok && video, "unpatchify: null pointer");
+    OT_CHECK_ARG(p % 4 == 0 && H % p == 0 && W % p == 0, "unpatchify: patch size %d unsupported", p);
+    OT_CHECK_ARG(f0 >= 0 && f0 + t * pt <= F, "unpatchify: frame range out of bounds");
+    const int64_t total = (int64_t)B * t * (H / p) * (W / p) * (C * pt * p * p / 4);
+    if (total == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, tok, B, C, F,
+                       H, W, f0, t, pt, p, video);
+    OT_LAUNCH_CHECK("unpatchify");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_transpose_tokens(const float *x, float *y, int64_t B, int64_t A, int64_t C, int D,
+                                        omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && y && x != y, "transpose_tokens: bad pointers");
+    OT_CHECK_ARG(D % 4 == 0, "transpose_tokens: D %% 4 != 0");
+    const int64_t total = B * A * C * (D / 4);
+    if (total == 0) return OMNITOK_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(transpose_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, stream,
+                       reinterpret_cast<const f32x4 *>(x), reinterpret_cast<f32x4 *>(y), B, A, C, D / 4);
+    OT_LAUNCH_CHECK("transpose_tokens");
+    return OMNITOK_OK;
+}

@@ -1,0 +1,278 @@
+// Vector quantiser: pre_vq projection + l2norm, nearest-codebook search (bit-exact with the
+// reference's fp32 arithmetic), de-quantisation + post_vq projection.
+//
+// vq_argmin (reference modules/codebook.py:82-86; oracle/vq_argmin.c is the arithmetic spec):
+//   d[n,c] = (xx[n] - dot[n,c]) + ee[c],   ids[n] = first argmin_c
+// codebook_dim = 8 makes the sweep fp32-FMA-bound (~1400 flop/byte), not HBM-bound.
+// The dot products run on the matrix pipe: v_mfma_f32_32x32x2_f32 is bitwise a k-ordered fmaf
+// chain (C = 0, k = 0..7 over four MFMA steps), i.e. exactly what MKL's sgemm produces for
+// (2x) @ E^T on the reference CPU path, while the VALU does the (xx - dot) + ee / compare /
+// select epilogue concurrently.  D[code][row]: each lane owns one input row (column of D) and
+// sees its codes in increasing index order, so a strict '<' keeps the first minimum; the two
+// half-waves are merged with a (distance, index) lexicographic compare.
+//   * codebook pre-packed in A-fragment order (one coalesced 16-byte load per lane per 32 codes,
+//     L2-resident: 256 KiB for 8192 codes), ee[] staged in LDS and read as broadcast float4;
+//   * each wave keeps two 32-row B fragments, so one A load feeds 8 MFMAs.
+#include "common.h"
+
+namespace omnitok {
+
+constexpr int VQ_ROWS_PER_WAVE = 64;
+constexpr int VQ_ROWS_PER_BLOCK = 256;
+
+__global__ void vq_prepare_kernel(const float *__restrict__ E, int n_codes, float *__restrict__ packed,
+                                  float *__restrict__ ee) {
+    // packed float4 index = tile*64 + lane, lane = hi*32 + r32 -> {E[c][hi], E[c][2+hi], E[c][4+hi], E[c][6+hi]}
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_codes * 2) return;
+    const int tile = idx >> 6, lane = idx & 63, r32 = lane & 31, hi = lane >> 5;
+    const int c = tile * 32 + r32;
+    f32x4 a;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a[s] = E[c * 8 + 2 * s + hi];
+    reinterpret_cast<f32x4 *>(packed)[idx] = a;
+    if (hi == 0) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc = __fadd_rn(acc, __fmul_rn(E[c * 8 + k], E[c * 8 + k]));
+        ee[c] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restrict__ z,
+                                                           const float *__restrict__ packed,
+                                                           const float *__restrict__ ee_g, int64_t n, int n_codes,
+                                                           int64_t *__restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) float ee_s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    for (int i = tid * 4; i < n_codes; i += 256 * 4)
+        *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + i);
+    __syncthreads();
+
+    const int64_t row_base = (int64_t)blockIdx.x * VQ_ROWS_PER_BLOCK + wave * VQ_ROWS_PER_WAVE;
+    float xb[2][4], xx[2], best[2];
+    int bidx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int64_t row = row_base + g * 32 + r32;
+        if (row > n - 1) row = n - 1;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(z + row * 8);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(z + row * 8 + 4);
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(lo[k], lo[k]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(hi4[k], hi4[k]));
+        xx[g] = acc;
+        // k = 2s + hi for MFMA step s
+        xb[g][0] = 2.0f * (hi ? lo[1] : lo[0]);
+        xb[g][1] = 2.0f * (hi ? lo[3] : lo[2]);
+        xb[g][2] = 2.0f * (hi ? hi4[1] : hi4[0]);
+        xb[g][3] = 2.0f * (hi ? hi4[3] : hi4[2]);
+        best[g] = INFINITY;
+        bidx[g] = 0;
+    }
+
+    const f32x4 *pk = reinterpret_cast<const f32x4 *>(packed) + lane;
+    const int ntiles = n_codes >> 5;
+    f32x4 a_next = pk[0];
+    for (int t = 0; t < ntiles; ++t) {
+        const f32x4 a = a_next;
+        if (t + 1 < ntiles) a_next = pk[(int64_t)(t + 1) * 64];
+        f32x16 acc[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xb[g][s], acc[g], 0, 0, 0);
+        }
+        const int cbase = t * 32 + 4 * hi;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ee_s + cbase + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int code = cbase + 8 * q + e;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const float d = __fadd_rn(__fsub_rn(xx[g], acc[g][q * 4 + e]), e4[e]);
+                    if (d < best[g]) {
+                        best[g] = d;
+                        bidx[g] = code;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float od = swap32(best[g]);
+        const int oi = __shfl_xor(bidx[g], 32);
+        if (od < best[g] || (od == best[g] && oi < bidx[g])) {
+            best[g] = od;
+            bidx[g] = oi;
+        }
+        const int64_t row = row_base + g * 32 + r32;
+        if (hi == 0 && row < n) ids[row] = (int64_t)bidx[g];
+    }
+}
+
+// z = l2norm(x W^T + b): one 16-lane DPP row per token row
+__global__ __launch_bounds__(256) void pre_vq_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                     const float *__restrict__ b, float *__restrict__ z, int64_t n,
+                                                     int D, int l2) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (row >= n) return;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+    const float *xr = x + row * D;
+    for (int i = l16 * 4; i < D; i += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + i);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + c * D + i);
+            acc[c] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        }
+    }
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        acc[c] = row16_allsum(acc[c]) + b[c];
+        ss += acc[c] * acc[c];
+    }
+    if (l2) {
+        const float den = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(p=2, eps=1e-12), omnitokenizer.py:252
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = acc[c] / den;
+    }
+    if (l16 == 0) *reinterpret_cast<f32x4 *>(z + row * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    if (l16 == 1) *reinterpret_cast<f32x4 *>(z + row * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
+// tok[n, 4c..4c+3] = b + sum_k E[ids[n]][k] * W[c][k]
+__global__ __launch_bounds__(256) void dequant_post_vq_kernel(const int64_t *__restrict__ ids,
+                                                              const float *__restrict__ E, int n_codes,
+                                                              const float *__restrict__ w,
+                                                              const float *__restrict__ b, float *__restrict__ tok,
+                                                              int64_t n, int D, int *err_flag) {
+    const int d4n = D >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * d4n) return;
+    const int64_t row = gid / d4n;
+    const int c4 = (int)(gid % d4n);
+    int64_t id = ids[row];
+    if (id < 0 || id >= n_codes) {
+        if (err_flag) atomicOr(err_flag, 1);
+        id = 0;
+    }
+    const f32x4 e0 = *reinterpret_cast<const f32x4 *>(E + id * 8);
+    const f32x4 e1 = *reinterpret_cast<const f32x4 *>(E + id * 8 + 4);
+    f32x4 o = reinterpret_cast<const f32x4 *>(b)[c4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + (c4 * 4 + j) * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(w + (c4 * 4 + j) * 8 + 4);
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = fmaf(e0[k], w0[k], s);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = fmaf(e1[k], w1[k], s);
+        o[j] += s;
+    }
+    reinterpret_cast<f32x4 *>(tok)[gid] = o;
+}
+
+__global__ __launch_bounds__(256) void vq_embed_st_kernel(const int64_t *__restrict__ ids,
+                                                          const float *__restrict__ z, const float *__restrict__ E,
+                                                          int64_t B, int64_t thw, float *__restrict__ emb) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= B * thw) return;
+    const int64_t b = gid / thw, s = gid % thw;
+    const int64_t id = ids[gid];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float zv = z[gid * 8 + c];
+        emb[(b * 8 + c) * thw + s] = __fadd_rn(__fsub_rn(E[id * 8 + c], zv), zv);  // (e - z) + z
+    }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+extern "C" int omnitok_pre_vq(const float *x, const float *w, const float *b, float *z, int64_t n, int D, int cdim,
+                              int l2, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && w && b && z, "pre_vq: null pointer");
+    OT_CHECK_ARG(cdim == 8, "pre_vq: codebook_dim=%d (kernels are built for 8)", cdim);
+    OT_CHECK_ARG(D % 64 == 0, "pre_vq: D %% 64 != 0");
+    if (n == 0) return OMNITOK_OK;
+    const int64_t threads = n * 16;
+    hipLaunchKernelGGL(pre_vq_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, w, b, z, n, D,
+                       l2);
+    OT_LAUNCH_CHECK("pre_vq");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, float *packed, float *ee,
+                                  omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(codebook && packed && ee, "vq_prepare: null pointer");
+    OT_CHECK_ARG(cdim == 8 && n_codes % 32 == 0 && n_codes > 0, "vq_prepare: need cdim == 8, n_codes %% 32 == 0");
+    hipLaunchKernelGGL(vq_prepare_kernel, dim3((n_codes * 2 + 255) / 256), dim3(256), 0, stream, codebook, n_codes,
+                       packed, ee);
+    OT_LAUNCH_CHECK("vq_prepare");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
+                                 int64_t *ids, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(z && packed && ee && ids, "vq_argmin: null pointer");
+    OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin: n_codes=%d unsupported", n_codes);
+    OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin: unaligned");
+    if (n == 0) return OMNITOK_OK;
+    const int lds = n_codes * 4;
+    static int attr_bytes = 0;
+    if (lds > attr_bytes) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_bytes = lds;
+    }
+    const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
+    hipLaunchKernelGGL(vq_argmin_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, z, packed, ee, n, n_codes,
+                       ids);
+    OT_LAUNCH_CHECK("vq_argmin");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_codes, int cdim,
+                                       const float *w, const float *b, float *tok, int64_t n, int D, int *err_flag,
+                                       omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(ids && codebook && w && b && tok, "dequant_post_vq: null pointer");
+    OT_CHECK_ARG(cdim == 8 && D % 4 == 0, "dequant_post_vq: need cdim == 8 and D %% 4 == 0");
+    if (n == 0) return OMNITOK_OK;
+    const int64_t total = n * (D / 4);
+    hipLaunchKernelGGL(dequant_post_vq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids,
+                       codebook, n_codes, w, b, tok, n, D, err_flag);
+    OT_LAUNCH_CHECK("dequant_post_vq");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_vq_embed_st(const int64_t *ids, const float *z, const float *codebook, int cdim, int64_t B,
+                                   int64_t thw, float *emb, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(ids && z && codebook && emb && cdim == 8, "vq_embed_st: bad arguments");
+    const int64_t total = B * thw;
+    if (total == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(vq_embed_st_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, z,
+                       codebook, B, thw, emb);
+    OT_LAUNCH_CHECK("vq_embed_st");
+    return OMNITOK_OK;
+}

@@ -1,0 +1,83 @@
+"""Clip-sharded multi-GPU encode/decode: one process per GPU, no data-path collective except
+the final all-gather of token ids (BASELINE.json north_star).
+
+The reference's encode/decode performs no communication (every clip is independent end to end:
+attention, PEG and VQ never cross the batch dimension), so the batch is partitioned into
+contiguous shards, weights are replicated, and only the ids -- 4 bytes per token after narrowing
+int64 -> int32 (n_codes <= 32768) -- are exchanged with one all_gather over RCCL/xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).  Decoded pixels stay local.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) of n items for `rank`; the first n % world ranks get one extra."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def all_gather_ids(ids_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """ids_local [b_local, ...] int64 -> [n_total, ...] int64 on every rank."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return ids_local
+    tail = tuple(ids_local.shape[1:])
+    bmax = -(-n_total // world)
+    send = torch.zeros((bmax,) + tail, dtype=torch.int32, device=ids_local.device)
+    send[: ids_local.shape[0]] = ids_local.to(torch.int32)
+    recv = torch.empty((world * bmax,) + tail, dtype=torch.int32, device=ids_local.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        parts.append(recv[r * bmax: r * bmax + (hi - lo)])
+    out = torch.cat(parts, dim=0).to(torch.int64)
+    assert out.shape[0] == n_total, (out.shape, n_total, rank)
+    return out
+
+
+def encode_sharded(encode_fn: Callable[[torch.Tensor], torch.Tensor], x_global_or_local: torch.Tensor,
+                   n_total: Optional[int] = None, group=None, already_sharded: bool = False) -> torch.Tensor:
+    """Runs encode_fn on this rank's shard of the batch and returns the ids of the WHOLE batch on
+    every rank.  x is either the full batch (each rank slices its shard) or, with
+    already_sharded=True, this rank's shard (n_total = global batch size)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if already_sharded:
+        assert n_total is not None
+        x_local = x_global_or_local
+    else:
+        n_total = x_global_or_local.shape[0]
+        lo, hi = shard_range(n_total, rank, world)
+        x_local = x_global_or_local[lo:hi]
+    ids_local = encode_fn(x_local) if x_local.shape[0] > 0 else None
+    if world == 1:
+        return ids_local
+    if ids_local is None:  # empty shard: learn the trailing shape from rank 0
+        shp = torch.zeros(8, dtype=torch.int64, device=x_global_or_local.device)
+        dist.broadcast(shp, src=0, group=group)
+        nd = int(shp[0])
+        ids_local = torch.zeros((0,) + tuple(int(v) for v in shp[1:1 + nd]), dtype=torch.int64,
+                                device=x_global_or_local.device)
+    elif n_total < world:  # someone has an empty shard: rank 0 publishes the shape
+        shp = torch.zeros(8, dtype=torch.int64, device=ids_local.device)
+        if rank == 0:
+            shp[0] = ids_local.dim() - 1
+            shp[1:ids_local.dim()] = torch.tensor(ids_local.shape[1:])
+        dist.broadcast(shp, src=0, group=group)
+    return all_gather_ids(ids_local, n_total, group)
+
+
+def decode_local(decode_fn: Callable[[torch.Tensor], torch.Tensor], ids_all: torch.Tensor, group=None):
+    """Decodes this rank's shard of the gathered ids; pixels are not gathered."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    lo, hi = shard_range(ids_all.shape[0], rank, world)
+    return decode_fn(ids_all[lo:hi])

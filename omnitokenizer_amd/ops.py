@@ -1,0 +1,292 @@
+"""Per-operator Python entry points over the C ABI (include/omnitok.h).
+
+Every function takes torch tensors that live on the MI355X ("cuda" device of PyTorch-ROCm), passes
+raw device pointers + the current HIP stream to libomnitok.so and returns torch tensors.  PyTorch
+is used for memory and streams only; all arithmetic is in the hand-written HIP kernels.  There is
+no CPU path: tensors on the CPU raise.
+
+The operators are also registered as PyTorch custom ops in the `omnitok::` namespace
+(torch.ops.omnitok.vq_argmin, .attn_spatial, .attn_window, .attn_temporal, .linear, .peg3d,
+.layernorm) so that callers who compose their own graphs get schema-checked ops.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+GEMM_BIAS, GEMM_RESIDUAL, GEMM_GEGLU, GEMM_LEAKY = 1, 2, 4, 8
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name}: tensor is on {t.device}; omnitokenizer_amd has no CPU path "
+                           "(the HIP kernels are the product)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def layernorm(x, gamma, beta=None, eps=1e-5):
+    x = _req(x, "x")
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().omnitok_layernorm(_p(x), _p(_req(gamma, "gamma")), _p(beta), _p(y), rows, dim, eps,
+                                        0, 0, 0, _stream()), "layernorm")
+    return y
+
+
+def linear(x, weight, bias=None, residual=None, leaky=False):
+    """y = x @ weight.T (+bias) (+leaky_relu 0.1) (+residual); weight [N, K], K % 32 == 0."""
+    x = _req(x, "x")
+    weight = _req(weight, "weight")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RESIDUAL if residual is not None else 0) \
+        | (GEMM_LEAKY if leaky else 0)
+    check(_lib.load().omnitok_gemm(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), N, _p(out), N,
+                                   M, N, K, flags, 0, 0, 0, _stream()), "gemm")
+    return out
+
+
+def pack_geglu_weight(w1, inner_pad):
+    w1 = _req(w1, "w1")
+    inner, K = w1.shape[0] // 2, w1.shape[1]
+    out = torch.empty(2 * inner_pad, K, device=w1.device, dtype=torch.float32)
+    check(_lib.load().omnitok_pack_geglu_weight(_p(w1), inner, K, inner_pad, _p(out), _stream()), "pack_geglu")
+    return out
+
+
+def linear_geglu(x, w1_packed):
+    """gelu(gate) * value of x @ w1.T with w1 packed by pack_geglu_weight -> [.., inner_pad]."""
+    x = _req(x, "x")
+    K = x.shape[-1]
+    M = x.numel() // K
+    Np = w1_packed.shape[0]
+    out = torch.empty(*x.shape[:-1], Np // 2, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_gemm(_p(x), K, _p(_req(w1_packed, "w1_packed")), K, None, None, 0, _p(out), Np // 2,
+                                   M, Np, K, GEMM_GEGLU, 0, 0, 0, _stream()), "gemm_geglu")
+    return out
+
+
+def patchify_ln(video, f0, t, pt, p, gamma, beta, eps=1e-5):
+    video = _req(video, "video")
+    B, C, F, H, W = video.shape
+    out = torch.empty(B * t * (H // p) * (W // p), C * pt * p * p, device=video.device, dtype=torch.float32)
+    check(_lib.load().omnitok_patchify_ln(_p(video), B, C, F, H, W, f0, t, pt, p, _p(_req(gamma, "gamma")),
+                                          _p(_req(beta, "beta")), eps, _p(out), _stream()), "patchify_ln")
+    return out
+
+
+def unpatchify(tok, video, f0, t, pt, p):
+    """Scatters tok rows into video[B,C,F,H,W] (in place) and returns video."""
+    B, C, F, H, W = video.shape
+    check(_lib.load().omnitok_unpatchify(_p(_req(tok, "tok")), B, C, F, H, W, f0, t, pt, p, _p(_req(video, "video")),
+                                         _stream()), "unpatchify")
+    return video
+
+
+def pack_peg_weight(w):
+    w = _req(w, "w")
+    D = w.shape[0]
+    out = torch.empty(27, D, device=w.device, dtype=torch.float32)
+    check(_lib.load().omnitok_pack_peg_weight(_p(w), D, _p(out), _stream()), "pack_peg")
+    return out
+
+
+def peg3d(x, w27, bias, shape, causal):
+    """PEG(x) + x on the raw buffer viewed as [B,T,H,W,D]."""
+    x = _req(x, "x")
+    B, T, H, W = shape
+    D = x.shape[-1]
+    assert x.numel() == B * T * H * W * D
+    y = torch.empty_like(x)
+    check(_lib.load().omnitok_peg3d(_p(x), _p(_req(w27, "w27")), _p(_req(bias, "bias")), _p(y), B, T, H, W, D,
+                                    int(bool(causal)), _stream()), "peg3d")
+    return y
+
+
+def transpose_tokens(x, B, A, C):
+    x = _req(x, "x")
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().omnitok_transpose_tokens(_p(x), _p(y), B, A, C, D, _stream()), "transpose_tokens")
+    return y
+
+
+def rope_table(n_tokens, dim_head=64, theta=10000.0):
+    cos = torch.empty(n_tokens, dim_head // 2, dtype=torch.float32)
+    sin = torch.empty_like(cos)
+    check(_lib.load().omnitok_rope_table(n_tokens, dim_head, theta, ctypes.c_void_p(cos.data_ptr()),
+                                         ctypes.c_void_p(sin.data_ptr())), "rope_table")
+    return cos, sin
+
+
+def qk_prep_(q, k, n_tokens, heads, q_scale, k_scale, cos=None, sin=None, scale=8.0):
+    """In place on q [rows, heads*64] and k (a [rows, heads*64] view with row stride k.stride(0))."""
+    assert q.dim() == 2 and k.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1
+    check(_lib.load().omnitok_qk_prep(_p(q), q.stride(0), _p(k), k.stride(0), q.shape[0], n_tokens, heads, _p(cos),
+                                      _p(sin), _p(_req(q_scale, "q_scale")), _p(_req(k_scale, "k_scale")), scale,
+                                      _stream()), "qk_prep")
+
+
+def attn_spatial(q, k, v, Bn, N, heads, bias_table=None, gh=0, gw=0):
+    """q [Bn*N, heads*64]; k, v: [Bn*N, heads*64] views sharing one row stride."""
+    assert k.stride(0) == v.stride(0) and q.stride(1) == 1
+    out = torch.empty(q.shape[0], heads * 64, device=q.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_spatial(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(out), heads * 64, Bn, N,
+                                           heads, _p(bias_table), gh, gw, _stream()), "attn_spatial")
+    return out
+
+
+def attn_window(qkv, bias_dense, Bn, gh, gw, heads):
+    qkv = _req(qkv, "qkv")
+    out = torch.empty(qkv.shape[0], heads * 64, device=qkv.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_window(_p(qkv), qkv.shape[1], _p(_req(bias_dense, "bias_dense")), _p(out),
+                                          heads * 64, Bn, gh, gw, heads, _stream()), "attn_window")
+    return out
+
+
+def attn_temporal(q, k, v, cols, T, heads, q_scale, k_scale, causal, alibi=None, scale=8.0):
+    assert k.stride(0) == v.stride(0)
+    out = torch.empty(q.shape[0], heads * 64, device=q.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_temporal(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(out), heads * 64, cols,
+                                            T, heads, _p(q_scale), _p(k_scale), scale, int(bool(causal)), _p(alibi),
+                                            _stream()), "attn_temporal")
+    return out
+
+
+def pre_vq(x, w, b, l2=True):
+    x = _req(x, "x")
+    n, D = x.numel() // x.shape[-1], x.shape[-1]
+    z = torch.empty(*x.shape[:-1], 8, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_pre_vq(_p(x), _p(_req(w, "w")), _p(_req(b, "b")), _p(z), n, D, 8, int(l2), _stream()),
+          "pre_vq")
+    return z
+
+
+def vq_prepare(codebook):
+    codebook = _req(codebook, "codebook")
+    n_codes, cdim = codebook.shape
+    packed = torch.empty(n_codes * 8, device=codebook.device, dtype=torch.float32)
+    ee = torch.empty(n_codes, device=codebook.device, dtype=torch.float32)
+    check(_lib.load().omnitok_vq_prepare(_p(codebook), n_codes, cdim, _p(packed), _p(ee), _stream()), "vq_prepare")
+    return packed, ee
+
+
+def vq_argmin(z, codebook, prepared=None):
+    """ids[n] = nearest code of z[n] (int64), bit-exact with reference modules/codebook.py:82-86."""
+    z = _req(z, "z")
+    packed, ee = prepared if prepared is not None else vq_prepare(codebook)
+    n = z.numel() // 8
+    ids = torch.empty(z.shape[:-1], device=z.device, dtype=torch.int64)
+    check(_lib.load().omnitok_vq_argmin(_p(z), _p(packed), _p(ee), n, ee.numel(), _p(ids), _stream()), "vq_argmin")
+    return ids
+
+
+def dequant_post_vq(ids, codebook, w, b):
+    ids = _req(ids, "ids", torch.int64)
+    D = w.shape[0]
+    n = ids.numel()
+    tok = torch.empty(*ids.shape, D, device=ids.device, dtype=torch.float32)
+    err = torch.zeros(1, device=ids.device, dtype=torch.int32)
+    check(_lib.load().omnitok_dequant_post_vq(_p(ids), _p(_req(codebook, "codebook")), codebook.shape[0], 8,
+                                              _p(_req(w, "w")), _p(_req(b, "b")), _p(tok), n, D, _p(err), _stream()),
+          "dequant_post_vq")
+    if int(err.item()):
+        raise IndexError("token id out of range")
+    return tok
+
+
+# ------------------------------------------------------------------------------------------------
+# PyTorch custom-op registration (omnitok:: namespace)
+# ------------------------------------------------------------------------------------------------
+def _register():
+    from torch.library import custom_op
+
+    @custom_op("omnitok::vq_argmin", mutates_args=(), device_types="cuda")
+    def _vq_argmin(z: torch.Tensor, codebook: torch.Tensor) -> torch.Tensor:
+        return vq_argmin(z.contiguous(), codebook.contiguous())
+
+    @_vq_argmin.register_fake
+    def _(z, codebook):
+        return z.new_empty(z.shape[:-1], dtype=torch.int64)
+
+    @custom_op("omnitok::linear", mutates_args=(), device_types="cuda")
+    def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return linear(x.contiguous(), weight.contiguous(), bias)
+
+    @_linear.register_fake
+    def _(x, weight, bias=None):
+        return x.new_empty(*x.shape[:-1], weight.shape[0])
+
+    @custom_op("omnitok::layernorm", mutates_args=(), device_types="cuda")
+    def _layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return layernorm(x.contiguous(), gamma, beta)
+
+    @_layernorm.register_fake
+    def _(x, gamma, beta=None):
+        return torch.empty_like(x)
+
+    @custom_op("omnitok::attn_spatial", mutates_args=(), device_types="cuda")
+    def _attn_spatial(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_tokens: int, heads: int) -> torch.Tensor:
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        return attn_spatial(q, k, v, q.shape[0] // n_tokens, n_tokens, heads)
+
+    @_attn_spatial.register_fake
+    def _(q, k, v, n_tokens, heads):
+        return torch.empty_like(q)
+
+    @custom_op("omnitok::attn_window", mutates_args=(), device_types="cuda")
+    def _attn_window(qkv: torch.Tensor, bias_dense: torch.Tensor, images: int, gh: int, gw: int,
+                     heads: int) -> torch.Tensor:
+        return attn_window(qkv.contiguous(), bias_dense.contiguous(), images, gh, gw, heads)
+
+    @_attn_window.register_fake
+    def _(qkv, bias_dense, images, gh, gw, heads):
+        return qkv.new_empty(qkv.shape[0], heads * 64)
+
+    @custom_op("omnitok::attn_temporal", mutates_args=(), device_types="cuda")
+    def _attn_temporal(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_scale: torch.Tensor,
+                       k_scale: torch.Tensor, T: int, heads: int, causal: bool) -> torch.Tensor:
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        return attn_temporal(q, k, v, q.shape[0] // T, T, heads, q_scale, k_scale, causal)
+
+    @_attn_temporal.register_fake
+    def _(q, k, v, q_scale, k_scale, T, heads, causal):
+        return torch.empty_like(q)
+
+    @custom_op("omnitok::peg3d", mutates_args=(), device_types="cuda")
+    def _peg3d(x: torch.Tensor, w27: torch.Tensor, bias: torch.Tensor, B: int, T: int, H: int, W: int,
+               causal: bool) -> torch.Tensor:
+        return peg3d(x.contiguous(), w27, bias, (B, T, H, W), causal)
+
+    @_peg3d.register_fake
+    def _(x, w27, bias, B, T, H, W, causal):
+        return torch.empty_like(x)
+
+
+try:
+    _register()
+    CUSTOM_OPS_REGISTERED = True
+except Exception as _e:  # registration is a convenience layer; the C ABI wrappers above are the API
+    CUSTOM_OPS_REGISTERED = False
+    _CUSTOM_OPS_ERROR = repr(_e)

@@ -1,0 +1,289 @@
+"""Drop-in for the reference's `OmniTokenizer_VQGAN` on the encode()/decode() path.
+
+Mirrors reference OmniTokenizer/omnitokenizer.py: constructor from the argparse Namespace (:64),
+`encode(x, is_image, include_embeddings=False)` (:247-266), `decode(encodings, is_image)`
+(:268-317), the state_dict key names / shapes of the path and the attributes the
+reference's callers touch (vqgan_eval.py:76-86, lm_transformer.py:95-101).  All arithmetic runs in
+libomnitok.so (hand-written gfx950 HIP kernels behind the C ABI of include/omnitok.h); this class
+only owns the parameters (as torch tensors, so .to()/.state_dict()/.load_state_dict() behave) and
+hands device pointers to the native engine.  Inference only; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import OmnitokConfig, check
+from .config import OmniTokConfig
+from .synth import path_state_spec, relative_position_index
+
+_OFF_PATH_PREFIXES = ("image_discriminator.", "video_discriminator.", "perceptual_model.")
+
+
+class _Holder(nn.Module):
+    """Parameter container that reproduces the reference's module nesting (names only)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; call OmniTokenizer_VQGAN.encode()/decode()")
+
+
+def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Holder())
+        mod = mod._modules[p]
+    if tensor.dtype.is_floating_point:
+        mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+    else:
+        mod.register_buffer(parts[-1], tensor)
+
+
+class OmniTokenizer_VQGAN(nn.Module):
+    def __init__(self, args, attention_mode: Optional[str] = None):
+        """args: the same Namespace the reference takes.  attention_mode: "sdpa" (what the
+        reference executes under torch >= 2.1, attention.py:439) or "legacy" (the einsum branch
+        `imagenet_only.ckpt` was trained with, README.md:58); default "sdpa", or
+        args.attention_mode if present."""
+        super().__init__()
+        mode = attention_mode or getattr(args, "attention_mode", "sdpa")
+        self.args = args
+        self.cfg = OmniTokConfig.from_args(args, attention_mode=mode)
+        cfg = self.cfg
+        # attributes read by the reference's callers
+        self.embedding_dim = cfg.dim
+        self.n_codes = cfg.n_codes
+        self.resolution = cfg.resolution
+        self.patch_size = cfg.patch_size
+        self.use_vae = False
+        self.use_external_codebook = False
+        self.l2_code = cfg.l2_code
+
+        for name, shape in path_state_spec(cfg).items():
+            if name.endswith("relative_position_index"):
+                t = relative_position_index(cfg.window_size)
+            elif name.endswith((".gamma", ".q_scale", ".k_scale")) or (name.endswith(".weight") and len(shape) == 1):
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            _attach(self, name, t)
+        self.encoder.image_size = (cfg.resolution, cfg.resolution)
+        self.decoder.image_size = (cfg.resolution, cfg.resolution)
+        self.codebook.n_codes = cfg.n_codes
+        self.codebook.embedding_dim = cfg.codebook_dim
+        self.codebook._need_init = False  # training-time k-means init (codebook.py:40-51) is not on the path
+
+        self._engine = None
+        self._engine_sig = None
+        self._timing = False
+
+    # ---- nn.Module plumbing -------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.codebook.embeddings.device
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("omnitokenizer_amd is inference-only (encode/decode path)")
+        return super().train(False)
+
+    def load_state_dict(self, state_dict, strict: bool = False, assign: bool = False):
+        """Accepts a reference checkpoint's state_dict.  Off-path entries (discriminators, LPIPS;
+        vqgan_eval.py:62-68 drops or ignores them the same way) are skipped silently."""
+        sd = {k: v for k, v in state_dict.items() if not k.startswith(_OFF_PATH_PREFIXES)}
+        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._engine_sig = None
+        return out
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", strict=False, **kw):
+        """PL-style checkpoint: {"state_dict":…, "hyper_parameters": {"args": Namespace}}
+        (reference omnitokenizer.py:208, download.py:49)."""
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        model = cls(ckpt["hyper_parameters"]["args"], **kw)
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        return model
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                _lib.load().omnitok_engine_destroy(self._engine)
+        except Exception:
+            pass
+
+    # ---- native engine ------------------------------------------------------------------------
+    def _native_config(self) -> OmnitokConfig:
+        c = self.cfg
+        nc = OmnitokConfig()
+        nc.resolution, nc.image_channels, nc.patch_size = c.resolution, c.image_channels, c.patch_size
+        nc.temporal_patch_size, nc.dim, nc.heads, nc.dim_head = c.temporal_patch_size, c.dim, c.heads, c.dim_head
+        nc.ff_inner, nc.window_size, nc.n_codes, nc.codebook_dim = c.ff_inner, c.window_size, c.n_codes, c.codebook_dim
+        nc.l2_code = int(c.l2_code)
+        nc.spatial_rope = int(c.spatial_pos == "rope")
+        nc.legacy_attention = int(c.attention_mode == "legacy")
+        nc.causal_temporal = int(c.causal_in_temporal_transformer)
+        nc.causal_peg = int(c.causal_in_peg)
+        nc.temporal_depth = c.temporal_depth
+        nc.enc_block = c.enc_block.encode()
+        nc.dec_block = c.dec_block.encode()
+        return nc
+
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def _sync_engine(self):
+        """Pushes the parameters into the native engine when they changed (load_state_dict, .to(),
+        in-place edits)."""
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"OmniTokenizer_VQGAN is on {dev}: move it to the GPU (.to('cuda')). The MI355X HIP path is "
+                "the only implementation; there is no CPU fallback.")
+        sig = self._signature()
+        if self._engine is not None and sig == self._engine_sig:
+            return
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._engine is None:
+            h = ctypes.c_void_p()
+            nc = self._native_config()
+            check(lib.omnitok_engine_create(ctypes.byref(nc), ctypes.byref(h)), "engine_create")
+            self._engine = h
+            lib.omnitok_engine_set_timing(self._engine, int(self._timing))
+        for name, t in self.state_dict(keep_vars=True).items():
+            t = t.detach()
+            if t.dtype.is_floating_point and t.dtype != torch.float32:
+                raise TypeError(f"{name}: parameters must be float32 (the path computes in fp32 like the reference)")
+            t = t.contiguous()
+            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+            check(lib.omnitok_engine_set_weight(self._engine, name.encode(), ctypes.c_void_p(t.data_ptr()), shape,
+                                                t.dim(), int(t.dtype == torch.int64), stream), f"set_weight({name})")
+        check(lib.omnitok_engine_finalize(self._engine, stream), "engine_finalize")
+        torch.cuda.current_stream().synchronize()
+        self._engine_sig = sig
+
+    # ---- the path -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x, is_image, include_embeddings=False, return_latents=False):
+        """reference omnitokenizer.py:247-258.  x: [B,C,H,W] (is_image) or [B,C,F,H,W] fp32 in
+        [-0.5,0.5] on the GPU.  Returns LongTensor ids [B,T',h,w]; with include_embeddings
+        (embeddings [B,cdim,T',h,w], ids)."""
+        if x.dim() not in (4, 5):
+            raise AssertionError("video.ndim in {4, 5}")  # reference omnitokenizer.py:921
+        if is_image:
+            if x.dim() != 4:
+                raise ValueError("is_image=True expects [B,C,H,W]")
+            B, C, H, W = x.shape
+            F = 1
+        else:
+            if x.dim() != 5:
+                raise ValueError("is_image=False expects [B,C,F,H,W]")
+            B, C, F, H, W = x.shape
+        if C != self.cfg.image_channels:
+            raise ValueError(f"expected {self.cfg.image_channels} channels, got {C}")
+        self._sync_engine()
+        if x.device != self.device:
+            raise RuntimeError(f"input on {x.device}, model on {self.device}")
+        x = x.to(torch.float32).contiguous()
+        pt, p = self.cfg.temporal_patch_size, self.cfg.patch_size
+        if (F - 1) % pt != 0:
+            raise AssertionError(f"number of frames ({F}) minus one ({F - 1}) must be divisible by temporal "
+                                 f"patch size ({pt})")  # reference omnitokenizer.py:931-932
+        T, h, w = 1 + (F - 1) // pt, H // p, W // p
+        ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
+        emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device) if include_embeddings else None
+        z = torch.empty(B, T, h, w, self.cfg.codebook_dim, device=x.device) if return_latents else None
+        lib = _lib.load()
+        check(lib.omnitok_encode(self._engine, ctypes.c_void_p(x.data_ptr()), B, F, H, W,
+                                 ctypes.c_void_p(ids.data_ptr()),
+                                 None if emb is None else ctypes.c_void_p(emb.data_ptr()),
+                                 None if z is None else ctypes.c_void_p(z.data_ptr()),
+                                 torch.cuda.current_stream().cuda_stream), "encode")
+        if return_latents:
+            return (emb, ids, z) if include_embeddings else (ids, z)
+        return (emb, ids) if include_embeddings else ids
+
+    @torch.no_grad()
+    def decode(self, encodings, is_image, check_ids: bool = False):
+        """reference omnitokenizer.py:268-291.  encodings: ids [B,T',h,w], flat video ids
+        [B,T'*h*w] (h = w = args.resolution // patch_size, :283-286) or flat image ids [B,h*w]
+        (h = int(sqrt(h*w)), :272-275).  Returns [B,3,H,W] (is_image) or [B,3,F,H,W]."""
+        self._sync_engine()
+        ids = encodings
+        if ids.dtype != torch.int64:
+            ids = ids.long()
+        if ids.device != self.device:
+            raise RuntimeError(f"ids on {ids.device}, model on {self.device}")
+        if ids.dim() == 2:
+            if is_image:
+                h = int(math.sqrt(ids.shape[1]))
+                ids = ids.reshape(ids.shape[0], 1, h, -1)
+            else:
+                h = self.resolution // self.patch_size
+                ids = ids.reshape(ids.shape[0], -1, h, h)
+        elif ids.dim() != 4:
+            raise ValueError("encodings must be [B,T,h,w] or flat [B,N]")
+        ids = ids.contiguous()
+        B, T, h, w = ids.shape
+        if is_image and T != 1:
+            raise ValueError("is_image=True expects a single latent frame")
+        c = self.cfg
+        F = 1 + (T - 1) * c.temporal_patch_size
+        out = torch.empty(B, c.image_channels, F, h * c.patch_size, w * c.patch_size, device=ids.device,
+                          dtype=torch.float32)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        check(lib.omnitok_decode(self._engine, ctypes.c_void_p(ids.data_ptr()), B, T, h, w,
+                                 ctypes.c_void_p(out.data_ptr()), stream), "decode")
+        if check_ids:
+            rc = lib.omnitok_engine_check_ids(self._engine, stream)
+            if rc == -1:
+                raise IndexError(lib.omnitok_last_error().decode())
+            check(rc, "check_ids")
+        return out[:, :, 0] if is_image else out
+
+    def forward(self, x, optimizer_idx=None, log_image=False):
+        """The inference use of reference VQGAN.forward (omnitokenizer.py:330-413,
+        `vqgan(x, log_image=True)` in vqgan_eval.py:119,187): returns
+        (frames, frames_recon, x, x_recon, vq_output) with vq_output carrying encodings/embeddings."""
+        if not log_image:
+            raise NotImplementedError("training forward (losses, discriminators) is outside the built path")
+        is_image = x.dim() == 4
+        emb, ids = self.encode(x, is_image, include_embeddings=True)
+        x_recon = self.decode(ids, is_image)
+        if is_image:
+            frames, frames_recon = x, x_recon
+        else:
+            B, C, T, H, W = x.shape
+            idx = torch.randint(0, T, [B], device=x.device).reshape(-1, 1, 1, 1, 1).repeat(1, C, 1, H, W)
+            frames = torch.gather(x, 2, idx).squeeze(2)
+            frames_recon = torch.gather(x_recon, 2, idx).squeeze(2)
+        return frames, frames_recon, x, x_recon, dict(embeddings=emb, encodings=ids)
+
+    # ---- measurement hooks ----------------------------------------------------------------------
+    def set_timing(self, enabled: bool):
+        self._timing = bool(enabled)
+        if self._engine is not None:
+            _lib.load().omnitok_engine_set_timing(self._engine, int(enabled))
+
+    def timing_report(self) -> Dict[str, dict]:
+        """{kernel family: {"calls", "ms", "work"}} accumulated since the last report (HIP events
+        recorded around each launch on the launch stream; synchronises)."""
+        if self._engine is None:
+            return {}
+        buf = ctypes.create_string_buffer(1 << 16)
+        check(_lib.load().omnitok_engine_timing_report(self._engine, buf, len(buf)), "timing_report")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms, work = line.split()
+            out[name] = dict(calls=int(calls), ms=float(ms), work=float(work))
+        return out
+
+    def workspace_bytes(self) -> int:
+        return 0 if self._engine is None else int(_lib.load().omnitok_engine_workspace_bytes(self._engine))

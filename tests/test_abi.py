@@ -1,0 +1,89 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/omnitok.h
+declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from omnitokenizer_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from omnitokenizer_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "omnitok.h")).read()
+    declared = set(re.findall(r"\b(omnitok_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"omnitok_stream_t"}
+    assert len(declared) >= 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in omnitok.h but not exported"
+    assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_version_and_argument_errors_without_gpu(lib):
+    assert b"gfx950" in lib.omnitok_version()
+    # argument validation happens before any HIP call, so it is testable on the CPU
+    rc = lib.omnitok_gemm(None, 0, None, 0, None, None, 0, None, 0, 1, 1, 1, 0, 0, 0, 0, None)
+    assert rc == -1 and b"null" in lib.omnitok_last_error()
+    rc = lib.omnitok_rope_table(0, 64, 10000.0, None, None)
+    assert rc == -1
+
+
+def test_rope_table_host_matches_oracle(lib):
+    import torch
+    from omnitokenizer_amd import ops
+    from oracle import omnitok_oracle as orc
+    for n in (64, 1024):
+        cos, sin = ops.rope_table(n)
+        rc, rs = orc.rope_table(n)
+        assert (cos - rc).abs().max().item() < 1e-6 and (sin - rs).abs().max().item() < 1e-6
+
+
+def test_product_refuses_cpu_tensors(lib):
+    import torch
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, ops
+    with pytest.raises(RuntimeError, match="no CPU"):
+        ops.layernorm(torch.zeros(4, 512), torch.ones(512))
+    m = OmniTokenizer_VQGAN(make_args(2, resolution=64)).eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encode(torch.zeros(1, 3, 64, 64), True)
+
+
+def test_state_dict_contract(lib):
+    """Same key set / shapes as the reference's path; off-path keys are ignored on load."""
+    import torch
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    for stage in (1, 2):
+        args = make_args(stage, resolution=64)
+        cfg = OmniTokConfig.from_args(args)
+        m = OmniTokenizer_VQGAN(args)
+        spec = synth.path_state_spec(cfg)
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(spec.keys())
+        assert all(tuple(sd[k].shape) == tuple(spec[k]) for k in spec)
+        src = synth.synth_state_dict(cfg, seed=1)
+        src["video_discriminator.main.0.weight"] = torch.zeros(3)
+        src["perceptual_model.net.x"] = torch.zeros(1)
+        res = m.load_state_dict(src, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        assert torch.equal(m.codebook.embeddings.data, src["codebook.embeddings"])
+        assert m.codebook.n_codes == cfg.n_codes and m.n_codes == cfg.n_codes and not m.use_vae
+        assert m.encoder.image_size == (64, 64)
+
+
+def test_config_rejects_unbuilt_variants():
+    from omnitokenizer_amd import make_args
+    from omnitokenizer_amd.config import OmniTokConfig
+    for bad in (dict(patch_embed="cnn"), dict(enc_block="ttaw"), dict(use_vae=True),
+                dict(use_external_codebook=True), dict(dim_head=32)):
+        with pytest.raises((NotImplementedError, ValueError)):
+            OmniTokConfig.from_args(make_args(2, **bad))
