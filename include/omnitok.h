@@ -42,6 +42,17 @@ enum omnitok_status {
 const char *omnitok_last_error(void);
 /* "omnitok <version> gfx950 ..." */
 const char *omnitok_version(void);
+/* Tuning knobs for A/B measurements (process-global; not part of the functional contract):
+ * "gemm_variant" (0|1), "gemm_lds_pad_kb". Unknown names return OMNITOK_ERR_INVALID. */
+int omnitok_set_option(const char *name, int value);
+/* Measurement only: pure v_mfma_f32_32x32x2_f32 stream (4 accumulators per wave, operands from
+ * `in`[4096]) to find the sustained fp32-MFMA ceiling of the chip. out[blocks*256]. */
+/* Measurement only: device buffer of 4 x 96 int64; workgroup 0 of the persistent GEMM stores
+ * s_memtime stamps (3 per K-step per wave: stream start, stream end, loop end). NULL = off. */
+int omnitok_debug_set_gemm_trace(long long *dev_ptr);
+int omnitok_debug_mfma_peak(const float *in, float *out, int blocks, int iters, int lds_bytes,
+                            long long *clk, omnitok_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Per-operator entry points (each is one HIP kernel family; the engine below chains them).

@@ -62,6 +62,9 @@ _PROTOS = {
     "omnitok_engine_workspace_bytes": [P],
     "omnitok_engine_set_timing": [P, c_int],
     "omnitok_engine_timing_report": [P, c_char_p, c_int],
+    "omnitok_set_option": [c_char_p, c_int],
+    "omnitok_debug_set_gemm_trace": [P],
+    "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
     "omnitok_last_error": [],
     "omnitok_version": [],
 }
@@ -89,7 +92,16 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, c_int)
     _lib = lib
+    # tuning knobs for A/B runs: OMNITOK_OPTS="gemm_variant=1,gemm_lds_pad_kb=40"
+    for kv in filter(None, os.environ.get("OMNITOK_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        if lib.omnitok_set_option(k.strip().encode(), int(v)) != 0:
+            raise OmnitokError(lib.omnitok_last_error().decode())
     return lib
+
+
+def set_option(name: str, value: int):
+    check(load().omnitok_set_option(name.encode(), int(value)), "set_option")
 
 
 def check(rc: int, what: str = ""):

@@ -13,5 +13,27 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace omnitok
 
+namespace omnitok {
+extern int g_gemm_variant;
+extern int g_gemm_lds_pad_kb;
+extern long long *g_gemm_trace;
+}  // namespace omnitok
+
+extern "C" int omnitok_set_option(const char *name, int value) {
+    if (!name) return OMNITOK_ERR_INVALID;
+    if (!strcmp(name, "gemm_variant")) omnitok::g_gemm_variant = value;
+    else if (!strcmp(name, "gemm_lds_pad_kb")) omnitok::g_gemm_lds_pad_kb = value;
+    else {
+        omnitok::set_error("set_option: unknown option %s", name);
+        return OMNITOK_ERR_INVALID;
+    }
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_debug_set_gemm_trace(long long *dev_ptr) {
+    omnitok::g_gemm_trace = dev_ptr;
+    return OMNITOK_OK;
+}
+
 extern "C" const char *omnitok_last_error(void) { return omnitok::g_err; }
 extern "C" const char *omnitok_version(void) { return "omnitok 0.1 gfx950 fp32-mfma"; }

@@ -24,6 +24,13 @@ constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;  // LDT: padded LDS row len
 constexpr int TILE_FLOATS = BM * LDT;
 constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * TILE_FLOATS * 4;
 
+// tuning knobs (omnitok_set_option, A/B measurements): "gemm_variant" 0 = one 128x128 tile per
+// workgroup, 1 = persistent workgroups with the fully interleaved MFMA stream (default), +4 = force;
+// "gemm_lds_pad_kb" extra dynamic LDS per workgroup (limits workgroups per CU).
+int g_gemm_variant = 1;
+int g_gemm_lds_pad_kb = 0;
+long long *g_gemm_trace = nullptr;
+
 struct GemmParams {
     const float *a;
     const float *w;
@@ -34,11 +41,58 @@ struct GemmParams {
     int64_t M;
     int N, K;
     int nbn;  // number of tile columns
+    int ntiles;
+    long long *trace;  // debug: per-wave s_memtime stamps of workgroup 0 (null = off)
     int64_t a_rpg, a_stride, a_off;
 };
 
 __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// fused epilogue on the accumulator registers (bias, leaky-relu, residual add, GEGLU)
+template <int FLAGS>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[2][2], int64_t bm, int bn, int wm,
+                                              int wn, int r32, int hi) {
+    const int64_t row0 = bm * BM + wm * 64;
+    if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
+        const int ocol = (bn * 2 + wn) * 32 + r32;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + mb * 32 + mfma32_row(r, hi);
+                if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[mb][1][r]) * acc[mb][0][r];
+            }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = bn * BN + wn * 64 + nb * 32 + r32;
+            const bool colok = col < p.N;
+            float bv = 0.0f;
+            if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = colok ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = row0 + mb * 32 + mfma32_row(r, hi);
+                    if (row < p.M && colok) {
+                        float v = acc[mb][nb][r];
+                        if constexpr (FLAGS & OMNITOK_GEMM_BIAS) v += bv;
+                        if constexpr (FLAGS & OMNITOK_GEMM_LEAKY) v = v > 0.0f ? v : 0.1f * v;
+                        if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) v += p.residual[row * p.ldr + col];
+                        p.c[row * p.ldc + col] = v;
+                    }
+                }
+        }
+    }
+}
+
+// XCD-aware bijective remap of a linear tile id (workgroup b runs on XCD b % 8): each XCD sweeps a
+// contiguous range of tiles, column index fastest, so the 128xK A panel stays in that XCD's L2
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int xcd = id & 7, q = n >> 3, rem = n & 7;
+    return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
 }
 
 template <int FLAGS>
@@ -50,14 +104,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hi = lane >> 5;
 
-    // XCD-aware bijective remap (block b runs on XCD b % 8)
-    const int nwg = gridDim.x;
-    int lid;
-    {
-        const int id = blockIdx.x;
-        const int xcd = id & 7, q = nwg >> 3, rem = nwg & 7;
-        lid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
-    }
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int64_t bm = lid / p.nbn;
     const int bn = lid % p.nbn;
 
@@ -139,53 +186,230 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------
-    const int64_t row0 = bm * BM + wm * 64;
-    if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
-        const int ocol = (bn * 2 + wn) * 32 + r32;
+    gemm_epilogue<FLAGS>(p, acc, bm, bn, wm, wn, r32, hi);
+}
+
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, which would
+// force the global loads issued in an L phase to land before the phase can end (they are not
+// needed until the next L phase, two matrix phases later).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only (vmcnt / expcnt fields at their maximum)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Persistent variant: 2 workgroups per CU walk the tile list (tile = blockIdx.x + i * gridDim.x,
+// then XCD-remapped); the global->register->LDS pipeline runs ACROSS tile boundaries, so per tile
+// there is no launch, no address prologue and no exposed first-load latency -- only the epilogue's
+// issue time sits between the last MFMA of one tile and the first of the next.
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int nk = p.K / BK;
+    if ((int)blockIdx.x >= p.ntiles) return;
+
+    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * nk;
+
+    const int lrow = tid >> 3, lc4 = tid & 7;
+    const float *ap[4];
+    const float *wp[4];
+    auto set_ptrs = [&](int i) {
+        const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
+        const int64_t tbm = lid / p.nbn;
+        const int tbn = lid % p.nbn;
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int r = 0; r < 4; ++r) {
+            int64_t gr = tbm * BM + lrow + 32 * r;
+            if (gr > p.M - 1) gr = p.M - 1;
+            int64_t ar = gr;
+            if (p.a_rpg > 0) ar = (gr / p.a_rpg) * p.a_stride + p.a_off + (gr % p.a_rpg);
+            ap[r] = p.a + ar * p.lda + lc4 * 4;
+            int wr = tbn * BN + lrow + 32 * r;
+            if (wr > p.N - 1) wr = p.N - 1;
+            wp[r] = p.w + (int64_t)wr * p.ldw + lc4 * 4;
+        }
+    };
+    const int st_off = lrow * LDT + lc4 * 4;
+    f32x4 ra[4], rb[4];
+    auto gload = [&](int k0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + mb * 32 + mfma32_row(r, hi);
-                if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[mb][1][r]) * acc[mb][0][r];
-            }
-    } else {
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
+            rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * 2 * TILE_FLOATS;
+        float *Bs = As + TILE_FLOATS;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int col = bn * BN + wn * 64 + nb * 32 + r32;
-            const bool colok = col < p.N;
-            float bv = 0.0f;
-            if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = colok ? p.bias[col] : 0.0f;
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
+            *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
+        }
+    };
+    f32x16 acc[2][2];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    };
+    zero_acc();
+    const int a_frag_off = (wm * 64 + r32) * LDT + hi * 16;
+    const int b_frag_off = (wn * 64 + r32) * LDT + hi * 16;
+
+    // Measured with s_memtime stamps (tools/gemm_trace.py): while one wave streams MFMAs its SIMD
+    // partner's non-MFMA instructions are not issued, so the two workgroups of a CU take turns
+    // K-step by K-step and everything a wave does OUTSIDE its own MFMA stream is exposed time.
+    // So every LDS / global instruction is embedded in the stream, one per group of 4 MFMAs:
+    //   steps 0-7  (fragments F0 of K-step g): ds_read F1(g) piece, ds_write piece of K-step g+1
+    //              (fetched one K-step ago), global load of the same piece of K-step g+2
+    //   lgkmcnt(0) + s_barrier            (orders LDS only; K-step g+1 is now complete in LDS)
+    //   steps 8-15 (fragments F1): ds_read F0(g+1) piece
+    // Hazards: tile g+1 is stored before barrier(g) and first read after it; buffer g&1 is
+    // overwritten (tile g+2) after barrier(g+1) >= every read of tile g (issued before barrier(g)).
+    int lk = 0, ltile = 0, lg = 0;  // load stream: the next K-step to fetch is lg
+    auto advance_load = [&]() {     // returns the k offset of K-step lg, switching tile if needed
+        if (lg > 0 && lg < total && ++lk == nk) {
+            lk = 0;
+            set_ptrs(++ltile);
+        }
+        ++lg;
+        return lk * BK;  // past the end: lk stays on the last valid K-step
+    };
+    int ck = 0, ctile = 0;
+    int tn = 0;
+    auto stamp = [&]() {
+        if (p.trace && blockIdx.x == 0 && lane == 0 && tn < 96) p.trace[wave * 96 + tn++] = __builtin_readcyclecounter();
+    };
+    f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];  // [row block][j] fragments of the two halves
+    auto frag_piece = [&](f32x4 (&fa)[2][2], f32x4 (&fb)[2][2], int buf, int half, int piece) {
+        const float *As = smem + buf * 2 * TILE_FLOATS;
+        const float *Bs = As + TILE_FLOATS;
+        const int mb = (piece >> 1) & 1, j = piece & 1;
+        if (piece < 4)
+            fa[mb][j] = *reinterpret_cast<const f32x4 *>(As + a_frag_off + mb * 32 * LDT + 8 * half + 4 * j);
+        else
+            fb[mb][j] = *reinterpret_cast<const f32x4 *>(Bs + b_frag_off + mb * 32 * LDT + 8 * half + 4 * j);
+    };
+    // store/load are compile-time after unrolling: a RUNTIME condition around a load makes hipcc
+    // branch around it and wait vmcnt(0) per element (cdna guide 5, trap (c)); past the end of the
+    // tile list the stream simply re-fetches its last K-step and stores it to the idle buffer
+    auto stage_piece = [&](int buf, int piece, bool store, bool load, int k0) {
+        float *As = smem + buf * 2 * TILE_FLOATS;
+        float *Bs = As + TILE_FLOATS;
+        const int i = piece & 3;
+        if (piece < 4) {
+            if (store) *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
+            if (load) ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
+        } else {
+            if (store) *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
+            if (load) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
+        }
+    };
+
+    set_ptrs(0);
+    gload(advance_load());  // K-step 0
+    lstore(0);
+    gload(advance_load());  // K-step 1 (or K-step 0 again), stays in registers until iteration 0
+    lds_barrier();
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) frag_piece(fa0, fb0, 0, 0, pc);
+
+    for (int g = 0; g < total; ++g) {
+        const int buf = g & 1;
+        const int k0 = advance_load();   // K-step g+2 (clamped to the last one past the end)
+        stamp();
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int j = step >> 2, e = step & 3;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = row0 + mb * 32 + mfma32_row(r, hi);
-                    if (row < p.M && colok) {
-                        float v = acc[mb][nb][r];
-                        if constexpr (FLAGS & OMNITOK_GEMM_BIAS) v += bv;
-                        if constexpr (FLAGS & OMNITOK_GEMM_LEAKY) v = v > 0.0f ? v : 0.1f * v;
-                        if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) v += p.residual[row * p.ldr + col];
-                        p.c[row * p.ldc + col] = v;
-                    }
-                }
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[mb][j][e], fb0[nb][j][e], acc[mb][nb], 0,
+                                                                      0, 0);
+            if (step < 4) {  // F1 reads early in the half: long landed when the second half starts
+                frag_piece(fa1, fb1, buf, 1, 2 * step);
+                frag_piece(fa1, fb1, buf, 1, 2 * step + 1);
+            }
+            // all eight LDS stores (steps 0-3) before the first new global load (steps 4-7), so that
+            // the vmcnt wait in front of a store never covers a load issued in this K-step
+            if (step < 4) {
+                stage_piece(buf ^ 1, 2 * step, true, false, k0);
+                stage_piece(buf ^ 1, 2 * step + 1, true, false, k0);
+            } else {
+                stage_piece(buf ^ 1, 2 * (step - 4), false, true, k0);
+                stage_piece(buf ^ 1, 2 * (step - 4) + 1, false, true, k0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        lds_barrier();
+#pragma unroll
+        for (int step = 0; step < 8; ++step) {
+            const int j = step >> 2, e = step & 3;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[mb][j][e], fb1[nb][j][e], acc[mb][nb], 0,
+                                                                      0, 0);
+            if (step < 4) {
+                frag_piece(fa0, fb0, buf ^ 1, 0, 2 * step);
+                frag_piece(fa0, fb0, buf ^ 1, 0, 2 * step + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        stamp();
+        if (++ck == nk) {
+            const int lid = xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, p.ntiles);
+            gemm_epilogue<FLAGS>(p, acc, lid / p.nbn, lid % p.nbn, wm, wn, r32, hi);
+            zero_acc();
+            ck = 0;
+            ++ctile;
+        }
+        stamp();
     }
 }
 
 template <int FLAGS>
-static int launch_gemm(const GemmParams &p, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-        attr_set = true;
+static int launch_gemm(GemmParams p, hipStream_t stream) {
+    static int attr_bytes[2] = {0, 0};
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        OT_HIP(hipGetDevice(&dev));
+        OT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     }
     const int64_t nbm = (p.M + BM - 1) / BM;
     const int64_t nwg = nbm * p.nbn;
     OT_CHECK_ARG(nwg < (1ll << 31), "gemm grid too large");
-    hipLaunchKernelGGL(gemm_f32_mfma<FLAGS>, dim3((unsigned)nwg), dim3(256), GEMM_LDS_BYTES, stream, p);
+    p.ntiles = (int)nwg;
+    p.trace = g_gemm_trace;
+    // persistent streaming kernel for anything that fills the chip more than once; bit 2 of the
+    // option forces the chosen variant whatever the size (tests)
+    int variant = g_gemm_variant & 1;
+    if (variant == 1 && nwg <= 2 * n_cu && !(g_gemm_variant & 4)) variant = 0;
+    const int lds = GEMM_LDS_BYTES + g_gemm_lds_pad_kb * 1024;
+    const void *fn = variant ? reinterpret_cast<const void *>(gemm_f32_mfma_persistent<FLAGS>)
+                             : reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS>);
+    if (attr_bytes[variant] < lds) {
+        OT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_bytes[variant] = lds;
+    }
+    if (variant)
+        hipLaunchKernelGGL(gemm_f32_mfma_persistent<FLAGS>, dim3(2 * n_cu), dim3(256), lds, stream, p);
+    else
+        hipLaunchKernelGGL(gemm_f32_mfma<FLAGS>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     OT_LAUNCH_CHECK("gemm_f32_mfma");
     return OMNITOK_OK;
 }

@@ -18,3 +18,9 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionstart(session):
+    # the CPU oracle (ATen/MKL) is much slower with every SMT thread of a large host than with a subset
+    import torch
+    torch.set_num_threads(min(32, os.cpu_count() or 1))

@@ -168,3 +168,34 @@ def test_full_size_properties(models, is_image, batch):
     # encode -> decode -> encode round trip stays in range and is deterministic
     ids2 = m.encode(rec.contiguous(), is_image)
     assert torch.equal(ids2, m.encode(rec.contiguous(), is_image))
+
+
+def test_c5_long_sequence_stress(models):
+    """BASELINE config C5 shape: one 65-frame 512x512 clip, n_codes = 16384 (T' = 17 -> streaming
+    temporal kernel, N = 4096 tokens per frame -> 64 K/V tiles per query block, 64x64 window grid),
+    against the CPU oracle."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    args = make_args(2, resolution=512, n_codes=16384, sequence_length=65)
+    cfg = OmniTokConfig.from_args(args)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    m = OmniTokenizer_VQGAN(args)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = synth.synth_video(1, 65, 512, seed=3)
+    ids, z = m.encode(x.cuda(), False, return_latents=True)
+    assert tuple(ids.shape) == (1, 17, 64, 64)
+    with torch.no_grad():
+        taps = {}
+        ids_ref = orc.encode(sd, x, False, cfg, taps=taps)
+        rec_ref = orc.decode(sd, ids_ref, False, cfg)
+    zerr = (z.cpu() - taps["z"]).abs().max().item()
+    assert zerr < 3e-5, zerr
+    flips = assert_ids_match_or_near_tie(ids, ids_ref, z, sd["codebook.embeddings"], "c5")
+    rec = m.decode(ids_ref.cuda(), False)
+    assert rec.shape == (1, 3, 65, 512, 512)
+    err = (rec.cpu() - rec_ref).abs().max().item()
+    assert err < PIXEL_TOL, err
+    # flat video ids need args.resolution = 512 (reference omnitokenizer.py:283-286)
+    assert torch.equal(m.decode(ids_ref.reshape(1, -1).cuda(), False), rec)
+    print(f"c5: id flips {flips}/{ids.numel()}, z err {zerr:.1e}, pixel err {err:.1e}")

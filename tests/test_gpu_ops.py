@@ -24,6 +24,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=[4, 5], ids=["tile_per_wg", "persistent_stream"])
+def gemm_variant(request):
+    """Runs a test once per GEMM kernel variant (forced whatever the problem size)."""
+    from omnitokenizer_amd import _lib
+    _lib.set_option("gemm_variant", request.param)
+    yield request.param
+    _lib.set_option("gemm_variant", 1)
+
+
 def dev(t):
     return t.contiguous().cuda()
 
@@ -49,9 +58,9 @@ def test_layernorm(ops, dim, with_beta):
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 512, 512), (1000, 192, 512), (300, 8, 512), (130, 1024, 192),
-                                   (4096, 1536, 512), (257, 768, 1408)])
+                                   (4096, 1536, 512), (257, 768, 1408), (20000 + 77, 1024, 512)])
 @pytest.mark.parametrize("mode", ["plain", "bias", "residual", "bias_residual", "bias_leaky"])
-def test_gemm(ops, M, N, K, mode):
+def test_gemm(ops, gemm_variant, M, N, K, mode):
     a, w = rnd(M, K, seed=4), rnd(N, K, seed=5) * 0.05
     bias = rnd(N, seed=6) if "bias" in mode else None
     res = rnd(M, N, seed=7) if "residual" in mode else None
@@ -68,7 +77,7 @@ def test_gemm(ops, M, N, K, mode):
     assert maxerr(out, ref) < 3e-6 * max(scale, 1.0) * math.sqrt(K / 512), f"scale {scale}"
 
 
-def test_gemm_inplace_residual_and_row_map(ops):
+def test_gemm_inplace_residual_and_row_map(ops, gemm_variant):
     import ctypes
     from omnitokenizer_amd import _lib
     M, N, K = 640, 512, 512
@@ -90,7 +99,7 @@ def test_gemm_inplace_residual_and_row_map(ops):
 
 
 @pytest.mark.parametrize("M", [512, 1000])
-def test_gemm_geglu_feedforward(ops, M):
+def test_gemm_geglu_feedforward(ops, gemm_variant, M):
     inner, D, pad = 1365, 512, 1408
     x = rnd(M, D, seed=11)
     w1, w2 = rnd(2 * inner, D, seed=12) * 0.05, rnd(D, inner, seed=13) * 0.05
