@@ -146,6 +146,19 @@ def main():
                             peak=PEAK_HBM_GBS, unit="GB/s", avg_launch_ms=round(avg_ms, 4),
                             bytes_per_launch=per_launch_bytes, traffic=None)
         roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
+        # HBM traffic per launch of the dominant kernel, from the committed PMC passes (rocprofv3
+        # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied; bench.py cannot
+        # collect counters itself).  null if no PMC run covers this kernel / workload.
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
+                roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
+                roofline["traffic_source"] = pmc[dom]["source"]
+                alg_bytes = {"gemm_ff_in": (B * tokens_per_clip) * (512 + 1408) * 4 + 2816 * 512 * 4}.get(dom)
+                if alg_bytes:
+                    roofline["algorithmic_bytes"] = alg_bytes
+        except Exception:
+            pass
         # the two kernels north_star names, with its formulas
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
             L = B * tokens_per_clip

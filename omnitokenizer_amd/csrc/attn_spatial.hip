@@ -20,6 +20,11 @@
 
 namespace omnitok {
 
+// exp(x) for x <= 0 as one multiply-add and one v_exp_f32 (1 ulp): on gfx950 every VALU instruction
+// issued between fp32 MFMAs costs matrix-pipe time (measured ~5 cycles each), and the library expf
+// is ~15 instructions per element of P.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 // -------------------------------------------------------------------------------------------
 // qk_prep: one 16-lane row per (token, head); each lane owns 4 consecutive channels, so the RoPE
 // pairs (2j, 2j+1) are lane-local and the l2 norm is a 4-step DPP all-reduce.
@@ -77,7 +82,7 @@ constexpr int AT_LDS_BYTES = 2 * AT_STAGE_FLOATS * 4;
 struct AttnParams {
     const float *q; const float *k; const float *v; float *out;
     int64_t ldq, ldkv, ldo;
-    int N, heads;
+    int N, heads, nqb, ngrp_real;
     const float *bias_table;  // [(2gh-1)*(2gw-1), heads] or null
     int gh, gw;
 };
@@ -87,7 +92,15 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hi = lane >> 5;
-    const int qb = blockIdx.x, head = blockIdx.y, seq = blockIdx.z;
+    // XCD-aware mapping (workgroup b runs on XCD b % 8, each XCD has its own L2): all query blocks
+    // of one (sequence, head) are placed on the same XCD so that its K/V (256 KiB at N = 1024) is
+    // fetched from HBM once and re-read from that L2 by the other query blocks -- measured without
+    // this: 5.7 GB of memory-side reads per launch at C3 against 1.0 GB algorithmic.
+    const int nqb = p.nqb;
+    const int b = blockIdx.x, j = b >> 3;
+    const int grp = (j / nqb) * 8 + (b & 7);  // (sequence, head) pair; heads * Bn is a multiple of 8
+    if (grp >= p.ngrp_real) return;  // padding workgroup (uniform exit before any barrier)
+    const int qb = j % nqb, head = grp % p.heads, seq = grp / p.heads;
     const int64_t seq_row0 = (int64_t)seq * p.N;
     // N % 64 == 0 but not necessarily % 128: the last workgroup may have idle waves, which still
     // take part in the cooperative K/V staging and barriers but store nothing
@@ -176,20 +189,26 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(AttnParams p) {
             for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
             mx = fmaxf(mx, swap32(mx));
             const float m_new = fmaxf(m_run, mx);
-            const float alpha = expf(m_run - m_new);  // 0 on the first tile (m_run = -inf)
+            const float mc = m_new * 1.44269504088896340736f;
             float ps = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                st[r] = expf(st[r] - m_new);
+                st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], 1.44269504088896340736f, -mc));
                 ps += st[r];
             }
             ps += swap32(ps);
-            l_run = l_run * alpha + ps;
+            // rescale only when some query of the wave saw its running max grow (wave-uniform
+            // branch; exact: alpha == 1 for every lane otherwise)
+            if (__any(m_new != m_run)) {
+                const float alpha = fast_exp(m_run - m_new);  // 0 on the first tile (m_run = -inf)
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            }
+            l_run += ps;
             m_run = m_new;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
             // ---- O^T += V^T . P^T -----------------------------------------------------------
             // step r: k-slot 0 -> key (r&3)+8*(r>>2), k-slot 1 -> that + 4 (lanes 32-63)
 #pragma unroll
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(WinParams p, int64_
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(st[kb][qb][r] - mx);
+                const float e = fast_exp(st[kb][qb][r] - mx);
                 st[kb][qb][r] = e;
                 ps += e;
             }
@@ -369,7 +388,7 @@ extern "C" int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k,
     OT_CHECK_ARG(!bias_table || gh * gw == N, "attn_spatial: bias grid %dx%d != N=%d", gh, gw, N);
     OT_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) &&
                      aligned16(out), "attn_spatial: unaligned");
-    OT_CHECK_ARG(heads <= 65535 && Bn <= 65535, "attn_spatial: grid too large");
+    OT_CHECK_ARG((int64_t)heads * Bn * ((N + 127) / 128) < (1ll << 31) - 8, "attn_spatial: grid too large");
     if (Bn == 0) return OMNITOK_OK;
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.out = out; p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.N = N; p.heads = heads;
@@ -382,7 +401,12 @@ extern "C" int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k,
                                    hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
         attr_set = true;
     }
-    dim3 grid((N + 127) / 128, heads, Bn);
+    p.nqb = (N + 127) / 128;
+    // groups (sequence, head) are dealt to the 8 XCDs round-robin; pad the group count to a multiple
+    // of 8 with idle workgroups when heads * Bn is not one
+    const int ngrp = ((heads * Bn + 7) / 8) * 8;
+    p.ngrp_real = heads * Bn;
+    dim3 grid((unsigned)((int64_t)ngrp * p.nqb));
     if (bias_table)
         hipLaunchKernelGGL(attn_spatial_kernel<true>, grid, dim3(256), AT_LDS_BYTES, stream, p);
     else

@@ -373,6 +373,19 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             OT_RUN("peg3d", 2.0 * L * D * 4.0,
                    omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
             std::swap(e->X, e->X2);
+            if (!spatial && T == 1) {
+                // Images: a temporal sequence of one token.  softmax over a single key is exactly 1
+                // (causal or not, with or without ALiBi), so the attention output is V bit for bit:
+                // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
+                // half and the attention kernel drop out.  Identical results to the general path.
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       omnitok_gemm(e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D,
+                                    0, 0, 0, 0, stream));
+                OT_RUN("gemm_out", gemm_f * D,
+                       omnitok_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D,
+                                    OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+                goto feed_forward;
+            }
             OT_RUN("layernorm", 2.0 * L * D * 4.0,
                    omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
             float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
@@ -416,6 +429,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                    omnitok_gemm(e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
                                 OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
         }
+    feed_forward:
         // FeedForward (reference attention.py:153-168)
         OT_RUN("layernorm", 2.0 * L * D * 4.0,
                omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));

@@ -41,13 +41,30 @@ struct GemmParams {
     int64_t M;
     int N, K;
     int nbn;  // number of tile columns
+    int nbm;  // number of tile rows
     int ntiles;
     long long *trace;  // debug: per-wave s_memtime stamps of workgroup 0 (null = off)
     int64_t a_rpg, a_stride, a_off;
 };
 
+// exact-erf GELU (reference attention.py:155-156, F.gelu default).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, i.e. fp32-roundoff class) in 14 branch-free VALU instructions instead of the
+// library erff's ~34 + divergent branches: the GEGLU epilogue evaluates it 32 times per lane per
+// tile, and on gfx950 VALU work between fp32 MFMAs costs matrix-pipe time.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * ax * ax);
+    return copysignf(fmaf(-p, e, 1.0f), x);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
 // fused epilogue on the accumulator registers (bias, leaky-relu, residual add, GEGLU)
@@ -89,10 +106,28 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)
 }
 
 // XCD-aware bijective remap of a linear tile id (workgroup b runs on XCD b % 8): each XCD sweeps a
-// contiguous range of tiles, column index fastest, so the 128xK A panel stays in that XCD's L2
+// contiguous range of the tile order below, so neighbouring tiles share that XCD's L2
 __device__ __forceinline__ int xcd_remap(int id, int n) {
     const int xcd = id & 7, q = n >> 3, rem = n & 7;
     return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (id >> 3);
+}
+
+// Tile order: column groups of GN = 8 tiles, row-major inside a group.  The ~64 tiles an XCD has
+// in flight then touch 8 A panels + 8 W tiles (4 MiB at K = 512 = the XCD's L2) instead of 3 A
+// panels + ALL W tiles (5.8 MiB for the FF-in weight, which thrashed: 4.5 GB of memory-side reads
+// per launch against 0.34 GB of operands).
+constexpr int GN = 8;
+__device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int64_t &bm, int &bn) {
+    const int full = nbn / GN;            // number of full column groups
+    const int gsz = GN * nbm;             // tiles per full group
+    int cg = lid / gsz, rem = lid - cg * gsz, width = GN;
+    if (cg >= full) {                     // the last, narrower group
+        cg = full;
+        rem = lid - full * gsz;
+        width = nbn - full * GN;
+    }
+    bm = rem / width;
+    bn = cg * GN + rem % width;
 }
 
 template <int FLAGS>
@@ -105,8 +140,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
     const int r32 = lane & 31, hi = lane >> 5;
 
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
-    const int64_t bm = lid / p.nbn;
-    const int bn = lid % p.nbn;
+    int64_t bm;
+    int bn;
+    tile_coords(lid, p.nbm, p.nbn, bm, bn);
 
     // ---- loader mapping: thread -> 4 rows x one float4 column of the 128x32 tile ----------
     const int lrow = tid >> 3, lc4 = tid & 7;
@@ -222,8 +258,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
     const float *wp[4];
     auto set_ptrs = [&](int i) {
         const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
-        const int64_t tbm = lid / p.nbn;
-        const int tbn = lid % p.nbn;
+        int64_t tbm;
+        int tbn;
+        tile_coords(lid, p.nbm, p.nbn, tbm, tbn);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int64_t gr = tbm * BM + lrow + 32 * r;
@@ -372,7 +409,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
         stamp();
         if (++ck == nk) {
             const int lid = xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, p.ntiles);
-            gemm_epilogue<FLAGS>(p, acc, lid / p.nbn, lid % p.nbn, wm, wn, r32, hi);
+            int64_t ebm;
+            int ebn;
+            tile_coords(lid, p.nbm, p.nbn, ebm, ebn);
+            gemm_epilogue<FLAGS>(p, acc, ebm, ebn, wm, wn, r32, hi);
             zero_acc();
             ck = 0;
             ++ctile;
@@ -394,6 +434,7 @@ static int launch_gemm(GemmParams p, hipStream_t stream) {
     const int64_t nwg = nbm * p.nbn;
     OT_CHECK_ARG(nwg < (1ll << 31), "gemm grid too large");
     p.ntiles = (int)nwg;
+    p.nbm = (int)nbm;
     p.trace = g_gemm_trace;
     // persistent streaming kernel for anything that fills the chip more than once; bit 2 of the
     // option forces the chosen variant whatever the size (tests)
