@@ -185,6 +185,15 @@ int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_cod
 int omnitok_vq_embed_st(const int64_t *ids, const float *z, const float *codebook, int cdim,
                         int64_t B, int64_t thw, float *emb, omnitok_stream_t stream);
 
+/* Codebook statistics that Codebook.forward returns next to the ids (reference
+ * modules/codebook.py:54-72, 122-140; read by vqgan_eval.py:152,195 through forward(log_image=True)):
+ * batch_usage[c] = fraction of the n ids equal to c; out2 = {perplexity, avg_usage};
+ * codebook_usage (the module's EMA buffer) is updated in place: = batch_usage on the first call,
+ * usage_sigma * old + (1 - usage_sigma) * batch_usage afterwards. counts_scratch: n_codes ints. */
+int omnitok_vq_stats(const int64_t *ids, int64_t n, int n_codes, int *counts_scratch,
+                     float *batch_usage, float *codebook_usage, int first_call, float usage_sigma,
+                     float *out2, omnitok_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Engine: the whole encode()/decode() path behind one handle.
  * ------------------------------------------------------------------------------------------ */

@@ -51,6 +51,7 @@ _PROTOS = {
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
     "omnitok_vq_embed_st": [P, P, P, c_int, I64, I64, P, P],
+    "omnitok_vq_stats": [P, I64, c_int, P, P, P, c_int, c_float, P, P],
     "omnitok_engine_create": [POINTER(OmnitokConfig), POINTER(P)],
     "omnitok_engine_destroy": [P],
     "omnitok_engine_set_weight": [P, c_char_p, P, POINTER(I64), c_int, c_int, P],

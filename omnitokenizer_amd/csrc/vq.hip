@@ -201,9 +201,73 @@ __global__ __launch_bounds__(256) void vq_embed_st_kernel(const int64_t *__restr
     }
 }
 
+// ---- codebook statistics of Codebook.forward (reference modules/codebook.py:122-140) ----------
+// counts[c] = number of tokens mapped to code c (one int atomic per token; ids are spread over
+// 8192 codes so contention is negligible)
+__global__ __launch_bounds__(256) void vq_hist_kernel(const int64_t *__restrict__ ids, int64_t n, int n_codes,
+                                                      int *__restrict__ counts) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t id = ids[i];
+        if (id >= 0 && id < n_codes) atomicAdd(counts + id, 1);
+    }
+}
+
+// one workgroup: batch_usage[c] = counts[c] / n (calculate_batch_codebook_usage_percentage, :54-72),
+// perplexity = exp(-sum_c p_c log(p_c + 1e-10)) (:122-123), EMA codebook_usage (:133-136) and
+// avg_usage = #(codebook_usage > 1/n_codes) / n_codes (:139-140).  out = {perplexity, avg_usage}.
+__global__ __launch_bounds__(1024) void vq_stats_finalize_kernel(const int *__restrict__ counts, int64_t n,
+                                                                 int n_codes, float *__restrict__ batch_usage,
+                                                                 float *__restrict__ codebook_usage, int first_call,
+                                                                 float sigma, float *__restrict__ out) {
+    __shared__ float s_ent[1024];
+    __shared__ int s_used[1024];
+    float ent = 0.0f;
+    int used = 0;
+    const float thr = 1.0f / (float)n_codes;
+    for (int c = threadIdx.x; c < n_codes; c += blockDim.x) {
+        const float pc = (float)counts[c] / (float)n;
+        batch_usage[c] = pc;
+        ent += pc * logf(pc + 1e-10f);
+        const float u = first_call ? pc : sigma * codebook_usage[c] + (1.0f - sigma) * pc;
+        codebook_usage[c] = u;
+        used += u > thr ? 1 : 0;
+    }
+    s_ent[threadIdx.x] = ent;
+    s_used[threadIdx.x] = used;
+    __syncthreads();
+    for (int st = blockDim.x / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            s_ent[threadIdx.x] += s_ent[threadIdx.x + st];
+            s_used[threadIdx.x] += s_used[threadIdx.x + st];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = expf(-s_ent[0]);
+        out[1] = (float)s_used[0] / (float)n_codes;
+    }
+}
+
 }  // namespace omnitok
 
 using namespace omnitok;
+
+extern "C" int omnitok_vq_stats(const int64_t *ids, int64_t n, int n_codes, int *counts_scratch, float *batch_usage,
+                                float *codebook_usage, int first_call, float usage_sigma, float *out2,
+                                omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(ids && counts_scratch && batch_usage && codebook_usage && out2 && n > 0 && n_codes > 0,
+                 "vq_stats: bad arguments");
+    OT_HIP(hipMemsetAsync(counts_scratch, 0, (size_t)n_codes * sizeof(int), stream));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(vq_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ids, n, n_codes, counts_scratch);
+    OT_LAUNCH_CHECK("vq_hist");
+    hipLaunchKernelGGL(vq_stats_finalize_kernel, dim3(1), dim3(1024), 0, stream, counts_scratch, n, n_codes,
+                       batch_usage, codebook_usage, first_call, usage_sigma, out2);
+    OT_LAUNCH_CHECK("vq_stats_finalize");
+    return OMNITOK_OK;
+}
 
 extern "C" int omnitok_pre_vq(const float *x, const float *w, const float *b, float *z, int64_t n, int D, int cdim,
                               int l2, omnitok_stream_t stream_) {

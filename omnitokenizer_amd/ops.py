@@ -216,6 +216,19 @@ def dequant_post_vq(ids, codebook, w, b):
     return tok
 
 
+def vq_stats(ids, n_codes, codebook_usage, first_call, usage_sigma=0.99):
+    """(batch_usage [n_codes], perplexity, avg_usage) of reference Codebook.forward; updates the
+    EMA buffer codebook_usage in place."""
+    ids = _req(ids, "ids", torch.int64)
+    counts = torch.empty(n_codes, device=ids.device, dtype=torch.int32)
+    usage = torch.empty(n_codes, device=ids.device, dtype=torch.float32)
+    out2 = torch.empty(2, device=ids.device, dtype=torch.float32)
+    check(_lib.load().omnitok_vq_stats(_p(ids), ids.numel(), n_codes, _p(counts), _p(usage),
+                                       _p(_req(codebook_usage, "codebook_usage")), int(bool(first_call)),
+                                       usage_sigma, _p(out2), _stream()), "vq_stats")
+    return usage, out2[0], out2[1]
+
+
 # ------------------------------------------------------------------------------------------------
 # PyTorch custom-op registration (omnitok:: namespace)
 # ------------------------------------------------------------------------------------------------

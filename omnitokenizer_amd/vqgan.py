@@ -79,6 +79,9 @@ class OmniTokenizer_VQGAN(nn.Module):
         self.codebook.embedding_dim = cfg.codebook_dim
         self.codebook._need_init = False  # training-time k-means init (codebook.py:40-51) is not on the path
 
+        self.codebook.call_cnt = 0          # reference codebook.py:19 (usage EMA state)
+        self.codebook.usage_sigma = 0.99    # reference codebook.py:12
+
         self._engine = None
         self._engine_sig = None
         self._timing = False
@@ -264,7 +267,15 @@ class OmniTokenizer_VQGAN(nn.Module):
             idx = torch.randint(0, T, [B], device=x.device).reshape(-1, 1, 1, 1, 1).repeat(1, C, 1, H, W)
             frames = torch.gather(x, 2, idx).squeeze(2)
             frames_recon = torch.gather(x_recon, 2, idx).squeeze(2)
-        return frames, frames_recon, x, x_recon, dict(embeddings=emb, encodings=ids)
+        # the statistics Codebook.forward returns next to the ids (reference codebook.py:122-143);
+        # vqgan_eval.py:152,195 accumulates batch_usage
+        from . import ops
+        cb = self.codebook
+        usage, perplexity, avg_usage = ops.vq_stats(ids, self.cfg.n_codes, cb.codebook_usage.data,
+                                                    cb.call_cnt == 0, cb.usage_sigma)
+        cb.call_cnt += 1
+        return frames, frames_recon, x, x_recon, dict(embeddings=emb, encodings=ids, batch_usage=usage,
+                                                      perplexity=perplexity, avg_usage=avg_usage)
 
     # ---- measurement hooks ----------------------------------------------------------------------
     def set_timing(self, enabled: bool):

@@ -102,6 +102,32 @@ def test_forward_log_image(models):
     assert (c.strided(x_recon.cpu()) - c.recon).abs().max().item() < PIXEL_TOL
 
 
+def test_forward_codebook_statistics(models):
+    """batch_usage / perplexity / avg_usage / EMA buffer of reference Codebook.forward
+    (modules/codebook.py:54-72, 122-140), which vqgan_eval.py:152,195 reads."""
+    c = GoldenCase("s2_sdpa_r64_vid")
+    from omnitokenizer_amd import OmniTokenizer_VQGAN
+    m = OmniTokenizer_VQGAN(c.args)
+    m.load_state_dict(c.sd, strict=True)
+    m = m.cuda().eval()
+    n_codes = c.cfg.n_codes
+    ema = None
+    for call in range(2):
+        x = c.x.cuda() if call == 0 else (c.x * 0.5).cuda()
+        _, _, _, _, vq = m(x, log_image=True)
+        ids = vq["encodings"].cpu().reshape(-1)
+        usage = torch.bincount(ids, minlength=n_codes).float() / ids.numel()
+        avg_probs = usage
+        perp = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))
+        ema = usage if call == 0 else 0.99 * ema + 0.01 * usage
+        avg_usage = (ema > 1 / n_codes).sum() / n_codes
+        assert (vq["batch_usage"].cpu() - usage).abs().max().item() < 1e-7
+        assert abs(vq["perplexity"].item() - perp.item()) < 1e-3 * perp.item()
+        assert abs(vq["avg_usage"].item() - avg_usage.item()) < 1e-6
+        assert (m.codebook.codebook_usage.data.cpu() - ema).abs().max().item() < 1e-7
+    assert m.codebook.call_cnt == 2
+
+
 def test_error_behaviour(models):
     c = GoldenCase("s2_sdpa_r64_vid")
     m = models(c)
