@@ -136,9 +136,13 @@ def test_patchify_ln_and_unpatchify(ops, pt, frames):
         assert vid[:, :, :f0].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 8, 8), (1, 1, 32, 32), (3, 3, 16, 16), (1, 17, 8, 8)])
+@pytest.mark.parametrize("shape", [(2, 5, 8, 8), (1, 1, 32, 32), (3, 3, 16, 16), (1, 17, 8, 8), (1, 2, 64, 64),
+                                   (2, 4, 6, 40)])
 @pytest.mark.parametrize("causal", [True, False])
-def test_peg3d(ops, shape, causal):
+@pytest.mark.parametrize("variant", [0, 1], ids=["regblock", "lds_ring"])
+def test_peg3d(ops, shape, causal, variant):
+    from omnitokenizer_amd import _lib
+    _lib.set_option("peg_variant", variant)
     B, T, H, W = shape
     D = 512
     x = rnd(B * T, H * W, D, seed=31)
