@@ -25,8 +25,8 @@ constexpr int TILE_FLOATS = BM * LDT;
 constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * TILE_FLOATS * 4;
 
 // tuning knobs (omnitok_set_option, A/B measurements): "gemm_variant" 0 = one 128x128 tile per
-// workgroup, 1 = persistent workgroups with the fully interleaved MFMA stream (default), +4 = force;
-// "gemm_lds_pad_kb" extra dynamic LDS per workgroup (limits workgroups per CU).
+// workgroup, 1 / 2 = persistent workgroups with the fully interleaved MFMA stream (128x128 x 4 waves /
+// 256x128 x 8 waves), +4 = force; "gemm_lds_pad_kb" extra dynamic LDS per workgroup (variants 0, 1).
 int g_gemm_variant = 1;
 int g_gemm_lds_pad_kb = 0;
 long long *g_gemm_trace = nullptr;
@@ -67,20 +67,73 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
-// fused epilogue on the accumulator registers (bias, leaky-relu, residual add, GEGLU)
-template <int FLAGS>
+// Fused epilogue on the accumulator registers (bias, leaky-relu, residual add, GEGLU).
+// NEDGE = false (N % 64 == 0, every production shape): buffer loads/stores through wave-uniform
+// descriptors of this wave's 64x64 output tile -- per element one SGPR offset and one shared 32-bit
+// lane offset, so no 64-bit VGPR address per element, no VALU address arithmetic, and all residual
+// loads of a column block in flight together.  Rows beyond M are dropped by the descriptor's
+// num_records bound (loads return 0), so no per-element guards are needed: with guards hipcc emits
+// branch / load / wait / store per element, i.e. 64 serialised memory round trips per tile.
+// NEDGE = true: per-element guards (only the N = heads = 8 GEMM of the position-bias MLP).
+template <int FLAGS, bool NEDGE>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams &p, f32x16 (&acc)[2][2], int64_t bm, int bn, int wm,
                                               int wn, int r32, int hi) {
     const int64_t row0 = bm * BM + wm * 64;
+    auto uniform_rsrc = [](const float *ptr, int bytes) {
+        const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
+        const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi32 << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+    };
+    int64_t vr64 = p.M - row0;  // valid rows of this wave tile
+    const int vr = vr64 > 64 ? 64 : (vr64 < 0 ? 0 : (int)vr64);
     if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
-        const int ocol = (bn * 2 + wn) * 32 + r32;
+        const int ocolb = (bn * 2 + wn) * 32;
+        const int ldc = (int)p.ldc;
+        const auto c_rs = uniform_rsrc(p.c + row0 * p.ldc + ocolb, vr > 0 ? ((vr - 1) * ldc + 32) * 4 : 0);
+        const int c_voff = (4 * hi * ldc + r32) * 4;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = row0 + mb * 32 + mfma32_row(r, hi);
-                if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[mb][1][r]) * acc[mb][0][r];
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(
+                    __builtin_bit_cast(unsigned, gelu_erf(acc[mb][1][r]) * acc[mb][0][r]), c_rs, c_voff,
+                    (mb * 32 + mfma32_row(r, 0)) * ldc * 4, 0);
+    } else if constexpr (!NEDGE) {
+        const int colb = bn * BN + wn * 64;
+        if (colb >= p.N) return;  // N % 64 == 0: a wave tile is entirely inside or entirely outside
+        const int ldc = (int)p.ldc, ldr = (int)p.ldr;
+        const auto c_rs = uniform_rsrc(p.c + row0 * p.ldc + colb, vr > 0 ? ((vr - 1) * ldc + 64) * 4 : 0);
+        const int c_voff = (4 * hi * ldc + r32) * 4;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            float res[2][16];  // 32 residual loads in flight per column block
+            if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) {
+                const auto r_rs = uniform_rsrc(p.residual + row0 * p.ldr + colb, vr > 0 ? ((vr - 1) * ldr + 64) * 4 : 0);
+                const int r_voff = (4 * hi * ldr + r32) * 4;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[mb][r] = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(
+                                       r_rs, r_voff, ((mb * 32 + mfma32_row(r, 0)) * ldr + nb * 32) * 4, 0));
             }
+            float bv = 0.0f;
+            if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = p.bias[colb + nb * 32 + r32];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mb][nb][r];
+                    if constexpr (FLAGS & OMNITOK_GEMM_BIAS) v += bv;
+                    if constexpr (FLAGS & OMNITOK_GEMM_LEAKY) v = v > 0.0f ? v : 0.1f * v;
+                    if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) v += res[mb][r];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, c_voff,
+                                                          ((mb * 32 + mfma32_row(r, 0)) * ldc + nb * 32) * 4, 0);
+                }
+        }
     } else {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
@@ -130,7 +183,7 @@ __device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int64_t &
     bn = cg * GN + rem % width;
 }
 
-template <int FLAGS>
+template <int FLAGS, bool NEDGE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -222,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
         __syncthreads();
     }
 
-    gemm_epilogue<FLAGS>(p, acc, bm, bn, wm, wn, r32, hi);
+    gemm_epilogue<FLAGS, NEDGE>(p, acc, bm, bn, wm, wn, r32, hi);
 }
 
 
@@ -235,12 +288,21 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("" ::: "memory");
 }
 
-// Persistent variant: 2 workgroups per CU walk the tile list (tile = blockIdx.x + i * gridDim.x,
-// then XCD-remapped); the global->register->LDS pipeline runs ACROSS tile boundaries, so per tile
-// there is no launch, no address prologue and no exposed first-load latency -- only the epilogue's
-// issue time sits between the last MFMA of one tile and the first of the next.
-template <int FLAGS>
-__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p) {
+// Persistent variant: workgroups walk the tile list (tile = blockIdx.x + i * gridDim.x, then
+// XCD-remapped); the global->register->LDS pipeline runs ACROSS tile boundaries, so per tile there
+// is no launch, no address prologue and no exposed first-load latency -- only the epilogue's issue
+// time sits between the last MFMA of one tile and the first of the next.
+// WM = wave rows: WM = 2 -> 128x128 tile, 4 waves, two workgroups per CU;
+//                 WM = 4 -> 256x128 tile, 8 waves (two per SIMD, same barrier domain), one per CU.
+template <int FLAGS, int WM, bool TRACE>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_f32_mfma_persistent(GemmParams p) {
+    constexpr int NT = 128 * WM;          // threads
+    constexpr int TM = 64 * WM;           // tile rows
+    constexpr int RPP = NT / 8;           // tile rows covered by one loader pass
+    constexpr int NA = TM / RPP;          // loader passes over A (= 4)
+    constexpr int NB = BN / RPP;          // loader passes over B (4 or 2)
+    constexpr int NP = NA + NB;           // staged float4 pieces per thread per K-step
+    constexpr int A_FLOATS = TM * LDT, STAGE_FLOATS = (TM + BN) * LDT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -251,45 +313,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
     if ((int)blockIdx.x >= p.ntiles) return;
 
     const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int total = my_tiles * nk;
 
     const int lrow = tid >> 3, lc4 = tid & 7;
-    const float *ap[4];
-    const float *wp[4];
+    const float *ap[NA];
+    const float *wp[NB];
     auto set_ptrs = [&](int i) {
         const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
         int64_t tbm;
         int tbn;
         tile_coords(lid, p.nbm, p.nbn, tbm, tbn);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int64_t gr = tbm * BM + lrow + 32 * r;
+        for (int r = 0; r < NA; ++r) {
+            int64_t gr = tbm * TM + lrow + RPP * r;
             if (gr > p.M - 1) gr = p.M - 1;
             int64_t ar = gr;
             if (p.a_rpg > 0) ar = (gr / p.a_rpg) * p.a_stride + p.a_off + (gr % p.a_rpg);
             ap[r] = p.a + ar * p.lda + lc4 * 4;
-            int wr = tbn * BN + lrow + 32 * r;
+        }
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+            int wr = tbn * BN + lrow + RPP * r;
             if (wr > p.N - 1) wr = p.N - 1;
             wp[r] = p.w + (int64_t)wr * p.ldw + lc4 * 4;
         }
     };
     const int st_off = lrow * LDT + lc4 * 4;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[NA], rb[NB];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
-            rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
-        }
+        for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
     };
     auto lstore = [&](int buf) {
-        float *As = smem + buf * 2 * TILE_FLOATS;
-        float *Bs = As + TILE_FLOATS;
+        float *As = smem + buf * STAGE_FLOATS;
+        float *Bs = As + A_FLOATS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
-            *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
-        }
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4 *>(As + st_off + i * RPP * LDT) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4 *>(Bs + st_off + i * RPP * LDT) = rb[i];
     };
     f32x16 acc[2][2];
     auto zero_acc = [&]() {
@@ -305,33 +367,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
     const int b_frag_off = (wn * 64 + r32) * LDT + hi * 16;
 
     // Measured with s_memtime stamps (tools/gemm_trace.py): while one wave streams MFMAs its SIMD
-    // partner's non-MFMA instructions are not issued, so the two workgroups of a CU take turns
-    // K-step by K-step and everything a wave does OUTSIDE its own MFMA stream is exposed time.
-    // So every LDS / global instruction is embedded in the stream, one per group of 4 MFMAs:
-    //   steps 0-7  (fragments F0 of K-step g): ds_read F1(g) piece, ds_write piece of K-step g+1
-    //              (fetched one K-step ago), global load of the same piece of K-step g+2
+    // partner's non-MFMA instructions are not issued, so two 4-wave workgroups on a CU end up taking
+    // turns K-step by K-step and everything a wave does OUTSIDE its own MFMA stream is exposed time.
+    // So every LDS / global instruction is embedded in the stream, between groups of 4 MFMAs:
+    //   steps 0-7  (fragments F0 of K-step g): ds_read F1(g), ds_write of K-step g+1 (fetched one
+    //              K-step ago; all stores before the first new load), global loads of K-step g+2
     //   lgkmcnt(0) + s_barrier            (orders LDS only; K-step g+1 is now complete in LDS)
-    //   steps 8-15 (fragments F1): ds_read F0(g+1) piece
+    //   steps 8-15 (fragments F1): ds_read F0(g+1)
     // Hazards: tile g+1 is stored before barrier(g) and first read after it; buffer g&1 is
     // overwritten (tile g+2) after barrier(g+1) >= every read of tile g (issued before barrier(g)).
-    int lk = 0, ltile = 0, lg = 0;  // load stream: the next K-step to fetch is lg
-    auto advance_load = [&]() {     // returns the k offset of K-step lg, switching tile if needed
-        if (lg > 0 && lg < total && ++lk == nk) {
-            lk = 0;
-            set_ptrs(++ltile);
-        }
-        ++lg;
-        return lk * BK;  // past the end: lk stays on the last valid K-step
-    };
-    int ck = 0, ctile = 0;
     int tn = 0;
     auto stamp = [&]() {
-        if (p.trace && blockIdx.x == 0 && lane == 0 && tn < 96) p.trace[wave * 96 + tn++] = __builtin_readcyclecounter();
+        if constexpr (TRACE)
+            if (p.trace && blockIdx.x == 0 && lane == 0 && tn < 96) p.trace[wave * 96 + tn++] = __builtin_readcyclecounter();
     };
     f32x4 fa0[2][2], fb0[2][2], fa1[2][2], fb1[2][2];  // [row block][j] fragments of the two halves
     auto frag_piece = [&](f32x4 (&fa)[2][2], f32x4 (&fb)[2][2], int buf, int half, int piece) {
-        const float *As = smem + buf * 2 * TILE_FLOATS;
-        const float *Bs = As + TILE_FLOATS;
+        const float *As = smem + buf * STAGE_FLOATS;
+        const float *Bs = As + A_FLOATS;
         const int mb = (piece >> 1) & 1, j = piece & 1;
         if (piece < 4)
             fa[mb][j] = *reinterpret_cast<const f32x4 *>(As + a_frag_off + mb * 32 * LDT + 8 * half + 4 * j);
@@ -340,31 +393,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
     };
     // store/load are compile-time after unrolling: a RUNTIME condition around a load makes hipcc
     // branch around it and wait vmcnt(0) per element (cdna guide 5, trap (c)); past the end of the
-    // tile list the stream simply re-fetches its last K-step and stores it to the idle buffer
+    // tile list the stream simply re-fetches valid data and stores it to the idle buffer
     auto stage_piece = [&](int buf, int piece, bool store, bool load, int k0) {
-        float *As = smem + buf * 2 * TILE_FLOATS;
-        float *Bs = As + TILE_FLOATS;
-        const int i = piece & 3;
-        if (piece < 4) {
-            if (store) *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
-            if (load) ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
-        } else {
-            if (store) *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
+        float *As = smem + buf * STAGE_FLOATS;
+        float *Bs = As + A_FLOATS;
+        if (piece < NA) {
+            if (store) *reinterpret_cast<f32x4 *>(As + st_off + piece * RPP * LDT) = ra[piece];
+            if (load) ra[piece] = *reinterpret_cast<const f32x4 *>(ap[piece] + k0);
+        } else if (piece < NP) {
+            const int i = piece - NA;
+            if (store) *reinterpret_cast<f32x4 *>(Bs + st_off + i * RPP * LDT) = rb[i];
             if (load) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
         }
     };
-
-    set_ptrs(0);
-    gload(advance_load());  // K-step 0
-    lstore(0);
-    gload(advance_load());  // K-step 1 (or K-step 0 again), stays in registers until iteration 0
-    lds_barrier();
-#pragma unroll
-    for (int pc = 0; pc < 8; ++pc) frag_piece(fa0, fb0, 0, 0, pc);
-
-    for (int g = 0; g < total; ++g) {
-        const int buf = g & 1;
-        const int k0 = advance_load();   // K-step g+2 (clamped to the last one past the end)
+    // one K-step of the stream: fragments of LDS buffer `buf`, stores the staged K-step into the
+    // other buffer and fetches the K-step at offset k0 of the current load pointers
+    auto kstep = [&](int buf, int k0) {
         stamp();
 #pragma unroll
         for (int step = 0; step < 8; ++step) {
@@ -379,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
                 frag_piece(fa1, fb1, buf, 1, 2 * step);
                 frag_piece(fa1, fb1, buf, 1, 2 * step + 1);
             }
-            // all eight LDS stores (steps 0-3) before the first new global load (steps 4-7), so that
-            // the vmcnt wait in front of a store never covers a load issued in this K-step
+            // all LDS stores (steps 0-3) before the first new global load (steps 4-7), so that the
+            // vmcnt wait in front of a store never covers a load issued in this K-step
             if (step < 4) {
                 stage_piece(buf ^ 1, 2 * step, true, false, k0);
                 stage_piece(buf ^ 1, 2 * step + 1, true, false, k0);
@@ -407,23 +451,66 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_persistent(GemmParams p)
             __builtin_amdgcn_sched_barrier(0);
         }
         stamp();
-        if (++ck == nk) {
-            const int lid = xcd_remap((int)blockIdx.x + ctile * (int)gridDim.x, p.ntiles);
-            int64_t ebm;
-            int ebn;
-            tile_coords(lid, p.nbm, p.nbn, ebm, ebn);
-            gemm_epilogue<FLAGS>(p, acc, ebm, ebn, wm, wn, r32, hi);
-            zero_acc();
-            ck = 0;
-            ++ctile;
-        }
-        stamp();
+    };
+
+    // prologue: K-steps 0 and 1 of the first tile (nk is even and >= 2: the launcher checks)
+    set_ptrs(0);
+    gload(0);
+    lstore(0);
+    gload(BK);  // stays in registers until the middle of the first K-step
+    lds_barrier();
+#pragma unroll
+    for (int pc = 0; pc < 8; ++pc) frag_piece(fa0, fb0, 0, 0, pc);
+
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        // K-steps 0 .. nk-3 fetch K-steps 2 .. nk-1 of the same tile
+        for (int k = 0; k < nk - 2; ++k) kstep(k & 1, (k + 2) * BK);
+        // the last two fetch K-steps 0 and 1 of the next tile (of this tile again when it is the last)
+        if (ti + 1 < my_tiles) set_ptrs(ti + 1);
+        kstep(0, 0);   // k = nk-2 (even): LDS buffer 0
+        kstep(1, BK);  // k = nk-1
+        const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
+        int64_t ebm;
+        int ebn;
+        tile_coords(lid, p.nbm, p.nbn, ebm, ebn);
+        // the shared epilogue addresses 64x64 wave tiles in 128-row units
+        gemm_epilogue<FLAGS, false>(p, acc, ebm * (WM / 2) + (wm >> 1), ebn, wm & 1, wn, r32, hi);
+        zero_acc();
     }
+}
+
+template <int FLAGS, int WM>
+static int launch_persistent(GemmParams p, int n_cu, hipStream_t stream) {
+    static int attr = 0;
+    constexpr int TM = 64 * WM;
+    const int lds = 2 * (TM + BN) * LDT * 4 + (WM == 2 ? g_gemm_lds_pad_kb * 1024 : 0);
+    if (attr < lds) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<FLAGS, WM, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (FLAGS == 0)
+            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<0, WM, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = lds;
+    }
+    p.nbm = (int)((p.M + TM - 1) / TM);
+    const int64_t ntiles = (int64_t)p.nbm * p.nbn;
+    OT_CHECK_ARG(ntiles < (1ll << 31), "gemm grid too large");
+    p.ntiles = (int)ntiles;
+    const int wg_per_cu = WM == 2 ? 2 : 1;
+    if (FLAGS == 0 && p.trace) {  // instrumented build of the plain variant (tools/gemm_trace.py)
+        hipLaunchKernelGGL((gemm_f32_mfma_persistent<0, WM, true>), dim3(wg_per_cu * n_cu), dim3(128 * WM), lds,
+                           stream, p);
+    } else {
+        hipLaunchKernelGGL((gemm_f32_mfma_persistent<FLAGS, WM, false>), dim3(wg_per_cu * n_cu), dim3(128 * WM), lds,
+                           stream, p);
+    }
+    OT_LAUNCH_CHECK("gemm_f32_mfma_persistent");
+    return OMNITOK_OK;
 }
 
 template <int FLAGS>
 static int launch_gemm(GemmParams p, hipStream_t stream) {
-    static int attr_bytes[2] = {0, 0};
+    static int attr_bytes = 0;
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -436,21 +523,38 @@ static int launch_gemm(GemmParams p, hipStream_t stream) {
     p.ntiles = (int)nwg;
     p.nbm = (int)nbm;
     p.trace = g_gemm_trace;
-    // persistent streaming kernel for anything that fills the chip more than once; bit 2 of the
-    // option forces the chosen variant whatever the size (tests)
-    int variant = g_gemm_variant & 1;
-    if (variant == 1 && nwg <= 2 * n_cu && !(g_gemm_variant & 4)) variant = 0;
+    // variant: 0 one 128x128 tile per workgroup; 1 persistent 128x128 (two 4-wave workgroups per CU);
+    // 2 persistent 256x128 (one 8-wave workgroup per CU).  Persistent kernels only when the problem
+    // fills the chip more than once; bit 2 (+4) forces the variant whatever the size (tests).
+    int variant = g_gemm_variant & 3;
+    const bool force = (g_gemm_variant & 4) != 0;
+    if (variant && nwg <= 2 * n_cu && !force) variant = 0;
+    const int nk = p.K / BK;
+    if (nk < 2 || (nk & 1)) variant = 0;  // the persistent stream is unrolled over K-step pairs
+    if (p.N % 64) variant = 0;            // persistent kernels use the unguarded buffer epilogue
+    // measured at C3: the 8-wave 256x128 workgroup is ahead for the wide GEGLU GEMM (131 vs 128 TF),
+    // the two 4-wave 128x128 workgroups for the N <= 1536 projections (134-140 vs 131-140 TF)
+    if (variant == 1 && !force && (FLAGS & OMNITOK_GEMM_GEGLU)) variant = 2;
+    if (variant == 2) return launch_persistent<FLAGS, 4>(p, n_cu, stream);
+    if (variant == 1) return launch_persistent<FLAGS, 2>(p, n_cu, stream);
     const int lds = GEMM_LDS_BYTES + g_gemm_lds_pad_kb * 1024;
-    const void *fn = variant ? reinterpret_cast<const void *>(gemm_f32_mfma_persistent<FLAGS>)
-                             : reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS>);
-    if (attr_bytes[variant] < lds) {
-        OT_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_bytes[variant] = lds;
+    const bool nedge = (p.N % 64) != 0;
+    if (attr_bytes < lds) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU))
+            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_bytes = lds;
     }
-    if (variant)
-        hipLaunchKernelGGL(gemm_f32_mfma_persistent<FLAGS>, dim3(2 * n_cu), dim3(256), lds, stream, p);
-    else
-        hipLaunchKernelGGL(gemm_f32_mfma<FLAGS>, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU)) {
+        if (nedge) {
+            hipLaunchKernelGGL((gemm_f32_mfma<FLAGS, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+            OT_LAUNCH_CHECK("gemm_f32_mfma");
+            return OMNITOK_OK;
+        }
+    }
+    hipLaunchKernelGGL((gemm_f32_mfma<FLAGS, false>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
     OT_LAUNCH_CHECK("gemm_f32_mfma");
     return OMNITOK_OK;
 }

@@ -24,7 +24,7 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=[4, 5], ids=["tile_per_wg", "persistent_stream"])
+@pytest.fixture(params=[4, 5, 6], ids=["tile_per_wg", "persistent_128x128", "persistent_256x128"])
 def gemm_variant(request):
     """Runs a test once per GEMM kernel variant (forced whatever the problem size)."""
     from omnitokenizer_amd import _lib
