@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Phase timeline of the ping-pong GEMM (workgroup 0): s_memtime stamps around M / barrier / L."""
+"""K-step timeline of the persistent GEMM (workgroup 0): s_memtime stamps at the start and the end of
+every K-step stream (2 per K-step per wave); deltas alternate stream / gap."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
