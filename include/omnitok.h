@@ -192,6 +192,19 @@ int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_cod
                             const float *w, const float *b, float *tok, int64_t n, int D,
                             int *err_flag, omnitok_stream_t stream);
 
+/* --use_vae posterior sample (reference modules/vae.py:4-17 on top of pre_vq_conv with 2*cdim
+ * outputs): h = x[n,:] . w[2*cdim, D]^T + b, n = B*thw rows in (b, thw) order;
+ * z[B,cdim,thw] = h[:, :cdim] + exp(0.5*clamp(h[:, cdim:], -30, 20)) * noise[B,cdim,thw]
+ * (noise NULL: z = mean).  moments (optional) [B,2*cdim,thw] = h.  cdim == 8, D % 64 == 0. */
+int omnitok_vae_sample(const float *x, const float *w, const float *b, const float *noise,
+                       float *z, float *moments, int64_t B, int64_t thw, int D, int cdim,
+                       omnitok_stream_t stream);
+
+/* tok[n, :] = z[n, :] . w[D, cdim]^T + b for continuous latents (post_vq_conv, reference
+ * omnitokenizer.py:156-160, 305/316).  channel_first: z[B,cdim,thw], else z[B*thw, cdim]. */
+int omnitok_post_vq(const float *z, int channel_first, int64_t B, int64_t thw, int cdim,
+                    const float *w, const float *b, float *tok, int D, omnitok_stream_t stream);
+
 /* emb[b, c, t, h, w] = (E[ids] - z) + z  (straight-through value, codebook.py:120), from
  * z[b,t,h,w,c] / ids[b,t,h,w]; thw = t*h*w. */
 int omnitok_vq_embed_st(const int64_t *ids, const float *z, const float *codebook, int cdim,
@@ -232,6 +245,7 @@ typedef struct omnitok_config {
     int temporal_depth;        /* 4 */
     char enc_block[16];        /* "ttww" */
     char dec_block[16];        /* "tttt" */
+    int use_vae;               /* --use_vae: pre_vq emits mean|logvar, no quantiser (omnitokenizer.py:143-154) */
 } omnitok_config;
 
 int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine **out);
@@ -259,6 +273,25 @@ int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W
 /* VQGAN.decode: ids[B,T',h,w] -> pixels[B,C,F,h*p,w*p], F = 1 + (T'-1)*pt. */
 int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int h, int w,
                    float *pixels_out, omnitok_stream_t stream);
+
+/* --use_vae variants (reference omnitokenizer.py:260-266 encode, :293-317 decode; the KL-regularised
+ * tokenizer DiT/Latte train on, Diffusion/Latte/train.py:216, sample_ddp.py:201-203).  The engine
+ * must have been created with cfg.use_vae = 1 (pre_vq_conv.1.weight is [2*cdim, dim]);
+ * omnitok_encode/omnitok_decode then return OMNITOK_ERR_STATE and vice versa.
+ *
+ * encode_vae: x[B,C,F,H,W] -> z_out[B,cdim,T',h,w] = mean + exp(0.5*clamp(logvar,-30,20)) * noise
+ * (modules/vae.py:4-17).  noise: [B,cdim,T',h,w] standard normal supplied by the caller (the
+ * reference draws it with torch.randn on the host), or NULL for the posterior mode (z = mean).
+ * moments_out (optional): the raw pre_vq output [B,2*cdim,T',h,w] (mean | unclamped logvar), what
+ * DiagonalGaussianDistribution.kl() consumes. */
+int omnitok_encode_vae(omnitok_engine *e, const float *x, int B, int F, int H, int W,
+                       const float *noise, float *z_out, float *moments_out,
+                       omnitok_stream_t stream);
+/* decode_vae: z -> pixels[B,C,F,h*p,w*p].  channel_first = 1: z[B,cdim,T',h,w] (the image
+ * branch's 'b c h w', omnitokenizer.py:303-304, and encode_vae's output); channel_first = 0:
+ * z[B,T',h,w,cdim] (the video branch's 'b t h w c' and both flat '(t h w) c' forms). */
+int omnitok_decode_vae(omnitok_engine *e, const float *z, int channel_first, int B, int T, int h,
+                       int w, float *pixels_out, omnitok_stream_t stream);
 
 /* decode() checks ids against [0, n_codes) on the device; this reads the flag back
  * (synchronises the stream) and returns OMNITOK_ERR_INVALID if any id was out of range --

@@ -20,7 +20,7 @@ class OmnitokConfig(Structure):
         ("ff_inner", c_int), ("window_size", c_int), ("n_codes", c_int), ("codebook_dim", c_int),
         ("l2_code", c_int), ("spatial_rope", c_int), ("legacy_attention", c_int),
         ("causal_temporal", c_int), ("causal_peg", c_int), ("temporal_depth", c_int),
-        ("enc_block", c_char * 16), ("dec_block", c_char * 16),
+        ("enc_block", c_char * 16), ("dec_block", c_char * 16), ("use_vae", c_int),
     ]
 
 
@@ -52,6 +52,8 @@ _PROTOS = {
     "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
+    "omnitok_vae_sample": [P, P, P, P, P, P, I64, I64, c_int, c_int, P],
+    "omnitok_post_vq": [P, c_int, I64, I64, c_int, P, P, P, c_int, P],
     "omnitok_vq_embed_st": [P, P, P, c_int, I64, I64, P, P],
     "omnitok_vq_stats": [P, I64, c_int, P, P, P, c_int, c_float, P, P],
     "omnitok_engine_create": [POINTER(OmnitokConfig), POINTER(P)],
@@ -61,6 +63,8 @@ _PROTOS = {
     "omnitok_engine_missing": [P, c_char_p, c_int],
     "omnitok_encode": [P, P, c_int, c_int, c_int, c_int, P, P, P, P],
     "omnitok_decode": [P, P, c_int, c_int, c_int, c_int, P, P],
+    "omnitok_encode_vae": [P, P, c_int, c_int, c_int, c_int, P, P, P, P],
+    "omnitok_decode_vae": [P, P, c_int, c_int, c_int, c_int, c_int, P, P],
     "omnitok_engine_check_ids": [P, P],
     "omnitok_engine_workspace_bytes": [P],
     "omnitok_engine_set_timing": [P, c_int],

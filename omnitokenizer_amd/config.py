@@ -101,8 +101,6 @@ class OmniTokConfig:
                     "are not used by any released config and are not built")
         if len(self.enc_block) != self.spatial_depth:
             raise ValueError("len(enc_block) must equal spatial_depth (reference attention.py:608)")
-        if self.use_vae:
-            raise NotImplementedError("use_vae path (reference omnitokenizer.py:260-266) is not built yet")
         if self.use_external_codebook:
             raise NotImplementedError("use_external_codebook (VectorQuantize) is not built; the released "
                                       "configs use modules/codebook.py::Codebook")

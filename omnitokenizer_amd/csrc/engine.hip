@@ -540,9 +540,11 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
     e->spec["decoder.to_pixels_first_frame.0.bias"] = {k0};
     e->spec["decoder.to_pixels.0.weight"] = {k1, d};
     e->spec["decoder.to_pixels.0.bias"] = {k1};
-    e->spec["codebook.embeddings"] = {c.n_codes, c.codebook_dim};
-    e->spec["pre_vq_conv.1.weight"] = {c.codebook_dim, d};
-    e->spec["pre_vq_conv.1.bias"] = {c.codebook_dim};
+    // --use_vae: no quantiser on the path, pre_vq emits mean | logvar (reference omnitokenizer.py:143-154)
+    const int64_t pre_out = c.use_vae ? 2 * c.codebook_dim : c.codebook_dim;
+    if (!c.use_vae) e->spec["codebook.embeddings"] = {c.n_codes, c.codebook_dim};
+    e->spec["pre_vq_conv.1.weight"] = {pre_out, d};
+    e->spec["pre_vq_conv.1.bias"] = {pre_out};
     e->spec["post_vq_conv.1.weight"] = {d, c.codebook_dim};
     e->spec["post_vq_conv.1.bias"] = {d};
     // drop keys the inference path never reads
@@ -629,9 +631,12 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     if (int rc = build_transformer(e, e->enc_t, "encoder.enc_temporal_transformer", tb, false, stream)) return rc;
     if (int rc = build_transformer(e, e->dec_s, "decoder.dec_spatial_transformer", c.dec_block, true, stream)) return rc;
     if (int rc = build_transformer(e, e->dec_t, "decoder.dec_temporal_transformer", tb, false, stream)) return rc;
-    if (int rc = alloc_f(e, &e->cb_packed, (int64_t)c.n_codes * 8)) return rc;
-    if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
-    if (int rc = omnitok_vq_prepare(W(e, "codebook.embeddings"), c.n_codes, 8, e->cb_packed, e->cb_ee, stream)) return rc;
+    if (!c.use_vae) {
+        if (int rc = alloc_f(e, &e->cb_packed, (int64_t)c.n_codes * 8)) return rc;
+        if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
+        if (int rc = omnitok_vq_prepare(W(e, "codebook.embeddings"), c.n_codes, 8, e->cb_packed, e->cb_ee, stream))
+            return rc;
+    }
     {
         // ALiBi slopes, reference attention.py:506-517 (_get_slopes)
         std::vector<float> sl;
@@ -662,12 +667,10 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     return OMNITOK_OK;
 }
 
-extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int64_t *ids_out,
-                              float *emb_out, float *z_out, omnitok_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(e, "encode: null engine");
-    if (B == 0) return OMNITOK_OK;
-    OT_CHECK_ARG(x && ids_out, "encode: null pointer");
+// encoder up to the pre_vq input: leaves tokens [B, T', h, w, D] in e->X  (reference
+// omnitokenizer.py:925-957 OmniTokenizer_Encoder.forward)
+static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int *T_out, int *S_out,
+                         hipStream_t stream) {
     if (!e->finalized) {
         set_error("encode: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -723,6 +726,27 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
         OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T, D, stream));
         std::swap(e->X, e->X2);
     }
+    *T_out = T;
+    *S_out = S;
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int64_t *ids_out,
+                              float *emb_out, float *z_out, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e, "encode: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(x && ids_out, "encode: null pointer");
+    if (e->cfg.use_vae) {
+        set_error("encode: engine was built with use_vae (no quantiser on the path, reference "
+                  "omnitokenizer.py:260-266); call omnitok_encode_vae");
+        return OMNITOK_ERR_STATE;
+    }
+    int T = 0, S = 0;
+    if (int rc = encode_tokens(e, x, B, F, H, W_, &T, &S, stream)) return rc;
+    const omnitok_config &c = e->cfg;
+    const int D = c.dim;
+    const int64_t L = (int64_t)B * T * S;
     // ---- pre_vq + l2norm + nearest code (reference omnitokenizer.py:248-255) ----------------
     OT_RUN("pre_vq", (double)L * D * 4.0,
            omnitok_pre_vq(e->X.p, W(e, "pre_vq_conv.1.weight"), W(e, "pre_vq_conv.1.bias"), e->Z.p, L, D, 8, c.l2_code,
@@ -736,12 +760,11 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
     return OMNITOK_OK;
 }
 
-extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int gh, int gw, float *pixels_out,
-                              omnitok_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(e, "decode: null engine");
-    if (B == 0) return OMNITOK_OK;
-    OT_CHECK_ARG(ids && pixels_out, "decode: null pointer");
+enum class LatentKind { Ids, ChannelLast, ChannelFirst };
+
+// shared decode body: latent (ids or continuous z) -> post_vq -> temporal -> spatial -> to_pixels
+static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent, int B, int T, int gh, int gw,
+                         float *pixels_out, hipStream_t stream) {
     if (!e->finalized) {
         set_error("decode: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -758,9 +781,15 @@ extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int 
     const int K0 = C * p * p, K1 = K0 * pt;
     const int H = gh * p, W_ = gw * p, F = 1 + (T - 1) * pt;
 
-    OT_RUN("dequant_post_vq", (double)L * D * 4.0,
-           omnitok_dequant_post_vq(ids, W(e, "codebook.embeddings"), c.n_codes, 8, W(e, "post_vq_conv.1.weight"),
-                                   W(e, "post_vq_conv.1.bias"), e->X.p, L, D, e->err_flag, stream));
+    if (kind == LatentKind::Ids)
+        OT_RUN("dequant_post_vq", (double)L * D * 4.0,
+               omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, "codebook.embeddings"), c.n_codes, 8,
+                                       W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, L, D,
+                                       e->err_flag, stream));
+    else
+        OT_RUN("post_vq", (double)L * D * 4.0,
+               omnitok_post_vq(static_cast<const float *>(latent), kind == LatentKind::ChannelFirst, B, (int64_t)T * S, 8,
+                               W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, D, stream));
     // temporal first on decode (reference omnitokenizer.py:1072-1084)
     if (T > 1) {
         OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S, D, stream));
@@ -789,6 +818,52 @@ extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int 
                omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T - 1, pt, p, pixels_out, stream));
     }
     return OMNITOK_OK;
+}
+
+extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int gh, int gw, float *pixels_out,
+                              omnitok_stream_t stream_) {
+    OT_CHECK_ARG(e, "decode: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(ids && pixels_out, "decode: null pointer");
+    if (e->cfg.use_vae) {
+        set_error("decode: engine was built with use_vae (latents are continuous, reference "
+                  "omnitokenizer.py:293-317); call omnitok_decode_vae");
+        return OMNITOK_ERR_STATE;
+    }
+    return decode_latent(e, LatentKind::Ids, ids, B, T, gh, gw, pixels_out, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int omnitok_encode_vae(omnitok_engine *e, const float *x, int B, int F, int H, int W_, const float *noise,
+                                  float *z_out, float *moments_out, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(e, "encode_vae: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(x && z_out, "encode_vae: null pointer");
+    if (!e->cfg.use_vae) {
+        set_error("encode_vae: engine was built without use_vae; call omnitok_encode");
+        return OMNITOK_ERR_STATE;
+    }
+    int T = 0, S = 0;
+    if (int rc = encode_tokens(e, x, B, F, H, W_, &T, &S, stream)) return rc;
+    const int D = e->cfg.dim;
+    const int64_t L = (int64_t)B * T * S;
+    OT_RUN("vae_sample", (double)L * D * 4.0,
+           omnitok_vae_sample(e->X.p, W(e, "pre_vq_conv.1.weight"), W(e, "pre_vq_conv.1.bias"), noise, z_out,
+                              moments_out, B, (int64_t)T * S, D, 8, stream));
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_decode_vae(omnitok_engine *e, const float *z, int channel_first, int B, int T, int gh, int gw,
+                                  float *pixels_out, omnitok_stream_t stream_) {
+    OT_CHECK_ARG(e, "decode_vae: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(z && pixels_out, "decode_vae: null pointer");
+    if (!e->cfg.use_vae) {
+        set_error("decode_vae: engine was built without use_vae; call omnitok_decode");
+        return OMNITOK_ERR_STATE;
+    }
+    return decode_latent(e, channel_first ? LatentKind::ChannelFirst : LatentKind::ChannelLast, z, B, T, gh, gw,
+                         pixels_out, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int64_t omnitok_engine_workspace_bytes(omnitok_engine *e) {

@@ -201,6 +201,88 @@ __global__ __launch_bounds__(256) void vq_embed_st_kernel(const int64_t *__restr
     }
 }
 
+// ---- --use_vae: DiagonalGaussianDistribution posterior (reference modules/vae.py:4-17) ---------
+// h = x W^T + b with W [16, D] (mean rows 0..7 | logvar rows 8..15, torch.chunk over channels);
+// z = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise.  One 16-lane DPP row per token row, lane c
+// and lane 8+c end up holding channel c's mean / logvar.  Outputs are channel-FIRST
+// [B, 8, thw] like the reference's 'b c t h w' tensors; noise has the same layout (it is
+// torch.randn(mean.shape) there).  noise == nullptr -> z = mean (posterior.mode()).
+__global__ __launch_bounds__(256) void vae_sample_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                         const float *__restrict__ b,
+                                                         const float *__restrict__ noise, float *__restrict__ z,
+                                                         float *__restrict__ moments, int64_t n, int64_t thw,
+                                                         int D) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (row >= n) return;
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.0f;
+    const float *xr = x + row * D;
+    for (int i = l16 * 4; i < D; i += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + i);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + c * D + i);
+            acc[c] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        }
+    }
+    float mine = 0.0f, other = 0.0f;  // lane l keeps h[l] and h[l ^ 8]
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float v = row16_allsum(acc[c]) + b[c];
+        if (c == l16) mine = v;
+        if (c == (l16 ^ 8)) other = v;
+    }
+    const int64_t bi = row / thw, s = row % thw;
+    if (moments) moments[(bi * 16 + l16) * thw + s] = mine;
+    if (l16 < 8) {
+        float out = mine;
+        if (noise) {
+            const float logvar = fminf(fmaxf(other, -30.0f), 20.0f);
+            out = __fadd_rn(mine, __fmul_rn(expf(0.5f * logvar), noise[(bi * 8 + l16) * thw + s]));
+        }
+        z[(bi * 8 + l16) * thw + s] = out;
+    }
+}
+
+// tok[n, 4c..4c+3] = b + sum_k z[n][k] * W[c][k] on continuous latents (the --use_vae decode,
+// reference omnitokenizer.py:293-317).  z element (row, k): channel-last [n, 8] or channel-first
+// [B, 8, thw].
+template <bool CHANNEL_FIRST>
+__global__ __launch_bounds__(256) void post_vq_latent_kernel(const float *__restrict__ z, int64_t thw,
+                                                             const float *__restrict__ w,
+                                                             const float *__restrict__ b, float *__restrict__ tok,
+                                                             int64_t n, int D) {
+    const int d4n = D >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * d4n) return;
+    const int64_t row = gid / d4n;
+    const int c4 = (int)(gid % d4n);
+    float e[8];
+    if (CHANNEL_FIRST) {
+        const int64_t bi = row / thw, s = row % thw;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = z[(bi * 8 + k) * thw + s];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) e[k] = z[row * 8 + k];
+    }
+    f32x4 o = reinterpret_cast<const f32x4 *>(b)[c4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(w + (c4 * 4 + j) * 8);
+        const f32x4 w1 = *reinterpret_cast<const f32x4 *>(w + (c4 * 4 + j) * 8 + 4);
+        float sacc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sacc = fmaf(e[k], w0[k], sacc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sacc = fmaf(e[4 + k], w1[k], sacc);
+        o[j] += sacc;
+    }
+    reinterpret_cast<f32x4 *>(tok)[gid] = o;
+}
+
 // ---- codebook statistics of Codebook.forward (reference modules/codebook.py:122-140) ----------
 // counts[c] = number of tokens mapped to code c (one int atomic per token; ids are spread over
 // 8192 codes so contention is negligible)
@@ -339,5 +421,38 @@ extern "C" int omnitok_vq_embed_st(const int64_t *ids, const float *z, const flo
     hipLaunchKernelGGL(vq_embed_st_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids, z,
                        codebook, B, thw, emb);
     OT_LAUNCH_CHECK("vq_embed_st");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_vae_sample(const float *x, const float *w, const float *b, const float *noise, float *z,
+                                  float *moments, int64_t B, int64_t thw, int D, int cdim,
+                                  omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t n = B * thw;
+    if (n == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(x && w && b && z, "vae_sample: null pointer");
+    OT_CHECK_ARG(cdim == 8, "vae_sample: codebook_dim=%d (kernels are built for 8)", cdim);
+    OT_CHECK_ARG(D % 64 == 0, "vae_sample: D %% 64 != 0");
+    const int64_t threads = n * 16;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, x, w, b,
+                       noise, z, moments, n, thw, D);
+    OT_LAUNCH_CHECK("vae_sample");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_post_vq(const float *z, int channel_first, int64_t B, int64_t thw, int cdim, const float *w,
+                               const float *b, float *tok, int D, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t n = B * thw;
+    if (n == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(z && w && b && tok, "post_vq: null pointer");
+    OT_CHECK_ARG(cdim == 8 && D % 4 == 0, "post_vq: need cdim == 8 and D %% 4 == 0");
+    const int64_t total = n * (D / 4);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (channel_first)
+        hipLaunchKernelGGL(post_vq_latent_kernel<true>, grid, dim3(256), 0, stream, z, thw, w, b, tok, n, D);
+    else
+        hipLaunchKernelGGL(post_vq_latent_kernel<false>, grid, dim3(256), 0, stream, z, thw, w, b, tok, n, D);
+    OT_LAUNCH_CHECK("post_vq");
     return OMNITOK_OK;
 }

@@ -243,6 +243,31 @@ def dequant_post_vq(ids, codebook, w, b):
     return tok
 
 
+def vae_sample(x, w, b, noise=None, return_moments=False):
+    """x [B, thw, D] tokens -> z [B, 8, thw] = mean + exp(0.5*clamp(logvar,-30,20))*noise (reference
+    modules/vae.py:4-17; w [16, D] = mean | logvar rows).  noise [B, 8, thw] or None (mode)."""
+    x = _req(x, "x")
+    B, thw, D = x.shape
+    z = torch.empty(B, 8, thw, device=x.device, dtype=torch.float32)
+    mom = torch.empty(B, 16, thw, device=x.device, dtype=torch.float32) if return_moments else None
+    check(_lib.load().omnitok_vae_sample(_p(x), _p(_req(w, "w")), _p(_req(b, "b")),
+                                         None if noise is None else _p(_req(noise, "noise")), _p(z),
+                                         None if mom is None else _p(mom), B, thw, D, 8, _stream()), "vae_sample")
+    return (z, mom) if return_moments else z
+
+
+def post_vq(z, w, b, channel_first=False):
+    """tok = z . w^T + b on continuous latents: z [B, thw, 8] or (channel_first) [B, 8, thw]."""
+    z = _req(z, "z")
+    B = z.shape[0]
+    thw = z.shape[2] if channel_first else z.shape[1]
+    D = w.shape[0]
+    tok = torch.empty(B, thw, D, device=z.device, dtype=torch.float32)
+    check(_lib.load().omnitok_post_vq(_p(z), int(channel_first), B, thw, 8, _p(_req(w, "w")), _p(_req(b, "b")),
+                                      _p(tok), D, _stream()), "post_vq")
+    return tok
+
+
 def vq_stats(ids, n_codes, codebook_usage, first_call, usage_sigma=0.99):
     """(batch_usage [n_codes], perplexity, avg_usage) of reference Codebook.forward; updates the
     EMA buffer codebook_usage in place."""

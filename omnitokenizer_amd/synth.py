@@ -90,8 +90,10 @@ def path_state_spec(cfg: OmniTokConfig) -> "OrderedDict[str, tuple]":
     spec["codebook.N"] = (cfg.n_codes,)
     spec["codebook.z_avg"] = (cfg.n_codes, cfg.codebook_dim)
     spec["codebook.codebook_usage"] = (cfg.n_codes,)
-    spec["pre_vq_conv.1.weight"] = (cfg.codebook_dim, d)
-    spec["pre_vq_conv.1.bias"] = (cfg.codebook_dim,)
+    # --use_vae: pre_vq emits mean | logvar (reference omnitokenizer.py:149-153)
+    pre_out = cfg.codebook_dim * (2 if cfg.use_vae else 1)
+    spec["pre_vq_conv.1.weight"] = (pre_out, d)
+    spec["pre_vq_conv.1.bias"] = (pre_out,)
     spec["post_vq_conv.1.weight"] = (d, cfg.codebook_dim)
     spec["post_vq_conv.1.bias"] = (d,)
     return spec

@@ -61,7 +61,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         self.n_codes = cfg.n_codes
         self.resolution = cfg.resolution
         self.patch_size = cfg.patch_size
-        self.use_vae = False
+        self.use_vae = cfg.use_vae
+        self.kl_weight = getattr(args, "kl_weight", 0.0)
         self.use_external_codebook = False
         self.l2_code = cfg.l2_code
 
@@ -135,6 +136,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         nc.temporal_depth = c.temporal_depth
         nc.enc_block = c.enc_block.encode()
         nc.dec_block = c.dec_block.encode()
+        nc.use_vae = int(c.use_vae)
         return nc
 
     def _signature(self):
@@ -173,10 +175,18 @@ class OmniTokenizer_VQGAN(nn.Module):
 
     # ---- the path -------------------------------------------------------------------------------
     @torch.no_grad()
-    def encode(self, x, is_image, include_embeddings=False, return_latents=False):
-        """reference omnitokenizer.py:247-258.  x: [B,C,H,W] (is_image) or [B,C,F,H,W] fp32 in
+    def encode(self, x, is_image, include_embeddings=False, return_latents=False, noise=None,
+               sample_posterior=True, return_moments=False):
+        """reference omnitokenizer.py:247-266.  x: [B,C,H,W] (is_image) or [B,C,F,H,W] fp32 in
         [-0.5,0.5] on the GPU.  Returns LongTensor ids [B,T',h,w]; with include_embeddings
-        (embeddings [B,cdim,T',h,w], ids)."""
+        (embeddings [B,cdim,T',h,w], ids).
+
+        With args.use_vae (:260-266) returns the posterior sample z [B,cdim,T',h,w]
+        ([B,cdim,h,w] for images).  The noise is drawn like the reference does
+        (modules/vae.py:16: torch.randn on the host with the global generator, then moved), so
+        torch.manual_seed() reproduces the reference's sample; pass `noise` ([B,cdim,T',h,w],
+        any device) to supply it, or sample_posterior=False for posterior.mode().
+        return_moments adds the raw mean|logvar tensor [B,2*cdim,T',h,w]."""
         if x.dim() not in (4, 5):
             raise AssertionError("video.ndim in {4, 5}")  # reference omnitokenizer.py:921
         if is_image:
@@ -199,6 +209,8 @@ class OmniTokenizer_VQGAN(nn.Module):
             raise AssertionError(f"number of frames ({F}) minus one ({F - 1}) must be divisible by temporal "
                                  f"patch size ({pt})")  # reference omnitokenizer.py:931-932
         T, h, w = 1 + (F - 1) // pt, H // p, W // p
+        if self.use_vae:
+            return self._encode_vae(x, is_image, (B, F, H, W, T, h, w), noise, sample_posterior, return_moments)
         ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
         emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device) if include_embeddings else None
         z = torch.empty(B, T, h, w, self.cfg.codebook_dim, device=x.device) if return_latents else None
@@ -212,12 +224,79 @@ class OmniTokenizer_VQGAN(nn.Module):
             return (emb, ids, z) if include_embeddings else (ids, z)
         return (emb, ids) if include_embeddings else ids
 
+    def _encode_vae(self, x, is_image, dims, noise, sample_posterior, return_moments):
+        B, F, H, W, T, h, w = dims
+        cd = self.cfg.codebook_dim
+        if sample_posterior:
+            if noise is None:
+                noise = torch.randn(B, cd, T, h, w)  # host draw, reference modules/vae.py:16
+            if tuple(noise.shape) != (B, cd, T, h, w) and not (is_image and tuple(noise.shape) == (B, cd, h, w)):
+                raise ValueError(f"noise must be [B,{cd},T',h,w] = {(B, cd, T, h, w)}, got {tuple(noise.shape)}")
+            noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
+        else:
+            noise = None
+        z = torch.empty(B, cd, T, h, w, device=x.device, dtype=torch.float32)
+        mom = torch.empty(B, 2 * cd, T, h, w, device=x.device, dtype=torch.float32) if return_moments else None
+        check(_lib.load().omnitok_encode_vae(self._engine, ctypes.c_void_p(x.data_ptr()), B, F, H, W,
+                                             None if noise is None else ctypes.c_void_p(noise.data_ptr()),
+                                             ctypes.c_void_p(z.data_ptr()),
+                                             None if mom is None else ctypes.c_void_p(mom.data_ptr()),
+                                             torch.cuda.current_stream().cuda_stream), "encode_vae")
+        if is_image:
+            z = z.squeeze(2)  # b c t h w -> b c h w, reference omnitokenizer.py:264
+        return (z, mom) if return_moments else z
+
+    def _decode_vae(self, z, is_image):
+        """reference omnitokenizer.py:293-317: image latents [B,hw,c] or channel-first [B,c,h,w];
+        video latents [B,thw,c] or channel-LAST [B,t,h,w,c] (what Latte's sampler hands over,
+        sample_ddp.py:201-203) -- encode()'s [B,c,t,h,w] must be permuted by the caller exactly
+        as with the reference."""
+        if z.device != self.device:
+            raise RuntimeError(f"latents on {z.device}, model on {self.device}")
+        z = z.to(torch.float32)
+        cd = self.cfg.codebook_dim
+        if z.dim() == 3:
+            if is_image:
+                h = int(math.sqrt(z.shape[1]))
+                z = z.reshape(z.shape[0], 1, h, -1, z.shape[-1])
+            else:
+                h = self.resolution // self.patch_size
+                z = z.reshape(z.shape[0], -1, h, h, z.shape[-1])
+            channel_first = 0
+        elif is_image:
+            if z.dim() != 4:
+                raise ValueError("is_image=True expects latents [B,c,h,w] or [B,hw,c]")
+            z = z.unsqueeze(2)
+            channel_first = 1
+        else:
+            if z.dim() != 5:
+                raise ValueError("is_image=False expects latents [B,t,h,w,c] or [B,thw,c]")
+            channel_first = 0
+        z = z.contiguous()
+        if channel_first:
+            B, C, T, h, w = z.shape
+        else:
+            B, T, h, w, C = z.shape
+        if C != cd:
+            raise ValueError(f"latent channel dim is {C}, expected codebook_dim={cd} "
+                             f"({'channel-first' if channel_first else 'channel-last'} layout)")
+        c = self.cfg
+        F = 1 + (T - 1) * c.temporal_patch_size
+        out = torch.empty(B, c.image_channels, F, h * c.patch_size, w * c.patch_size, device=z.device,
+                          dtype=torch.float32)
+        check(_lib.load().omnitok_decode_vae(self._engine, ctypes.c_void_p(z.data_ptr()), channel_first, B, T, h, w,
+                                             ctypes.c_void_p(out.data_ptr()),
+                                             torch.cuda.current_stream().cuda_stream), "decode_vae")
+        return out[:, :, 0] if is_image else out
+
     @torch.no_grad()
     def decode(self, encodings, is_image, check_ids: bool = False):
         """reference omnitokenizer.py:268-291.  encodings: ids [B,T',h,w], flat video ids
         [B,T'*h*w] (h = w = args.resolution // patch_size, :283-286) or flat image ids [B,h*w]
         (h = int(sqrt(h*w)), :272-275).  Returns [B,3,H,W] (is_image) or [B,3,F,H,W]."""
         self._sync_engine()
+        if self.use_vae:
+            return self._decode_vae(encodings, is_image)
         ids = encodings
         if ids.dtype != torch.int64:
             ids = ids.long()
@@ -258,8 +337,13 @@ class OmniTokenizer_VQGAN(nn.Module):
         if not log_image:
             raise NotImplementedError("training forward (losses, discriminators) is outside the built path")
         is_image = x.dim() == 4
-        emb, ids = self.encode(x, is_image, include_embeddings=True)
-        x_recon = self.decode(ids, is_image)
+        if self.use_vae:
+            # reference omnitokenizer.py:366-370, 410-411: sample -> post_vq -> decoder, vq_output None
+            z = self.encode(x, is_image)
+            x_recon = self.decode(z if is_image else z.permute(0, 2, 3, 4, 1), is_image)
+        else:
+            emb, ids = self.encode(x, is_image, include_embeddings=True)
+            x_recon = self.decode(ids, is_image)
         if is_image:
             frames, frames_recon = x, x_recon
         else:
@@ -267,6 +351,8 @@ class OmniTokenizer_VQGAN(nn.Module):
             idx = torch.randint(0, T, [B], device=x.device).reshape(-1, 1, 1, 1, 1).repeat(1, C, 1, H, W)
             frames = torch.gather(x, 2, idx).squeeze(2)
             frames_recon = torch.gather(x_recon, 2, idx).squeeze(2)
+        if self.use_vae:
+            return frames, frames_recon, x, x_recon, None
         # the statistics Codebook.forward returns next to the ids (reference codebook.py:122-143);
         # vqgan_eval.py:152,195 accumulates batch_usage
         from . import ops

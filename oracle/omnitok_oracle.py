@@ -300,6 +300,51 @@ def encode(sd, x, is_image, cfg, include_embeddings=False, taps=None):
     return ids
 
 
+def vae_posterior(sd, tok):
+    """reference omnitokenizer.py:248 + modules/vae.py:4-13: pre_vq Linear(dim -> 2*cdim) on channel-last
+    tokens, mean | logvar = chunk over channels, logvar clamped to [-30, 20], std = exp(0.5 logvar).
+    Returns (mean, std) as [b, c, t, h, w] like the reference's 'b c t h w' tensors."""
+    h = F.linear(tok, sd["pre_vq_conv.1.weight"], sd["pre_vq_conv.1.bias"]).permute(0, 4, 1, 2, 3)
+    mean, logvar = torch.chunk(h, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return mean, torch.exp(0.5 * logvar)
+
+
+def encode_vae(sd, x, is_image, cfg, noise=None):
+    """reference omnitokenizer.py:260-266 (--use_vae): z = mean + std * randn (vae.py:15-17; the
+    reference draws the noise on the CPU with the global generator).  noise [b,c,t,h,w] or None."""
+    tok = encoder(sd, x, is_image, cfg)
+    mean, std = vae_posterior(sd, tok)
+    if noise is None:
+        noise = torch.randn(mean.shape)
+    z = mean + std * noise
+    return z.squeeze(2) if is_image else z
+
+
+def decode_vae(sd, z, is_image, cfg):
+    """reference omnitokenizer.py:293-317 (--use_vae) -> post_vq -> decoder.  Accepted latent
+    layouts are the reference's, which are NOT symmetric with encode's output for video:
+      image: [b, hw, c] (:298-301) or channel-first [b, c, h, w] (:303-304, what encode returns);
+      video: [b, t*h*w, c] (:309-312) or channel-LAST [b, t, h, w, c] (:313-314; Latte
+             sample_ddp.py:201-203 permutes the sampler's output into it) -- encode's
+             [b, c, t, h, w] must be permuted by the caller."""
+    if z.ndim == 3:
+        if is_image:
+            hh = int(math.sqrt(z.shape[1]))
+            zl = z.reshape(z.shape[0], 1, hh, -1, z.shape[-1])
+        else:
+            hh = cfg.resolution // cfg.patch_size
+            zl = z.reshape(z.shape[0], -1, hh, hh, z.shape[-1])
+    elif is_image:
+        assert z.ndim == 4
+        zl = z.permute(0, 2, 3, 1).unsqueeze(1)
+    else:
+        assert z.ndim == 5
+        zl = z
+    tok = F.linear(zl, sd["post_vq_conv.1.weight"], sd["post_vq_conv.1.bias"])
+    return _decode_tokens(sd, tok, is_image, cfg, None)
+
+
 def decode(sd, ids, is_image, cfg, taps=None):
     """reference omnitokenizer.py:268-291 VQGAN.decode + 1101-1118 / 1059-1098 decoder."""
     z = F.embedding(ids, sd["codebook.embeddings"])
@@ -313,6 +358,11 @@ def decode(sd, ids, is_image, cfg, taps=None):
     tok = F.linear(z, sd["post_vq_conv.1.weight"], sd["post_vq_conv.1.bias"])  # b t h w d
     if taps is not None:
         taps["post_vq"] = tok
+    return _decode_tokens(sd, tok, is_image, cfg, taps)
+
+
+def _decode_tokens(sd, tok, is_image, cfg, taps):
+    """decoder on post_vq tokens [b,t,h,w,d] (reference omnitokenizer.py:1101-1118 / 1059-1098)."""
     b, t, h, w, d = tok.shape
     shape = (b, t, h, w)
     s = tok.permute(0, 2, 3, 1, 4).reshape(b * h * w, t, d)

@@ -10,6 +10,13 @@ a crc32 of the synthetic state_dict (pins omnitokenizer_amd/synth.py) and the re
   z       pre-VQ l2-normalised latents             (fp32)  -- lets the VQ kernel be tested on the
                                                               reference's own z, bit-exact
   recon   decode(ids) pixels, optionally strided   (fp32)
+
+vae_*.npz (--use_vae, reference omnitokenizer.py:260-266 / 293-317) store the host noise the
+reference drew (torch.manual_seed(noise_seed); torch.randn), the raw mean|logvar moments, the
+posterior sample z = encode(x) and recon = decode(z) in the layout the reference's decode accepts.
+
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py vae        # only the vae_* fixtures
 """
 import os
 import sys
@@ -80,6 +87,53 @@ def run_case(name, stage, mode, overrides, batch, frames, stride):
           f"absmax {recon.abs().max().item():.3f}")
 
 
+VAE_CASES = [
+    ("vae_s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64, use_vae=True), 2, 1, 1),
+    ("vae_s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64, use_vae=True), 2, 5, 1),
+    ("vae_s1_legacy_r64_vid", 1, "legacy", dict(resolution=64, use_vae=True), 1, 5, 1),
+    ("vae_s2_sdpa_r256_vid", 2, "sdpa", dict(resolution=256, use_vae=True), 1, 5, 4),
+]
+
+
+def run_vae_case(name, stage, mode, overrides, batch, frames, stride, noise_seed=4321):
+    args = make_args(stage, **overrides)
+    cfg = OmniTokConfig.from_args(args, attention_mode=mode)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = rh.build_reference_model(args)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    is_image = frames == 1
+    res = cfg.resolution
+    x = synth.synth_image(batch, res, seed=1234) if is_image else synth.synth_video(batch, frames, res, seed=1234)
+    with torch.no_grad(), rh.attention_mode(mode):
+        moments = model.pre_vq_conv(model.encoder(x, is_image))          # b 2c t h w
+        torch.manual_seed(noise_seed)
+        noise = torch.randn(batch, cfg.codebook_dim, *moments.shape[2:])  # what vae.py:16 draws
+        torch.manual_seed(noise_seed)
+        z = model.encode(x, is_image)                                     # b c h w | b c t h w
+        z5 = z.unsqueeze(2) if is_image else z
+        # the layouts reference decode accepts (omnitokenizer.py:296-316)
+        z_in = z if is_image else z.permute(0, 2, 3, 4, 1).contiguous()
+        recon = model.decode(z_in, is_image)
+        flat = z5.permute(0, 2, 3, 4, 1).reshape(batch, -1, cfg.codebook_dim)
+        assert torch.equal(recon, model.decode(flat, is_image))
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    assert torch.equal(z5, mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise)
+    sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        stage=stage, mode=mode, overrides=repr(overrides), batch=batch, frames=frames,
+        stride=stride, weight_seed=0, input_seed=1234, noise_seed=noise_seed,
+        state_crc=np.uint32(synth.state_checksum(sd)),
+        input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
+        noise=noise.numpy(), moments=moments.contiguous().numpy(), z=z5.contiguous().numpy(),
+        recon=recon[sl].contiguous().numpy(),
+        recon_absmax=np.float32(recon.abs().max().item()),
+    )
+    print(f"{name}: z {tuple(z.shape)} std {z.std().item():.3f} logvar [{logvar.min().item():.2f}, "
+          f"{logvar.max().item():.2f}] recon {tuple(recon.shape)} absmax {recon.abs().max().item():.3f}")
+
+
 def make_vq_kat():
     """Known-answer vectors for the quantizer alone, from the reference's Codebook.forward
     (modules/codebook.py:76-143): random unit-norm z, un-normalised z, exact code rows, and
@@ -114,6 +168,12 @@ def make_vq_kat():
 
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
-    make_vq_kat()
-    for c in CASES:
-        run_case(*c)
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "vq"):
+        make_vq_kat()
+    if only in (None, "e2e"):
+        for c in CASES:
+            run_case(*c)
+    if only in (None, "vae"):
+        for c in VAE_CASES:
+            run_vae_case(*c)

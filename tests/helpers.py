@@ -18,6 +18,9 @@ E2E_CASES = ["s2_sdpa_r64_img", "s2_sdpa_r64_vid", "s2_sdpa_r64_vid9", "s1_legac
 SMALL_CASES = [c for c in E2E_CASES if "r64" in c]
 
 
+VAE_CASES = ["vae_s2_sdpa_r64_img", "vae_s2_sdpa_r64_vid", "vae_s1_legacy_r64_vid", "vae_s2_sdpa_r256_vid"]
+
+
 class GoldenCase:
     def __init__(self, name):
         g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -39,11 +42,23 @@ class GoldenCase:
         self.x = (synth.synth_image(self.batch, res, seed) if self.is_image
                   else synth.synth_video(self.batch, self.frames, res, seed))
         assert zlib.crc32(self.x.numpy().tobytes()) == int(g["input_crc"]), "synthetic input drifted"
-        self.ids = torch.from_numpy(g["ids"].astype(np.int64))
-        self.z = torch.from_numpy(g["z"])          # b t h w c
-        self.emb = torch.from_numpy(g["emb"])      # b t h w c
+        self.is_vae = "noise" in g.files
+        if self.is_vae:  # --use_vae fixture (make_golden.run_vae_case)
+            self.noise = torch.from_numpy(g["noise"])      # b c t h w
+            self.moments = torch.from_numpy(g["moments"])  # b 2c t h w (mean | raw logvar)
+            self.z = torch.from_numpy(g["z"])              # b c t h w posterior sample
+            self.noise_seed = int(g["noise_seed"])
+        else:
+            self.ids = torch.from_numpy(g["ids"].astype(np.int64))
+            self.z = torch.from_numpy(g["z"])          # b t h w c
+            self.emb = torch.from_numpy(g["emb"])      # b t h w c
         self.recon = torch.from_numpy(g["recon"])  # strided
         self.recon_absmax = float(g["recon_absmax"])
+
+    def decode_input(self, z5=None):
+        """z in the layout reference decode() accepts: image [b,c,h,w], video [b,t,h,w,c]."""
+        z5 = self.z if z5 is None else z5
+        return z5[:, :, 0] if self.is_image else z5.permute(0, 2, 3, 4, 1).contiguous()
 
     def strided(self, recon_full):
         s = self.stride

@@ -83,7 +83,20 @@ def test_state_dict_contract(lib):
 def test_config_rejects_unbuilt_variants():
     from omnitokenizer_amd import make_args
     from omnitokenizer_amd.config import OmniTokConfig
-    for bad in (dict(patch_embed="cnn"), dict(enc_block="ttaw"), dict(use_vae=True),
-                dict(use_external_codebook=True), dict(dim_head=32)):
+    for bad in (dict(patch_embed="cnn"), dict(enc_block="ttaw"), dict(use_external_codebook=True),
+                dict(dim_head=32)):
         with pytest.raises((NotImplementedError, ValueError)):
             OmniTokConfig.from_args(make_args(2, **bad))
+    assert OmniTokConfig.from_args(make_args(2, use_vae=True)).use_vae
+
+
+def test_vae_state_dict_contract(lib):
+    """--use_vae: pre_vq_conv emits mean|logvar (reference omnitokenizer.py:149-153)."""
+    import torch
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args
+    m = OmniTokenizer_VQGAN(make_args(2, resolution=64, use_vae=True))
+    assert m.use_vae
+    assert tuple(m.state_dict()["pre_vq_conv.1.weight"].shape) == (16, 512)
+    assert tuple(m.state_dict()["pre_vq_conv.1.bias"].shape) == (16,)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encode(torch.zeros(1, 3, 64, 64), True)

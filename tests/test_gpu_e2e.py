@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import omnitok_oracle as orc
-from tests.helpers import E2E_CASES, GoldenCase
+from tests.helpers import E2E_CASES, VAE_CASES, GoldenCase
 
 pytestmark = pytest.mark.gpu
 
@@ -225,3 +225,93 @@ def test_c5_long_sequence_stress(models):
     # flat video ids need args.resolution = 512 (reference omnitokenizer.py:283-286)
     assert torch.equal(m.decode(ids_ref.reshape(1, -1).cuda(), False), rec)
     print(f"c5: id flips {flips}/{ids.numel()}, z err {zerr:.1e}, pixel err {err:.1e}")
+
+
+# ---- --use_vae (reference omnitokenizer.py:260-266, 293-317; what DiT/Latte call) --------------
+VAE_Z_TOL = 5e-5  # |z| reaches ~8 (mean + std*noise with std up to e^1.8); relative 1e-5
+
+
+@pytest.mark.parametrize("name", VAE_CASES)
+def test_vae_encode_decode_vs_reference_golden(models, name):
+    c = GoldenCase(name)
+    m = models(c)
+    assert m.use_vae
+    x = c.x.cuda()
+    # (a) with the reference's stored noise
+    z, mom = m.encode(x, c.is_image, noise=c.noise, return_moments=True)
+    z5 = z.unsqueeze(2) if c.is_image else z
+    assert tuple(z5.shape) == tuple(c.z.shape)
+    merr = (mom.cpu() - c.moments).abs().max().item()
+    zerr = (z5.cpu() - c.z).abs().max().item()
+    assert merr < 2e-5, f"posterior moments differ from the reference by {merr:.2e}"
+    assert zerr < VAE_Z_TOL, f"posterior sample differs from the reference by {zerr:.2e}"
+    # (b) seeded like a reference user would: torch.manual_seed + host draw (modules/vae.py:16)
+    torch.manual_seed(c.noise_seed)
+    z_seeded = m.encode(x, c.is_image)
+    assert torch.equal(z_seeded, z)
+    # (c) posterior mode == mean
+    mode = m.encode(x, c.is_image, sample_posterior=False)
+    mode5 = mode.unsqueeze(2) if c.is_image else mode
+    assert (mode5.cpu() - c.moments[:, :8]).abs().max().item() < 2e-5
+    # (d) decode of the reference's z in the layouts the reference accepts
+    recon = m.decode(c.decode_input().cuda(), c.is_image)
+    err = (c.strided(recon.cpu()) - c.recon).abs().max().item()
+    assert err < PIXEL_TOL, f"decode differs from the reference by {err:.2e}"
+    flat = c.z.permute(0, 2, 3, 4, 1).reshape(c.z.shape[0], -1, 8).cuda()
+    if c.is_image or c.cfg.resolution // c.cfg.patch_size == c.z.shape[-1]:
+        assert torch.equal(m.decode(flat, c.is_image), recon)
+    print(f"{name}: moments err {merr:.1e}, z err {zerr:.1e}, pixel err {err:.1e}")
+
+
+def test_vae_forward_and_mode_errors(models):
+    c = GoldenCase("vae_s2_sdpa_r64_vid")
+    m = models(c)
+    x = c.x.cuda()
+    torch.manual_seed(7)
+    frames, frames_recon, xx, x_recon, vq = m(x, log_image=True)
+    assert vq is None and x_recon.shape == x.shape and frames.shape == frames_recon.shape
+    torch.manual_seed(7)
+    z = m.encode(x, False)
+    assert torch.equal(m.decode(z.permute(0, 2, 3, 4, 1), False), x_recon)
+    # encode()'s channel-first video output is NOT what decode() takes (reference quirk, :313-314)
+    with pytest.raises((ValueError, RuntimeError)):
+        m.decode(z, False)
+    with pytest.raises(ValueError):
+        m.encode(x, False, noise=torch.zeros(1, 8, 1, 8, 8))
+    # the native VQ entry points refuse a use_vae engine and vice versa
+    import ctypes
+    from omnitokenizer_amd import _lib
+    lib = _lib.load()
+    ids = torch.zeros(2, 2, 8, 8, dtype=torch.int64, device="cuda")
+    out = torch.empty(2, 3, 5, 64, 64, device="cuda")
+    rc = lib.omnitok_decode(m._engine, ctypes.c_void_p(ids.data_ptr()), 2, 2, 8, 8, ctypes.c_void_p(out.data_ptr()), None)
+    assert rc != 0 and b"use_vae" in lib.omnitok_last_error()
+    cq = GoldenCase("s2_sdpa_r64_vid")
+    mq = models(cq)
+    mq.encode(cq.x.cuda(), False)
+    rc = lib.omnitok_decode_vae(mq._engine, ctypes.c_void_p(out.data_ptr()), 0, 2, 2, 8, 8,
+                                ctypes.c_void_p(out.data_ptr()), None)
+    assert rc != 0 and b"use_vae" in lib.omnitok_last_error()
+
+
+def test_vae_full_size_round_trip(models):
+    """C3-sized clip batch slice through the VAE path: determinism, batch invariance and
+    reconstruction == decode(encode) with the oracle on one clip."""
+    from omnitokenizer_amd import synth
+    c = GoldenCase("vae_s2_sdpa_r256_vid")
+    m = models(c)
+    x = synth.synth_video(4, 17, 256, seed=99).cuda()
+    noise = torch.randn(4, 8, 5, 32, 32, generator=torch.Generator().manual_seed(5))
+    z = m.encode(x, False, noise=noise)
+    assert torch.isfinite(z).all()
+    z_again = m.encode(x, False, noise=noise)
+    assert torch.equal(z, z_again)
+    z1 = m.encode(x[1:2], False, noise=noise[1:2])
+    assert (z1 - z[1:2]).abs().max().item() < 1e-4  # batch slices see different tile schedules only
+    rec = m.decode(z.permute(0, 2, 3, 4, 1), False)
+    assert tuple(rec.shape) == (4, 3, 17, 256, 256) and torch.isfinite(rec).all()
+    with torch.no_grad():
+        z_ref = orc.encode_vae(c.sd, x[:1].cpu(), False, c.cfg, noise=noise[:1])
+        rec_ref = orc.decode_vae(c.sd, z[:1].permute(0, 2, 3, 4, 1).cpu(), False, c.cfg)
+    assert (z[:1].cpu() - z_ref).abs().max().item() < VAE_Z_TOL
+    assert (rec[:1].cpu() - rec_ref).abs().max().item() < PIXEL_TOL

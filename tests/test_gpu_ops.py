@@ -364,6 +364,41 @@ def test_pre_vq_and_dequant(ops):
         ops.dequant_post_vq(dev(bad), dev(E), dev(pw), dev(pb))
 
 
+def test_vae_sample_and_post_vq(ops):
+    """--use_vae kernels against the oracle's DiagonalGaussianDistribution restatement."""
+    c = GoldenCase("vae_s2_sdpa_r64_vid")
+    B, thw = 3, 200
+    x = rnd(B, thw, 512, seed=93)
+    x[0, :4] *= 40.0  # drive some logvars into the [-30, 20] clamp
+    w, b = c.sd["pre_vq_conv.1.weight"].clone(), c.sd["pre_vq_conv.1.bias"]
+    w[8:] *= 6.0
+    noise = rnd(B, 8, thw, seed=94)
+    h = F.linear(x, w, b).permute(0, 2, 1)  # b 2c thw
+    mean, logvar = torch.chunk(h, 2, dim=1)
+    clamped = torch.clamp(logvar, -30.0, 20.0)
+    assert (clamped != logvar).any(), "test input does not reach the clamp"
+    ref = mean + torch.exp(0.5 * clamped) * noise
+    z, mom = ops.vae_sample(dev(x), dev(w), dev(b), dev(noise), return_moments=True)
+    assert maxerr(mom, h) < 2e-4 * max(1.0, h.abs().max().item() / 10)
+    # the sample arithmetic alone, on the kernel's own moments (the inflated logvars amplify the
+    # fp32 summation-order noise of h by 0.5*std, so the end-to-end bound is looser)
+    dmean, dlogvar = torch.chunk(mom.cpu(), 2, dim=1)
+    ref_dev = dmean + torch.exp(0.5 * torch.clamp(dlogvar, -30.0, 20.0)) * noise
+    rel = ((z.cpu() - ref_dev).abs() / ref_dev.abs().clamp_min(1.0)).max().item()
+    assert rel < 2e-6, rel
+    rel = ((z.cpu() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert rel < 2e-4, rel
+    mode = ops.vae_sample(dev(x), dev(w), dev(b), None)
+    assert maxerr(mode, mean) < 2e-4
+    # post_vq on continuous latents, both layouts
+    pw, pb = c.sd["post_vq_conv.1.weight"], c.sd["post_vq_conv.1.bias"]
+    zl = rnd(B, thw, 8, seed=95)
+    want = F.linear(zl, pw, pb)
+    assert maxerr(ops.post_vq(dev(zl), dev(pw), dev(pb), channel_first=False), want) < 1e-5
+    assert maxerr(ops.post_vq(dev(zl.permute(0, 2, 1).contiguous()), dev(pw), dev(pb), channel_first=True),
+                  want) < 1e-5
+
+
 @pytest.mark.parametrize("n_codes", [8192, 16384])
 def test_vq_argmin_bit_exact_vs_reference_kat(ops, n_codes):
     """ids bit-exact against the reference's own Codebook.forward outputs (golden KAT), including

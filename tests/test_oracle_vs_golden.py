@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, GOLDEN
+from tests.helpers import GoldenCase, E2E_CASES, GOLDEN, VAE_CASES
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -70,3 +70,23 @@ def test_bias_table_equals_pairwise_bias():
     dy = ys[:, None] - ys[None, :] + h - 1
     dx = xs[:, None] - xs[None, :] + w - 1
     assert torch.equal(full, tab[:, dy, dx])
+
+
+@pytest.mark.parametrize("name", [c for c in VAE_CASES if "r256" not in c])
+def test_oracle_vae_matches_reference(name):
+    """--use_vae path (reference omnitokenizer.py:260-266, 293-317) with the reference's own noise."""
+    c = GoldenCase(name)
+    with torch.no_grad():
+        z = orc.encode_vae(c.sd, c.x, c.is_image, c.cfg, noise=c.noise)
+        # the reference's host draw is reproducible from the seed alone
+        torch.manual_seed(c.noise_seed)
+        z_seeded = orc.encode_vae(c.sd, c.x, c.is_image, c.cfg)
+        recon = orc.decode_vae(c.sd, c.decode_input(), c.is_image, c.cfg)
+        flat = c.z.permute(0, 2, 3, 4, 1).reshape(c.z.shape[0], -1, c.z.shape[1])
+        recon_flat = orc.decode_vae(c.sd, flat, c.is_image, c.cfg)
+    z5 = z.unsqueeze(2) if c.is_image else z
+    assert tuple(z5.shape) == tuple(c.z.shape)
+    assert (z5 - c.z).abs().max().item() < 1e-5
+    assert torch.equal(z, z_seeded)
+    assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
+    assert torch.equal(recon, recon_flat)
