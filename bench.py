@@ -55,7 +55,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
@@ -171,8 +171,10 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"C3: B={B}/GPU {a.frames}x{a.resolution}x{a.resolution} clips, stage-2 "
-                                   f"(imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes=8192), encode + "
+            "config": {"workload": (f"C2: B={B}/GPU {a.resolution}x{a.resolution} images, stage-2 " if is_image else
+                                    f"C3: B={B}/GPU {a.frames}x{a.resolution}x{a.resolution} clips, stage-2 ")
+                                   +
+                                   "(imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes=8192), encode + "
                                    f"{'RCCL id all-gather + ' if world > 1 else ''}decode",
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
                        "parallelism": f"clip-sharded x{world}"},

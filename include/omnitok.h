@@ -108,10 +108,21 @@ int omnitok_pack_geglu_weight(const float *w1, int inner, int K, int inner_pad, 
 
 /* Patch gather + first LayerNorm of the patch embedding (reference omnitokenizer.py:806-809 /
  * 814-818): video[B,C,F,H,W] frames [f0, f0 + t*pt) -> out[B*t*(H/p)*(W/p), C*pt*p*p] with
- * feature order (c, pt, p1, p2), each row layer-normalised with gamma/beta. */
+ * feature order (c, pt, p1, p2), each row layer-normalised with gamma/beta.  gamma == beta ==
+ * NULL: no normalisation, i.e. the im2col rows of the 'cnn' patch-embed's Conv3d with kernel ==
+ * stride (omnitokenizer.py:823-836).  ldo: output row stride in floats (0 = dense); columns
+ * [C*pt*p*p, ldo) are zero-filled so that the GEMM's K % 32 rule can be met by padding. */
 int omnitok_patchify_ln(const float *video, int B, int C, int F, int H, int W, int f0, int t,
                         int pt, int p, const float *gamma, const float *beta, float eps,
-                        float *out, omnitok_stream_t stream);
+                        float *out, int64_t ldo, omnitok_stream_t stream);
+
+/* Token-grid resampling of the pooling blocks / deferred pools (csrc/resample.hip). mode:
+ *  0 avg2d, 1 max2d: x[n,gh,gw,D] -> out[n,gh/2,gw/2,D]   (Pooling 'a'/'m', attention.py:83-106)
+ *  2 up2d:           x[n,gh,gw,D] -> out[n,2gh,2gw,D]     (nearest, omnitokenizer.py:1001)
+ *  3 avg_t:          x[n,T,gh*gw,D] -> out[n,1+(T-1)/2,gh*gw,D], frame 0 kept (omnitokenizer.py:909-914)
+ *  4 up_t:           x[n,T,gh*gw,D] -> out[n,1+(T-1)*2,gh*gw,D], frame 0 kept (omnitokenizer.py:1103-1107) */
+int omnitok_token_resample(const float *x, float *out, int mode, int64_t n, int T, int gh, int gw,
+                           int D, omnitok_stream_t stream);
 
 /* Inverse rearrange of to_pixels (reference omnitokenizer.py:1008-1009, 1015-1016):
  * tok[B*t*(H/p)*(W/p), C*pt*p*p] -> video[B,C,F,H,W] frames [f0, f0 + t*pt). */
@@ -246,6 +257,14 @@ typedef struct omnitok_config {
     char enc_block[16];        /* "ttww" */
     char dec_block[16];        /* "tttt" */
     int use_vae;               /* --use_vae: pre_vq emits mean|logvar, no quantiser (omnitokenizer.py:143-154) */
+    /* config coverage beyond the released checkpoints (all 0 for them) */
+    int patch_embed_cnn;       /* --patch_embed cnn: Conv3d / ConvTranspose3d (kernel == stride) + eval-mode
+                                * SyncBatchNorm instead of LN-Linear-LN / Linear (omnitokenizer.py:823-836,
+                                * 1019-1033); enc_block may also hold 'a' 'm' 'l' pooling blocks
+                                * (attention.py:83-113) */
+    int defer_temporal_pool;   /* --defer_temporal_pool (omnitokenizer.py:792-797, 985-990), linear only */
+    int defer_spatial_pool;    /* --defer_spatial_pool  (omnitokenizer.py:799-804, 992-1003), linear only */
+    int gen_upscale;           /* --gen_upscale: decoder patch_size *= gen_upscale (0 / 1 = off) */
 } omnitok_config;
 
 int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine **out);
@@ -273,6 +292,12 @@ int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, int H, int W
 /* VQGAN.decode: ids[B,T',h,w] -> pixels[B,C,F,h*p,w*p], F = 1 + (T'-1)*pt. */
 int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int h, int w,
                    float *pixels_out, omnitok_stream_t stream);
+
+/* Shapes of the path for this configuration (pooling blocks, deferred pools and gen_upscale change
+ * them): encode_shape: pixels F,H,W -> latent T,h,w; decode_shape: latent T,h,w -> pixels F,H,W.
+ * Return OMNITOK_ERR_INVALID (with omnitok_last_error) for sizes the path rejects. */
+int omnitok_engine_encode_shape(omnitok_engine *e, int F, int H, int W, int *T, int *h, int *w);
+int omnitok_engine_decode_shape(omnitok_engine *e, int T, int h, int w, int *F, int *H, int *W);
 
 /* --use_vae variants (reference omnitokenizer.py:260-266 encode, :293-317 decode; the KL-regularised
  * tokenizer DiT/Latte train on, Diffusion/Latte/train.py:216, sample_ddp.py:201-203).  The engine

@@ -21,6 +21,8 @@ class OmnitokConfig(Structure):
         ("l2_code", c_int), ("spatial_rope", c_int), ("legacy_attention", c_int),
         ("causal_temporal", c_int), ("causal_peg", c_int), ("temporal_depth", c_int),
         ("enc_block", c_char * 16), ("dec_block", c_char * 16), ("use_vae", c_int),
+        ("patch_embed_cnn", c_int), ("defer_temporal_pool", c_int), ("defer_spatial_pool", c_int),
+        ("gen_upscale", c_int),
     ]
 
 
@@ -38,7 +40,7 @@ _PROTOS = {
     "omnitok_split3": [P, I64, I64, c_int, I64, I64, I64, P, P],
     "omnitok_gemm_bf16x3": [P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, P],
     "omnitok_pack_geglu_weight": [P, c_int, c_int, c_int, P, P],
-    "omnitok_patchify_ln": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, P],
+    "omnitok_patchify_ln": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P, c_float, P, I64, P],
     "omnitok_unpatchify": [P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P, P],
     "omnitok_peg3d": [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P],
     "omnitok_pack_peg_weight": [P, c_int, P, P],
@@ -52,6 +54,7 @@ _PROTOS = {
     "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
+    "omnitok_token_resample": [P, P, c_int, I64, c_int, c_int, c_int, c_int, P],
     "omnitok_vae_sample": [P, P, P, P, P, P, I64, I64, c_int, c_int, P],
     "omnitok_post_vq": [P, c_int, I64, I64, c_int, P, P, P, c_int, P],
     "omnitok_vq_embed_st": [P, P, P, c_int, I64, I64, P, P],
@@ -65,6 +68,8 @@ _PROTOS = {
     "omnitok_decode": [P, P, c_int, c_int, c_int, c_int, P, P],
     "omnitok_encode_vae": [P, P, c_int, c_int, c_int, c_int, P, P, P, P],
     "omnitok_decode_vae": [P, P, c_int, c_int, c_int, c_int, c_int, P, P],
+    "omnitok_engine_encode_shape": [P, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
+    "omnitok_engine_decode_shape": [P, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "omnitok_engine_check_ids": [P, P],
     "omnitok_engine_workspace_bytes": [P],
     "omnitok_engine_set_timing": [P, c_int],

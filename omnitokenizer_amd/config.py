@@ -44,11 +44,47 @@ class OmniTokConfig:
     use_vae: bool
     use_external_codebook: bool
     attention_mode: str  # "sdpa" | "legacy"  (reference attention.py:439 picks by torch version)
+    defer_temporal_pool: bool = False  # omnitokenizer.py:792-797 / 985-990 ('linear' patch-embed only)
+    defer_spatial_pool: bool = False   # omnitokenizer.py:799-804 / 992-1003
+    gen_upscale: int = 1               # decoder patch_size *= gen_upscale, omnitokenizer.py:957-959
+    norm_type: str = "batch"           # Normalize() of the 'cnn' patch-embed, base.py:272-277
 
     @property
     def ff_inner(self) -> int:
         # reference attention.py:161  inner_dim = int(mult * (2 / 3) * dim)
         return int(self.ff_mult * (2 / 3) * self.dim)
+
+    # patch sizes actually used (the deferred pools only exist for patch_embed == 'linear')
+    @property
+    def _defer_t(self) -> bool:
+        return self.defer_temporal_pool and self.patch_embed == "linear"
+
+    @property
+    def _defer_s(self) -> bool:
+        return self.defer_spatial_pool and self.patch_embed == "linear"
+
+    @property
+    def enc_patch_size(self) -> int:
+        return self.patch_size // 2 if self._defer_s else self.patch_size
+
+    @property
+    def enc_temporal_patch_size(self) -> int:
+        return self.temporal_patch_size // 2 if self._defer_t else self.temporal_patch_size
+
+    @property
+    def dec_patch_size(self) -> int:
+        p = self.patch_size * self.gen_upscale
+        return p // 2 if self._defer_s else p
+
+    @property
+    def dec_temporal_patch_size(self) -> int:
+        return self.enc_temporal_patch_size
+
+    @property
+    def enc_grid_divisor(self) -> int:
+        """latent grid = (resolution / enc_patch_size) / enc_grid_divisor."""
+        n_pool = sum(self.enc_block.count(c) for c in "aml")
+        return (2 ** n_pool) * (2 if self._defer_s else 1)
 
     @staticmethod
     def from_args(args, attention_mode: str = "sdpa") -> "OmniTokConfig":
@@ -80,6 +116,10 @@ class OmniTokConfig:
             use_vae=bool(_get(args, "use_vae", False)),
             use_external_codebook=bool(_get(args, "use_external_codebook", False)),
             attention_mode=attention_mode,
+            defer_temporal_pool=bool(_get(args, "defer_temporal_pool", False)),  # omnitokenizer.py:79-81
+            defer_spatial_pool=bool(_get(args, "defer_spatial_pool", False)),
+            gen_upscale=int(_get(args, "gen_upscale", None) or 1),                # omnitokenizer.py:91-92
+            norm_type=str(_get(args, "norm_type", "batch")),
         )
         cfg.validate()
         return cfg
@@ -89,16 +129,27 @@ class OmniTokConfig:
         computing something else (SURVEY.md section 8 a18/a19/a16/a4')."""
         if self.attention_mode not in ("sdpa", "legacy"):
             raise ValueError(f"attention_mode must be 'sdpa' or 'legacy', got {self.attention_mode!r}")
-        if self.patch_embed != "linear":
+        if self.patch_embed not in ("linear", "cnn"):
+            raise NotImplementedError(f"patch_embed={self.patch_embed!r} (reference omnitokenizer.py:839-840)")
+        if self.patch_embed == "cnn" and self.norm_type != "batch":
+            # GroupNorm(32 groups) over the decoder's 3 output channels cannot be constructed
+            raise ValueError("patch_embed='cnn' needs norm_type='batch': the reference's "
+                             "Normalize(image_channel, 'group') raises 'num_channels (3) must be divisible by "
+                             "num_groups (32)' (base.py:274, omnitokenizer.py:1023)")
+        bad = sorted(set(self.enc_block) - set("twaml"))
+        if bad:
+            raise NotImplementedError(f"enc_block={self.enc_block!r}: unknown block types {bad} "
+                                      "(reference attention.py:614-649)")
+        bad = sorted(set(self.dec_block) - set("tw"))
+        if bad:
             raise NotImplementedError(
-                f"patch_embed={self.patch_embed!r}: only the 'linear' patch-embed of the released "
-                "checkpoints is built (reference omnitokenizer.py:806-822)")
-        for blk, name in ((self.enc_block, "enc_block"), (self.dec_block, "dec_block")):
-            bad = sorted(set(blk) - set("tw"))
-            if bad:
-                raise NotImplementedError(
-                    f"{name}={blk!r}: pooling/upsampling blocks {bad} (reference attention.py:631-647) "
-                    "are not used by any released config and are not built")
+                f"dec_block={self.dec_block!r}: block types {bad} are not built. 'n'/'r' (Up) blocks make the "
+                "reference decoder itself raise (einops shape mismatch at omnitokenizer.py:1078: it regroups "
+                "(b h w) rows with h // down_ratio), pooling blocks are encoder-side")
+        if self.gen_upscale < 1:
+            raise ValueError("gen_upscale must be >= 1")
+        if (self._defer_s and self.patch_size % 2) or (self._defer_t and self.temporal_patch_size % 2):
+            raise ValueError("deferred pooling needs an even patch size")
         if len(self.enc_block) != self.spatial_depth:
             raise ValueError("len(enc_block) must equal spatial_depth (reference attention.py:608)")
         if self.use_external_codebook:
@@ -110,7 +161,7 @@ class OmniTokConfig:
             raise NotImplementedError("embedding_dim must be a multiple of 128")
         if self.spatial_pos not in ("rel", "rope"):
             raise ValueError(f"spatial_pos={self.spatial_pos!r}")
-        if self.resolution % self.patch_size:
+        if self.resolution % self.enc_patch_size:
             raise ValueError("resolution must be divisible by patch_size (reference omnitokenizer.py:789-790)")
 
 

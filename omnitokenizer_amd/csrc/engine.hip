@@ -53,10 +53,17 @@ struct LayerFF {
     const float *lw, *lb, *w1p, *w2p;
 };
 struct Layer {
-    char kind;
+    char kind;  // 't', 'w', or a pooling block 'a' / 'm' / 'l'
     LayerT t;
     LayerW w;
     LayerFF ff;
+    const float *pool_w = nullptr, *pool_b = nullptr;  // 'l': Linear(4*dim, dim)
+};
+
+// patch / grid geometry of a configuration (reference omnitokenizer.py:792-804, 957-959, 985-1003)
+struct Geo {
+    bool defer_t, defer_s;
+    int p_enc, pt_enc, p_dec, pt_dec, n_pool;
 };
 struct TransformerW {
     std::vector<Layer> layers;
@@ -81,6 +88,11 @@ struct omnitok_engine {
     bool finalized = false;
     int inner_pad = 0;
     TransformerW enc_s, enc_t, dec_s, dec_t;
+    // patch-embed / to_pixels GEMM operands, [0] first frame, [1] the rest (original tensors, or
+    // K-padded / BatchNorm-folded / transposed copies made by finalize)
+    const float *pe_w[2] = {nullptr, nullptr}, *pe_b[2] = {nullptr, nullptr};
+    int pe_k[2] = {0, 0}, pe_ld[2] = {0, 0};
+    const float *px_w[2] = {nullptr, nullptr}, *px_b[2] = {nullptr, nullptr};
     // derived
     float *cb_packed = nullptr, *cb_ee = nullptr, *alibi = nullptr;
     std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
@@ -95,6 +107,21 @@ struct omnitok_engine {
 };
 
 namespace omnitok {
+
+static Geo geometry(const omnitok_config &c) {
+    Geo g;
+    const bool lin = !c.patch_embed_cnn;  // the deferred pools exist for the 'linear' patch-embed only
+    g.defer_t = lin && c.defer_temporal_pool;
+    g.defer_s = lin && c.defer_spatial_pool;
+    const int up = c.gen_upscale > 1 ? c.gen_upscale : 1;
+    g.p_enc = g.defer_s ? c.patch_size / 2 : c.patch_size;
+    g.pt_enc = g.defer_t ? c.temporal_patch_size / 2 : c.temporal_patch_size;
+    g.p_dec = g.defer_s ? c.patch_size * up / 2 : c.patch_size * up;
+    g.pt_dec = g.pt_enc;
+    g.n_pool = 0;
+    for (const char *q = c.enc_block; *q; ++q) g.n_pool += (*q == 'a' || *q == 'm' || *q == 'l');
+    return g;
+}
 
 static void add_transformer_spec(omnitok_engine *e, const std::string &prefix, const std::string &block,
                                  bool rel) {
@@ -120,6 +147,11 @@ static void add_transformer_spec(omnitok_engine *e, const std::string &prefix, c
             e->spec[p + ".1.to_q.weight"] = {hd * heads, d};
             e->spec[p + ".1.to_kv.weight"] = {2 * hd * heads, d};
             e->spec[p + ".1.to_out.weight"] = {d, hd * heads};
+        } else if (block[i] == 'l') {
+            e->spec[p + ".1.pool.weight"] = {d, 4 * d};
+            e->spec[p + ".1.pool.bias"] = {d};
+        } else if (block[i] == 'a' || block[i] == 'm') {
+            // parameter-free pooling
         } else {
             e->spec[p + ".1.relative_position_bias_table"] = {(2 * ws - 1) * (2 * ws - 1), heads};
             e->spec[p + ".1.relative_position_index"] = {ws * ws, ws * ws};
@@ -250,6 +282,10 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
             L.t.q_scale = W(e, p + ".1.q_scale");
             L.t.k_scale = W(e, p + ".1.k_scale");
             L.t.bias_prefix = (spatial && c.legacy_attention && !c.spatial_rope) ? p + ".1.spatial_rel_pos_bias" : "";
+        } else if (block[i] == 'l') {
+            L.pool_w = W(e, p + ".1.pool.weight");
+            L.pool_b = W(e, p + ".1.pool.bias");
+        } else if (block[i] == 'a' || block[i] == 'm') {
         } else {
             const int ntok = c.window_size * c.window_size;
             float *dense;
@@ -286,6 +322,92 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
     }
     tw.og = W(e, prefix + ".norm_out.gamma");
     tw.ob = W(e, prefix + ".norm_out.beta");
+    return OMNITOK_OK;
+}
+
+// eval-mode (Sync)BatchNorm folded into the preceding convolution (ATen's CPU batch_norm applies
+// y = x * alpha + beta with alpha = w / sqrt(var + eps), beta = b - mean * alpha):
+//   encoder  Conv3d weight [D, K] (K = c pt p1 p2, the patchify feature order): row d scaled by alpha[d]
+__global__ void fold_bn_rows_kernel(const float *__restrict__ w, const float *__restrict__ cb,
+                                    const float *__restrict__ bw, const float *__restrict__ bb,
+                                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int rows,
+                                    int K, int ld, float *__restrict__ wo, float *__restrict__ bo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)rows * ld) return;
+    const int r = (int)(idx / ld), k = (int)(idx % ld);
+    const float alpha = bw[r] / sqrtf(var[r] + eps);
+    wo[idx] = k < K ? w[(int64_t)r * K + k] * alpha : 0.0f;
+    if (k == 0) bo[r] = cb[r] * alpha + (bb[r] - mean[r] * alpha);
+}
+//   decoder  ConvTranspose3d weight [D, N] (N = c pt p1 p2) -> Linear layout [N, D], column n scaled by
+//   the alpha of its output channel c = n / per_c
+__global__ void fold_bn_transpose_kernel(const float *__restrict__ w, const float *__restrict__ cb,
+                                         const float *__restrict__ bw, const float *__restrict__ bb,
+                                         const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                                         int D, int N, int per_c, float *__restrict__ wo, float *__restrict__ bo) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * D) return;
+    const int n = (int)(idx / D), k = (int)(idx % D);
+    const int ch = n / per_c;
+    const float alpha = bw[ch] / sqrtf(var[ch] + eps);
+    wo[idx] = w[(int64_t)k * N + n] * alpha;
+    if (k == 0) bo[n] = cb[ch] * alpha + (bb[ch] - mean[ch] * alpha);
+}
+
+static int build_patch_operands(omnitok_engine *e, hipStream_t stream) {
+    const omnitok_config &c = e->cfg;
+    const Geo g = geometry(c);
+    const int D = c.dim, C = c.image_channels;
+    const char *names[2] = {"encoder.to_patch_emb_first_frame", "encoder.to_patch_emb"};
+    const char *pnames[2] = {"decoder.to_pixels_first_frame", "decoder.to_pixels"};
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = names[i];
+        const int K = C * g.p_enc * g.p_enc * (i ? g.pt_enc : 1);
+        const int ld = ((K + 31) / 32) * 32;  // the GEMM's K % 32 rule; patchify zero-fills the pad
+        e->pe_k[i] = K;
+        e->pe_ld[i] = ld;
+        if (c.patch_embed_cnn) {
+            float *wo, *bo;
+            if (int rc = alloc_f(e, &wo, (int64_t)D * ld)) return rc;
+            if (int rc = alloc_f(e, &bo, D)) return rc;
+            const int64_t total = (int64_t)D * ld;
+            hipLaunchKernelGGL(fold_bn_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               W(e, p + ".0.weight"), W(e, p + ".0.bias"), W(e, p + ".1.weight"), W(e, p + ".1.bias"),
+                               W(e, p + ".1.running_mean"), W(e, p + ".1.running_var"), 1e-5f, D, K, ld, wo, bo);
+            OT_LAUNCH_CHECK("fold_bn_rows");
+            e->pe_w[i] = wo;
+            e->pe_b[i] = bo;
+        } else if (ld != K) {
+            float *wo;
+            if (int rc = alloc_f(e, &wo, (int64_t)D * ld)) return rc;
+            const int64_t total = (int64_t)D * ld;
+            hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               W(e, p + ".2.weight"), D, K, ld, wo);
+            OT_LAUNCH_CHECK("pad_cols");
+            e->pe_w[i] = wo;
+            e->pe_b[i] = W(e, p + ".2.bias");
+        } else {
+            e->pe_w[i] = W(e, p + ".2.weight");
+            e->pe_b[i] = W(e, p + ".2.bias");
+        }
+        const std::string q = pnames[i];
+        if (c.patch_embed_cnn) {
+            const int per_c = g.p_dec * g.p_dec * (i ? g.pt_dec : 1), N = C * per_c;
+            float *wo, *bo;
+            if (int rc = alloc_f(e, &wo, (int64_t)N * D)) return rc;
+            if (int rc = alloc_f(e, &bo, N)) return rc;
+            const int64_t total = (int64_t)N * D;
+            hipLaunchKernelGGL(fold_bn_transpose_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                               W(e, q + ".1.weight"), W(e, q + ".1.bias"), W(e, q + ".2.weight"), W(e, q + ".2.bias"),
+                               W(e, q + ".2.running_mean"), W(e, q + ".2.running_var"), 1e-5f, D, N, per_c, wo, bo);
+            OT_LAUNCH_CHECK("fold_bn_transpose");
+            e->px_w[i] = wo;
+            e->px_b[i] = bo;
+        } else {
+            e->px_w[i] = W(e, q + ".0.weight");
+            e->px_b[i] = W(e, q + ".0.bias");
+        }
+    }
     return OMNITOK_OK;
 }
 
@@ -361,14 +483,39 @@ static int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, 
 }
 
 // One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
-static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int gh, int gw, bool spatial,
+// Pooling blocks shrink the token grid (attention.py:683-684): *ghp / *gwp are updated.
+static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
                            hipStream_t stream) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim, heads = c.heads;
-    const int64_t L = (int64_t)B * T * gh * gw;
-    const int S = gh * gw;
-    const double gemm_f = 2.0 * (double)L * D;
+    int gh = *ghp, gw = *gwp;
+    int64_t L = (int64_t)B * T * gh * gw;
+    int S = gh * gw;
+    double gemm_f = 2.0 * (double)L * D;
     for (const Layer &ly : tw.layers) {
+        if (ly.kind == 'a' || ly.kind == 'm' || ly.kind == 'l') {
+            // Pooling (reference attention.py:83-113), no residual (:674); then FF (+residual) on the
+            // quarter-size sequence
+            if (!spatial || gh % 2 || gw % 2) {
+                set_error("pooling block '%c' on a %dx%d grid", ly.kind, gh, gw);
+                return OMNITOK_ERR_INVALID;
+            }
+            if (ly.kind == 'l')  // Linear(4D -> D) on four consecutive tokens: x.view(B, N/4, 4C)
+                OT_RUN("pool", 2.0 * (double)L * D * D,
+                       omnitok_gemm(e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
+                                    OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+            else
+                OT_RUN("pool", 1.25 * L * D * 4.0,
+                       omnitok_token_resample(e->X.p, e->X2.p, ly.kind == 'a' ? 0 : 1, (int64_t)B * T, 1, gh, gw, D,
+                                              stream));
+            std::swap(e->X, e->X2);
+            gh /= 2;
+            gw /= 2;
+            S = gh * gw;
+            L = (int64_t)B * T * S;
+            gemm_f = 2.0 * (double)L * D;
+            goto feed_forward;
+        }
         if (ly.kind == 't') {
             OT_RUN("peg3d", 2.0 * L * D * 4.0,
                    omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
@@ -443,13 +590,18 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
     OT_RUN("layernorm", 2.0 * L * D * 4.0,
            omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
     std::swap(e->X, e->X2);
+    *ghp = gh;
+    *gwp = gw;
     return OMNITOK_OK;
 }
 
 static int ensure_workspace(omnitok_engine *e, int64_t L) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim;
-    const int kmax = c.image_channels * c.patch_size * c.patch_size * c.temporal_patch_size;
+    const Geo g = geometry(c);
+    const int kenc = ((c.image_channels * g.p_enc * g.p_enc * g.pt_enc + 31) / 32) * 32;
+    const int kdec = c.image_channels * g.p_dec * g.p_dec * g.pt_dec;
+    const int kmax = kenc > kdec ? kenc : kdec;
     int64_t hdw = e->inner_pad;
     if (kmax > hdw) hdw = kmax;
     if (int rc = ensure(e->X, L * D)) return rc;
@@ -504,29 +656,48 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
         set_error("engine_create: window attention is built for twod_window_size == 8 (got %d)", c.window_size);
         return OMNITOK_ERR_UNSUPPORTED;
     }
-    if (c.patch_size % 4 != 0 || (c.image_channels * c.patch_size * c.patch_size) % 32 != 0) {
-        set_error("engine_create: patch_size %d unsupported", c.patch_size);
+    const Geo g = geometry(c);
+    if (g.p_enc % 4 != 0 || g.p_dec % 4 != 0 || g.pt_enc < 1 ||
+        (c.defer_spatial_pool && c.patch_size % 2) || (c.defer_temporal_pool && c.temporal_patch_size % 2)) {
+        set_error("engine_create: patch_size %d / temporal_patch_size %d unsupported (encoder patch %d, decoder patch "
+                  "%d must be multiples of 4)", c.patch_size, c.temporal_patch_size, g.p_enc, g.p_dec);
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    if ((int64_t)c.image_channels * g.p_enc * g.p_enc * g.pt_enc > 1024) {
+        set_error("engine_create: patch feature dim > 1024 unsupported");
         return OMNITOK_ERR_UNSUPPORTED;
     }
     const std::string eb(c.enc_block), db(c.dec_block);
-    for (char ch : eb + db)
+    for (char ch : eb)
+        if (!strchr("twaml", ch)) {
+            set_error("engine_create: enc_block type '%c' unknown (reference attention.py:614-649)", ch);
+            return OMNITOK_ERR_UNSUPPORTED;
+        }
+    for (char ch : db)
         if (ch != 't' && ch != 'w') {
-            set_error("engine_create: block type '%c' (pooling/upsampling, reference attention.py:631-647) not built", ch);
+            set_error("engine_create: dec_block type '%c' not built ('n'/'r' Up blocks make the reference decoder "
+                      "raise at omnitokenizer.py:1078; pooling blocks are encoder-side)", ch);
             return OMNITOK_ERR_UNSUPPORTED;
         }
     omnitok_engine *e = new omnitok_engine();
     e->cfg = c;
     e->inner_pad = ((c.ff_inner + 63) / 64) * 64;
     if (e->inner_pad % 32 != 0) e->inner_pad = ((e->inner_pad + 31) / 32) * 32;
-    const int64_t d = c.dim, k0 = (int64_t)c.image_channels * c.patch_size * c.patch_size,
-                  k1 = k0 * c.temporal_patch_size;
+    const int64_t d = c.dim, C = c.image_channels;
     const char *names[2] = {"to_patch_emb_first_frame", "to_patch_emb"};
-    const int64_t ks[2] = {k0, k1};
+    const int64_t pts[2] = {1, g.pt_enc};
     for (int i = 0; i < 2; ++i) {
         const std::string p = std::string("encoder.") + names[i];
-        e->spec[p + ".1.weight"] = {ks[i]};
-        e->spec[p + ".1.bias"] = {ks[i]};
-        e->spec[p + ".2.weight"] = {d, ks[i]};
+        const int64_t k = C * g.p_enc * g.p_enc * pts[i];
+        if (c.patch_embed_cnn) {  // Conv3d + SyncBatchNorm, reference omnitokenizer.py:823-836
+            e->spec[p + ".0.weight"] = {d, C, pts[i], g.p_enc, g.p_enc};
+            e->spec[p + ".0.bias"] = {d};
+            for (const char *q : {".1.weight", ".1.bias", ".1.running_mean", ".1.running_var"}) e->spec[p + q] = {d};
+            continue;
+        }
+        e->spec[p + ".1.weight"] = {k};
+        e->spec[p + ".1.bias"] = {k};
+        e->spec[p + ".2.weight"] = {d, k};
         e->spec[p + ".2.bias"] = {d};
         e->spec[p + ".3.weight"] = {d};
         e->spec[p + ".3.bias"] = {d};
@@ -536,10 +707,19 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
     add_transformer_spec(e, "encoder.enc_temporal_transformer", tb, false);
     add_transformer_spec(e, "decoder.dec_spatial_transformer", db, !c.spatial_rope);
     add_transformer_spec(e, "decoder.dec_temporal_transformer", tb, false);
-    e->spec["decoder.to_pixels_first_frame.0.weight"] = {k0, d};
-    e->spec["decoder.to_pixels_first_frame.0.bias"] = {k0};
-    e->spec["decoder.to_pixels.0.weight"] = {k1, d};
-    e->spec["decoder.to_pixels.0.bias"] = {k1};
+    const char *pnames[2] = {"to_pixels_first_frame", "to_pixels"};
+    const int64_t ptd[2] = {1, g.pt_dec};
+    for (int i = 0; i < 2; ++i) {
+        const std::string p = std::string("decoder.") + pnames[i];
+        if (c.patch_embed_cnn) {  // ConvTranspose3d + SyncBatchNorm(3), reference omnitokenizer.py:1019-1031
+            e->spec[p + ".1.weight"] = {d, C, ptd[i], g.p_dec, g.p_dec};
+            e->spec[p + ".1.bias"] = {C};
+            for (const char *q : {".2.weight", ".2.bias", ".2.running_mean", ".2.running_var"}) e->spec[p + q] = {C};
+        } else {
+            e->spec[p + ".0.weight"] = {C * g.p_dec * g.p_dec * ptd[i], d};
+            e->spec[p + ".0.bias"] = {C * g.p_dec * g.p_dec * ptd[i]};
+        }
+    }
     // --use_vae: no quantiser on the path, pre_vq emits mean | logvar (reference omnitokenizer.py:143-154)
     const int64_t pre_out = c.use_vae ? 2 * c.codebook_dim : c.codebook_dim;
     if (!c.use_vae) e->spec["codebook.embeddings"] = {c.n_codes, c.codebook_dim};
@@ -631,6 +811,7 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     if (int rc = build_transformer(e, e->enc_t, "encoder.enc_temporal_transformer", tb, false, stream)) return rc;
     if (int rc = build_transformer(e, e->dec_s, "decoder.dec_spatial_transformer", c.dec_block, true, stream)) return rc;
     if (int rc = build_transformer(e, e->dec_t, "decoder.dec_temporal_transformer", tb, false, stream)) return rc;
+    if (int rc = build_patch_operands(e, stream)) return rc;
     if (!c.use_vae) {
         if (int rc = alloc_f(e, &e->cb_packed, (int64_t)c.n_codes * 8)) return rc;
         if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
@@ -667,8 +848,59 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     return OMNITOK_OK;
 }
 
+// Shapes of the path (pooling blocks, deferred pools and gen_upscale change them).
+static int encode_shape(omnitok_engine *e, int F, int H, int W_, int *T, int *gh, int *gw) {
+    const omnitok_config &c = e->cfg;
+    const Geo g = geometry(c);
+    // reference omnitokenizer.py:931-932
+    OT_CHECK_ARG(F >= 1 && (F - 1) % g.pt_enc == 0,
+                 "number of frames (%d) minus one (%d) must be divisible by temporal patch size (%d)", F, F - 1,
+                 g.pt_enc);
+    OT_CHECK_ARG(H > 0 && W_ > 0 && H % g.p_enc == 0 && W_ % g.p_enc == 0,
+                 "image size %dx%d not divisible by patch size %d", H, W_, g.p_enc);
+    int t = 1 + (F - 1) / g.pt_enc, h = H / g.p_enc, w = W_ / g.p_enc;
+    const int div = (1 << g.n_pool) * (g.defer_s ? 2 : 1);
+    OT_CHECK_ARG(h % div == 0 && w % div == 0, "token grid %dx%d not divisible by the pooling factor %d", h, w, div);
+    h /= div;
+    w /= div;
+    if (g.defer_t) t = 1 + (t - 1) / 2;  // AvgPool3d((2,1,1)) floors, omnitokenizer.py:909-914
+    *T = t;
+    *gh = h;
+    *gw = w;
+    return OMNITOK_OK;
+}
+
+static int decode_shape(omnitok_engine *e, int T, int gh, int gw, int *F, int *H, int *W_) {
+    const Geo g = geometry(e->cfg);
+    OT_CHECK_ARG(T >= 1 && gh >= 1 && gw >= 1, "decode: bad latent shape %dx%dx%d", T, gh, gw);
+    const int t = g.defer_t ? 1 + (T - 1) * 2 : T, up = g.defer_s ? 2 : 1;
+    *F = 1 + (t - 1) * g.pt_dec;
+    *H = gh * up * g.p_dec;
+    *W_ = gw * up * g.p_dec;
+    return OMNITOK_OK;
+}
+
+static int check_attention_grid(const char *who, const std::string &block, int gh, int gw) {
+    // grids seen by the blocks of a spatial transformer ('t': N % 64, square; 'w': 8x8 windows)
+    for (char ch : block) {
+        if (ch == 't') {
+            OT_CHECK_ARG((gh * gw) % 64 == 0, "%s: %d tokens per frame; spatial attention needs a multiple of 64", who,
+                         gh * gw);
+            OT_CHECK_ARG(gh == gw, "%s: the reference assumes a square token grid (int(sqrt(N)), attention.py:261)", who);
+        } else if (ch == 'w') {
+            OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0 && gh == gw, "%s: token grid %dx%d not divisible by the 8x8 window",
+                         who, gh, gw);
+        } else {
+            OT_CHECK_ARG(gh % 2 == 0 && gw % 2 == 0 && gh == gw, "%s: pooling block on a %dx%d grid", who, gh, gw);
+            gh /= 2;
+            gw /= 2;
+        }
+    }
+    return OMNITOK_OK;
+}
+
 // encoder up to the pre_vq input: leaves tokens [B, T', h, w, D] in e->X  (reference
-// omnitokenizer.py:925-957 OmniTokenizer_Encoder.forward)
+// omnitokenizer.py:881-947 OmniTokenizer_Encoder.forward / encode)
 static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int *T_out, int *S_out,
                          hipStream_t stream) {
     if (!e->finalized) {
@@ -676,58 +908,81 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
         return OMNITOK_ERR_STATE;
     }
     const omnitok_config &c = e->cfg;
-    const int p = c.patch_size, pt = c.temporal_patch_size, D = c.dim, C = c.image_channels;
-    // reference omnitokenizer.py:931-932
-    OT_CHECK_ARG(F >= 1 && (F - 1) % pt == 0,
-                 "number of frames (%d) minus one (%d) must be divisible by temporal patch size (%d)", F, F - 1, pt);
-    OT_CHECK_ARG(H % p == 0 && W_ % p == 0, "image size %dx%d not divisible by patch size %d", H, W_, p);
-    const int gh = H / p, gw = W_ / p, S = gh * gw, T = 1 + (F - 1) / pt;
-    OT_CHECK_ARG(S % 64 == 0, "encode: %d tokens per frame; spatial attention needs a multiple of 64", S);
-    OT_CHECK_ARG(gh == gw, "encode: the reference assumes a square token grid (int(sqrt(N)), attention.py:261)");
-    if (std::string(c.enc_block).find('w') != std::string::npos)
-        OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "encode: token grid %dx%d not divisible by the 8x8 window", gh, gw);
-    if (B == 0) return OMNITOK_OK;
+    const Geo g = geometry(c);
+    const int D = c.dim, C = c.image_channels, p = g.p_enc, pt = g.pt_enc;
+    int To, gho, gwo;
+    if (int rc = encode_shape(e, F, H, W_, &To, &gho, &gwo)) return rc;
+    int gh = H / p, gw = W_ / p;
+    const int S = gh * gw, T = 1 + (F - 1) / pt;
+    if (int rc = check_attention_grid("encode", c.enc_block, gh, gw)) return rc;
     const int64_t L = (int64_t)B * T * S;
     if (int rc = ensure_workspace(e, L)) return rc;
-    const int K0 = C * p * p, K1 = K0 * pt;
+    const char *names[2] = {"encoder.to_patch_emb_first_frame", "encoder.to_patch_emb"};
 
-    // ---- patch embedding (reference omnitokenizer.py:806-822, 934-945) ----------------------
-    OT_RUN("patchify_ln", ((double)B * S * K0) * 8.0,
-           omnitok_patchify_ln(x, B, C, F, H, W_, 0, 1, 1, p, W(e, "encoder.to_patch_emb_first_frame.1.weight"),
-                               W(e, "encoder.to_patch_emb_first_frame.1.bias"), 1e-5f, e->HD.p, stream));
-    OT_RUN("gemm_patch", 2.0 * B * S * (double)K0 * D,
-           omnitok_gemm(e->HD.p, K0, W(e, "encoder.to_patch_emb_first_frame.2.weight"), K0,
-                        W(e, "encoder.to_patch_emb_first_frame.2.bias"), nullptr, 0, e->AO.p, D, (int64_t)B * S, D, K0,
-                        OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
-    OT_RUN("layernorm", 2.0 * B * S * D * 4.0,
-           omnitok_layernorm(e->AO.p, W(e, "encoder.to_patch_emb_first_frame.3.weight"),
-                             W(e, "encoder.to_patch_emb_first_frame.3.bias"), e->X.p, (int64_t)B * S, D, 1e-5f, S,
-                             (int64_t)T * S, 0, stream));
-    if (T > 1) {
-        const int64_t M1 = (int64_t)B * (T - 1) * S;
-        OT_RUN("patchify_ln", ((double)M1 * K1) * 8.0,
-               omnitok_patchify_ln(x, B, C, F, H, W_, 1, T - 1, pt, p, W(e, "encoder.to_patch_emb.1.weight"),
-                                   W(e, "encoder.to_patch_emb.1.bias"), 1e-5f, e->HD.p, stream));
-        OT_RUN("gemm_patch", 2.0 * M1 * (double)K1 * D,
-               omnitok_gemm(e->HD.p, K1, W(e, "encoder.to_patch_emb.2.weight"), K1, W(e, "encoder.to_patch_emb.2.bias"),
-                            nullptr, 0, e->AO.p, D, M1, D, K1, OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
-        OT_RUN("layernorm", 2.0 * M1 * D * 4.0,
-               omnitok_layernorm(e->AO.p, W(e, "encoder.to_patch_emb.3.weight"), W(e, "encoder.to_patch_emb.3.bias"),
-                                 e->X.p, M1, D, 1e-5f, (int64_t)(T - 1) * S, (int64_t)T * S, S, stream));
+    // ---- patch embedding (reference omnitokenizer.py:806-838, 934-945) ----------------------
+    for (int i = 0; i < 2; ++i) {
+        const int tt = i ? T - 1 : 1, f0 = i, pti = i ? pt : 1;
+        if (tt == 0) break;
+        const int64_t M = (int64_t)B * tt * S;
+        const std::string n = names[i];
+        const int K = e->pe_k[i], ld = e->pe_ld[i];
+        // rows (b, t, s) of this frame group -> rows of the [B, T, S] token tensor
+        const int64_t rpg = (int64_t)tt * S, gstride = (int64_t)T * S, goff = i ? S : 0;
+        if (c.patch_embed_cnn) {
+            // Conv3d with kernel == stride is im2col x W; eval-mode BatchNorm is folded into W, b
+            OT_RUN("patchify_ln", ((double)M * K) * 8.0,
+                   omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, nullptr, nullptr, 0.0f, e->HD.p, ld, stream));
+            OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
+                   omnitok_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
+                                OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+            // scatter the frame group into the token tensor (a strided row copy)
+            for (int b = 0; b < B; ++b)
+                OT_HIP(hipMemcpyAsync(e->X.p + ((int64_t)b * gstride + goff) * D, e->AO.p + (int64_t)b * rpg * D,
+                                      (size_t)rpg * D * 4, hipMemcpyDeviceToDevice, stream));
+            continue;
+        }
+        OT_RUN("patchify_ln", ((double)M * K) * 8.0,
+               omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, W(e, n + ".1.weight"), W(e, n + ".1.bias"), 1e-5f,
+                                   e->HD.p, ld, stream));
+        OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
+               omnitok_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
+                            OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+        OT_RUN("layernorm", 2.0 * M * D * 4.0,
+               omnitok_layernorm(e->AO.p, W(e, n + ".3.weight"), W(e, n + ".3.bias"), e->X.p, M, D, 1e-5f, rpg, gstride,
+                                 goff, stream));
     }
     // ---- spatial then temporal transformer (reference omnitokenizer.py:891-903) -------------
-    if (int rc = run_transformer(e, e->enc_s, B, T, gh, gw, true, stream)) return rc;
+    if (int rc = run_transformer(e, e->enc_s, B, T, &gh, &gw, true, stream)) return rc;
+    const int S2 = gh * gw;  // pooling blocks shrink the grid, omnitokenizer.py:898-899
+    const int64_t L2 = (int64_t)B * T * S2;
     if (T > 1) {
-        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S, D, stream));
+        OT_RUN("transpose", 2.0 * L2 * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S2, D, stream));
         std::swap(e->X, e->X2);
     }
-    if (int rc = run_transformer(e, e->enc_t, B, T, gh, gw, false, stream)) return rc;
+    if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream)) return rc;
     if (T > 1) {
-        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T, D, stream));
+        OT_RUN("transpose", 2.0 * L2 * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S2, T, D, stream));
         std::swap(e->X, e->X2);
     }
-    *T_out = T;
-    *S_out = S;
+    // ---- deferred pools (reference omnitokenizer.py:907-914) ---------------------------------
+    if (g.defer_s) {
+        OT_RUN("pool", 1.25 * L2 * D * 4.0,
+               omnitok_token_resample(e->X.p, e->X2.p, 0, (int64_t)B * T, 1, gh, gw, D, stream));
+        std::swap(e->X, e->X2);
+        gh /= 2;
+        gw /= 2;
+    }
+    if (g.defer_t && T > 1) {
+        OT_RUN("pool", 1.5 * (double)B * T * gh * gw * D * 4.0,
+               omnitok_token_resample(e->X.p, e->X2.p, 3, B, T, gh * gw, 1, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    if (gh != gho || gw != gwo) {
+        set_error("encode: internal shape mismatch");
+        return OMNITOK_ERR_STATE;
+    }
+    *T_out = To;
+    *S_out = gh * gw;
     return OMNITOK_OK;
 }
 
@@ -762,7 +1017,8 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
 
 enum class LatentKind { Ids, ChannelLast, ChannelFirst };
 
-// shared decode body: latent (ids or continuous z) -> post_vq -> temporal -> spatial -> to_pixels
+// shared decode body: latent (ids or continuous z) -> post_vq -> [deferred up-sampling] -> temporal ->
+// spatial -> to_pixels  (reference omnitokenizer.py:1101-1118 forward, :1059-1098 decode)
 static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent, int B, int T, int gh, int gw,
                          float *pixels_out, hipStream_t stream) {
     if (!e->finalized) {
@@ -770,54 +1026,76 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
         return OMNITOK_ERR_STATE;
     }
     const omnitok_config &c = e->cfg;
-    const int p = c.patch_size, pt = c.temporal_patch_size, D = c.dim, C = c.image_channels;
-    const int S = gh * gw;
-    OT_CHECK_ARG(T >= 1 && S % 64 == 0 && gh == gw, "decode: unsupported token grid %dx%dx%d", T, gh, gw);
-    if (std::string(c.dec_block).find('w') != std::string::npos)
-        OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "decode: token grid %dx%d not divisible by the 8x8 window", gh, gw);
-    if (B == 0) return OMNITOK_OK;
-    const int64_t L = (int64_t)B * T * S;
+    const Geo g = geometry(c);
+    const int p = g.p_dec, pt = g.pt_dec, D = c.dim, C = c.image_channels;
+    int F, H, W_;
+    if (int rc = decode_shape(e, T, gh, gw, &F, &H, &W_)) return rc;
+    const int T2 = g.defer_t ? 1 + (T - 1) * 2 : T, gh2 = g.defer_s ? gh * 2 : gh, gw2 = g.defer_s ? gw * 2 : gw;
+    if (int rc = check_attention_grid("decode", std::string("t") + c.dec_block, gh2, gw2)) return rc;
+    const int64_t L0 = (int64_t)B * T * gh * gw;
+    const int S = gh2 * gw2;
+    const int64_t L = (int64_t)B * T2 * S;
     if (int rc = ensure_workspace(e, L)) return rc;
     const int K0 = C * p * p, K1 = K0 * pt;
-    const int H = gh * p, W_ = gw * p, F = 1 + (T - 1) * pt;
 
     if (kind == LatentKind::Ids)
-        OT_RUN("dequant_post_vq", (double)L * D * 4.0,
+        OT_RUN("dequant_post_vq", (double)L0 * D * 4.0,
                omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, "codebook.embeddings"), c.n_codes, 8,
-                                       W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, L, D,
+                                       W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, L0, D,
                                        e->err_flag, stream));
     else
-        OT_RUN("post_vq", (double)L * D * 4.0,
-               omnitok_post_vq(static_cast<const float *>(latent), kind == LatentKind::ChannelFirst, B, (int64_t)T * S, 8,
-                               W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, D, stream));
+        OT_RUN("post_vq", (double)L0 * D * 4.0,
+               omnitok_post_vq(static_cast<const float *>(latent), kind == LatentKind::ChannelFirst, B,
+                               (int64_t)T * gh * gw, 8, W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"),
+                               e->X.p, D, stream));
+    // deferred up-sampling: time first, then space (reference omnitokenizer.py:1103-1109)
+    if (g.defer_t && T > 1) {
+        OT_RUN("pool", 1.5 * (double)B * T2 * gh * gw * D * 4.0,
+               omnitok_token_resample(e->X.p, e->X2.p, 4, B, T, gh * gw, 1, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    if (g.defer_s) {
+        OT_RUN("pool", 1.25 * L * D * 4.0,
+               omnitok_token_resample(e->X.p, e->X2.p, 2, (int64_t)B * T2, 1, gh, gw, D, stream));
+        std::swap(e->X, e->X2);
+    }
+    int ghc = gh2, gwc = gw2;
     // temporal first on decode (reference omnitokenizer.py:1072-1084)
-    if (T > 1) {
-        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S, D, stream));
+    if (T2 > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T2, S, D, stream));
         std::swap(e->X, e->X2);
     }
-    if (int rc = run_transformer(e, e->dec_t, B, T, gh, gw, false, stream)) return rc;
-    if (T > 1) {
-        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T, D, stream));
+    if (int rc = run_transformer(e, e->dec_t, B, T2, &ghc, &gwc, false, stream)) return rc;
+    if (T2 > 1) {
+        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T2, D, stream));
         std::swap(e->X, e->X2);
     }
-    if (int rc = run_transformer(e, e->dec_s, B, T, gh, gw, true, stream)) return rc;
-    // ---- to_pixels (reference omnitokenizer.py:1006-1017, 1089-1096) -------------------------
+    if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream)) return rc;
+    // ---- to_pixels (reference omnitokenizer.py:1006-1033, 1089-1096) -------------------------
     OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,
-           omnitok_gemm(e->X.p, D, W(e, "decoder.to_pixels_first_frame.0.weight"), D,
-                        W(e, "decoder.to_pixels_first_frame.0.bias"), nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
-                        OMNITOK_GEMM_BIAS, S, (int64_t)T * S, 0, stream));
+           omnitok_gemm(e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
+                        OMNITOK_GEMM_BIAS, S, (int64_t)T2 * S, 0, stream));
     OT_RUN("unpatchify", (double)B * S * K0 * 8.0,
            omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 0, 1, 1, p, pixels_out, stream));
-    if (T > 1) {
-        const int64_t M1 = (int64_t)B * (T - 1) * S;
+    if (T2 > 1) {
+        const int64_t M1 = (int64_t)B * (T2 - 1) * S;
         OT_RUN("gemm_pixels", 2.0 * M1 * (double)K1 * D,
-               omnitok_gemm(e->X.p, D, W(e, "decoder.to_pixels.0.weight"), D, W(e, "decoder.to_pixels.0.bias"), nullptr,
-                            0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS, (int64_t)(T - 1) * S, (int64_t)T * S, S,
-                            stream));
+               omnitok_gemm(e->X.p, D, e->px_w[1], D, e->px_b[1], nullptr, 0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS,
+                            (int64_t)(T2 - 1) * S, (int64_t)T2 * S, S, stream));
         OT_RUN("unpatchify", (double)M1 * K1 * 8.0,
-               omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T - 1, pt, p, pixels_out, stream));
+               omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T2 - 1, pt, p, pixels_out, stream));
     }
     return OMNITOK_OK;
+}
+
+extern "C" int omnitok_engine_encode_shape(omnitok_engine *e, int F, int H, int W_, int *T, int *h, int *w) {
+    OT_CHECK_ARG(e && T && h && w, "encode_shape: null pointer");
+    return encode_shape(e, F, H, W_, T, h, w);
+}
+
+extern "C" int omnitok_engine_decode_shape(omnitok_engine *e, int T, int h, int w, int *F, int *H, int *W_) {
+    OT_CHECK_ARG(e && F && H && W_, "decode_shape: null pointer");
+    return decode_shape(e, T, h, w, F, H, W_);
 }
 
 extern "C" int omnitok_decode(omnitok_engine *e, const int64_t *ids, int B, int T, int gh, int gw, float *pixels_out,

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void patchify_ln_kernel(const float *__restric
                                                           int W, int f0, int t, int pt, int p,
                                                           const float *__restrict__ gamma,
                                                           const float *__restrict__ beta, float eps,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, int64_t ldo) {
     const int lane = threadIdx.x & 63;
     const int h = H / p, w = W / p;
     const int64_t rows = (int64_t)B * t * h * w;
@@ -96,9 +96,17 @@ __global__ __launch_bounds__(256) void patchify_ln_kernel(const float *__restric
             v[i] = *reinterpret_cast<const f32x4 *>(video + off);
         }
     }
+    f32x4 *yr = reinterpret_cast<f32x4 *>(out + row * ldo);
+    // zero the K padding [dim, ldo) the GEMM reads (ldo - dim < 32)
+    if (dim + lane * 4 < ldo) yr[dim / 4 + lane] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    if (!gamma) {  // plain im2col rows (the 'cnn' patch-embed: Conv3d with kernel == stride)
+#pragma unroll
+        for (int i = 0; i < LN_MAX_V4; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < dim) yr[lane + 64 * i] = v[i];
+        return;
+    }
     float mean, rstd;
     row_stats(v, nv, lane, dim, eps, mean, rstd);
-    f32x4 *yr = reinterpret_cast<f32x4 *>(out + row * dim);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
 #pragma unroll
@@ -172,18 +180,20 @@ extern "C" int omnitok_layernorm(const float *x, const float *gamma, const float
 
 extern "C" int omnitok_patchify_ln(const float *video, int B, int C, int F, int H, int W, int f0, int t, int pt,
                                    int p, const float *gamma, const float *beta, float eps, float *out,
-                                   omnitok_stream_t stream_) {
+                                   int64_t ldo, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(video && gamma && beta && out, "patchify_ln: null pointer");
+    OT_CHECK_ARG(video && out && ((gamma != nullptr) == (beta != nullptr)), "patchify_ln: null pointer");
     OT_CHECK_ARG(p % 4 == 0 && H % p == 0 && W % p == 0, "patchify_ln: patch size %d / image %dx%d unsupported", p,
                  H, W);
     OT_CHECK_ARG(f0 >= 0 && f0 + t * pt <= F, "patchify_ln: frame range out of bounds");
     const int dim = C * pt * p * p;
     OT_CHECK_ARG(dim <= 256 * LN_MAX_V4, "patchify_ln: feature dim %d too large", dim);
+    if (ldo == 0) ldo = dim;
+    OT_CHECK_ARG(ldo >= dim && ldo % 4 == 0 && ldo - dim < 256, "patchify_ln: bad output row stride %lld", (long long)ldo);
     const int64_t rows = (int64_t)B * t * (H / p) * (W / p);
     if (rows == 0) return OMNITOK_OK;
     hipLaunchKernelGGL(patchify_ln_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, video, B, C, F, H,
-                       W, f0, t, pt, p, gamma, beta, eps, out);
+                       W, f0, t, pt, p, gamma, beta, eps, out, ldo);
     OT_LAUNCH_CHECK("patchify_ln");
     return OMNITOK_OK;
 }

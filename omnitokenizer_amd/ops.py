@@ -114,12 +114,17 @@ def linear_geglu(x, w1_packed):
     return out
 
 
-def patchify_ln(video, f0, t, pt, p, gamma, beta, eps=1e-5):
+def patchify_ln(video, f0, t, pt, p, gamma=None, beta=None, eps=1e-5, ldo=0):
+    """gamma/beta None: plain im2col rows (no LayerNorm).  ldo: output row stride (0 = dense);
+    the padding columns are zero."""
     video = _req(video, "video")
     B, C, F, H, W = video.shape
-    out = torch.empty(B * t * (H // p) * (W // p), C * pt * p * p, device=video.device, dtype=torch.float32)
-    check(_lib.load().omnitok_patchify_ln(_p(video), B, C, F, H, W, f0, t, pt, p, _p(_req(gamma, "gamma")),
-                                          _p(_req(beta, "beta")), eps, _p(out), _stream()), "patchify_ln")
+    dim = C * pt * p * p
+    out = torch.empty(B * t * (H // p) * (W // p), ldo or dim, device=video.device, dtype=torch.float32)
+    check(_lib.load().omnitok_patchify_ln(_p(video), B, C, F, H, W, f0, t, pt, p,
+                                          None if gamma is None else _p(_req(gamma, "gamma")),
+                                          None if beta is None else _p(_req(beta, "beta")), eps, _p(out), ldo,
+                                          _stream()), "patchify_ln")
     return out
 
 
@@ -241,6 +246,28 @@ def dequant_post_vq(ids, codebook, w, b):
     if int(err.item()):
         raise IndexError("token id out of range")
     return tok
+
+
+def token_resample(x, mode):
+    """Token-grid resampling used by the pooling blocks and the deferred pools.  mode:
+    "avg2d" / "max2d": x [n, gh, gw, D] -> [n, gh/2, gw/2, D]   (Pooling 'a' / 'm', attention.py:83-106)
+    "up2d":            x [n, gh, gw, D] -> [n, 2gh, 2gw, D]     (nearest, omnitokenizer.py:1001)
+    "avg_t":           x [B, T, S, D]   -> [B, 1+(T-1)//2, S, D] (frame 0 kept, omnitokenizer.py:909-914)
+    "up_t":            x [B, T, S, D]   -> [B, 1+(T-1)*2, S, D]  (frame 0 kept, omnitokenizer.py:1103-1107)"""
+    x = _req(x, "x")
+    m = {"avg2d": 0, "max2d": 1, "up2d": 2, "avg_t": 3, "up_t": 4}[mode]
+    D = x.shape[-1]
+    if m <= 2:
+        n, gh, gw = x.shape[:3]
+        T = 1
+        oshape = (n, gh // 2, gw // 2, D) if m < 2 else (n, 2 * gh, 2 * gw, D)
+    else:
+        n, T, S = x.shape[:3]
+        gh, gw = S, 1
+        oshape = (n, 1 + (T - 1) // 2, S, D) if m == 3 else (n, 1 + (T - 1) * 2, S, D)
+    out = torch.empty(oshape, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_token_resample(_p(x), _p(out), m, n, T, gh, gw, D, _stream()), "token_resample")
+    return out
 
 
 def vae_sample(x, w, b, noise=None, return_moments=False):

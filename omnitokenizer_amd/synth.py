@@ -54,6 +54,11 @@ def _transformer_spec(prefix: str, block: str, cfg: OmniTokConfig, spatial_pos: 
             spec[f"{p}.1.qkv.weight"] = (3 * d, d)
             spec[f"{p}.1.proj.weight"] = (d, d)
             spec[f"{p}.1.proj.bias"] = (d,)
+        elif c == "l":  # Pooling('l'): Linear(4*dim, dim), reference attention.py:92-93
+            spec[f"{p}.1.pool.weight"] = (d, 4 * d)
+            spec[f"{p}.1.pool.bias"] = (d,)
+        elif c in "am":  # parameter-free AvgPool2d / MaxPool2d
+            pass
         else:
             raise NotImplementedError(c)
         spec[f"{p}.3.0.weight"] = (d,)
@@ -67,9 +72,24 @@ def _transformer_spec(prefix: str, block: str, cfg: OmniTokConfig, spatial_pos: 
 def path_state_spec(cfg: OmniTokConfig) -> "OrderedDict[str, tuple]":
     """name -> shape for every reference state_dict entry on the encode/decode path."""
     spec: OrderedDict = OrderedDict()
-    c, p, pt, d = cfg.image_channels, cfg.patch_size, cfg.temporal_patch_size, cfg.dim
+    c, d = cfg.image_channels, cfg.dim
+    p, pt = cfg.enc_patch_size, cfg.enc_temporal_patch_size
     k0, k1 = c * p * p, c * p * p * pt
-    for name, k in (("to_patch_emb_first_frame", k0), ("to_patch_emb", k1)):
+    cnn = cfg.patch_embed == "cnn"
+
+    def batchnorm(prefix, n):  # SyncBatchNorm state (base.py:276)
+        spec[f"{prefix}.weight"] = (n,)
+        spec[f"{prefix}.bias"] = (n,)
+        spec[f"{prefix}.running_mean"] = (n,)
+        spec[f"{prefix}.running_var"] = (n,)
+        spec[f"{prefix}.num_batches_tracked"] = ()
+
+    for name, k, ptk in (("to_patch_emb_first_frame", k0, 1), ("to_patch_emb", k1, pt)):
+        if cnn:  # reference omnitokenizer.py:823-836
+            spec[f"encoder.{name}.0.weight"] = (d, c, ptk, p, p)
+            spec[f"encoder.{name}.0.bias"] = (d,)
+            batchnorm(f"encoder.{name}.1", d)
+            continue
         spec[f"encoder.{name}.1.weight"] = (k,)
         spec[f"encoder.{name}.1.bias"] = (k,)
         spec[f"encoder.{name}.2.weight"] = (d, k)
@@ -82,10 +102,15 @@ def path_state_spec(cfg: OmniTokConfig) -> "OrderedDict[str, tuple]":
     _transformer_spec("encoder.enc_temporal_transformer", "t" * cfg.temporal_depth, cfg, "rel", spec)
     _transformer_spec("decoder.dec_spatial_transformer", cfg.dec_block, cfg, cfg.spatial_pos, spec)
     _transformer_spec("decoder.dec_temporal_transformer", "t" * cfg.temporal_depth, cfg, "rel", spec)
-    spec["decoder.to_pixels_first_frame.0.weight"] = (k0, d)
-    spec["decoder.to_pixels_first_frame.0.bias"] = (k0,)
-    spec["decoder.to_pixels.0.weight"] = (k1, d)
-    spec["decoder.to_pixels.0.bias"] = (k1,)
+    pd, ptd = cfg.dec_patch_size, cfg.dec_temporal_patch_size
+    for name, ptk in (("to_pixels_first_frame", 1), ("to_pixels", ptd)):
+        if cnn:  # reference omnitokenizer.py:1019-1031
+            spec[f"decoder.{name}.1.weight"] = (d, c, ptk, pd, pd)
+            spec[f"decoder.{name}.1.bias"] = (c,)
+            batchnorm(f"decoder.{name}.2", c)
+        else:
+            spec[f"decoder.{name}.0.weight"] = (c * pd * pd * ptk, d)
+            spec[f"decoder.{name}.0.bias"] = (c * pd * pd * ptk,)
     spec["codebook.embeddings"] = (cfg.n_codes, cfg.codebook_dim)
     spec["codebook.N"] = (cfg.n_codes,)
     spec["codebook.z_avg"] = (cfg.n_codes, cfg.codebook_dim)
@@ -126,6 +151,15 @@ def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, tor
 
         if name.endswith("relative_position_index"):
             sd[name] = relative_position_index(cfg.window_size)
+            continue
+        if leaf == "num_batches_tracked":
+            sd[name] = torch.tensor(0, dtype=torch.int64)
+            continue
+        if leaf == "running_var":
+            sd[name] = torch.from_numpy((rng.random(shape, dtype=np.float32) + np.float32(0.5)).astype(np.float32))
+            continue
+        if leaf == "running_mean":
+            sd[name] = torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)))
             continue
         if name == "codebook.embeddings":
             v = randn(1.0)  # reference codebook.py:14 torch.randn(n_codes, dim)

@@ -69,7 +69,10 @@ class OmniTokenizer_VQGAN(nn.Module):
         for name, shape in path_state_spec(cfg).items():
             if name.endswith("relative_position_index"):
                 t = relative_position_index(cfg.window_size)
-            elif name.endswith((".gamma", ".q_scale", ".k_scale")) or (name.endswith(".weight") and len(shape) == 1):
+            elif name.endswith("num_batches_tracked"):
+                t = torch.tensor(0, dtype=torch.int64)
+            elif name.endswith((".gamma", ".q_scale", ".k_scale", ".running_var")) or \
+                    (name.endswith(".weight") and len(shape) == 1):
                 t = torch.ones(shape)
             else:
                 t = torch.zeros(shape)
@@ -137,6 +140,10 @@ class OmniTokenizer_VQGAN(nn.Module):
         nc.enc_block = c.enc_block.encode()
         nc.dec_block = c.dec_block.encode()
         nc.use_vae = int(c.use_vae)
+        nc.patch_embed_cnn = int(c.patch_embed == "cnn")
+        nc.defer_temporal_pool = int(c.defer_temporal_pool)
+        nc.defer_spatial_pool = int(c.defer_spatial_pool)
+        nc.gen_upscale = int(c.gen_upscale)
         return nc
 
     def _signature(self):
@@ -204,11 +211,11 @@ class OmniTokenizer_VQGAN(nn.Module):
         if x.device != self.device:
             raise RuntimeError(f"input on {x.device}, model on {self.device}")
         x = x.to(torch.float32).contiguous()
-        pt, p = self.cfg.temporal_patch_size, self.cfg.patch_size
+        pt = self.cfg.enc_temporal_patch_size
         if (F - 1) % pt != 0:
             raise AssertionError(f"number of frames ({F}) minus one ({F - 1}) must be divisible by temporal "
                                  f"patch size ({pt})")  # reference omnitokenizer.py:931-932
-        T, h, w = 1 + (F - 1) // pt, H // p, W // p
+        T, h, w = self._shape("encode", F, H, W)
         if self.use_vae:
             return self._encode_vae(x, is_image, (B, F, H, W, T, h, w), noise, sample_posterior, return_moments)
         ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
@@ -223,6 +230,14 @@ class OmniTokenizer_VQGAN(nn.Module):
         if return_latents:
             return (emb, ids, z) if include_embeddings else (ids, z)
         return (emb, ids) if include_embeddings else ids
+
+    def _shape(self, which, a, b, c):
+        """latent <-> pixel shapes from the engine (pooling blocks, deferred pools and gen_upscale
+        change them; include/omnitok.h omnitok_engine_{encode,decode}_shape)."""
+        out = [ctypes.c_int() for _ in range(3)]
+        fn = getattr(_lib.load(), f"omnitok_engine_{which}_shape")
+        check(fn(self._engine, a, b, c, *[ctypes.byref(o) for o in out]), f"{which}_shape")
+        return tuple(o.value for o in out)
 
     def _encode_vae(self, x, is_image, dims, noise, sample_posterior, return_moments):
         B, F, H, W, T, h, w = dims
@@ -281,9 +296,8 @@ class OmniTokenizer_VQGAN(nn.Module):
             raise ValueError(f"latent channel dim is {C}, expected codebook_dim={cd} "
                              f"({'channel-first' if channel_first else 'channel-last'} layout)")
         c = self.cfg
-        F = 1 + (T - 1) * c.temporal_patch_size
-        out = torch.empty(B, c.image_channels, F, h * c.patch_size, w * c.patch_size, device=z.device,
-                          dtype=torch.float32)
+        F, Ho, Wo = self._shape("decode", T, h, w)
+        out = torch.empty(B, c.image_channels, F, Ho, Wo, device=z.device, dtype=torch.float32)
         check(_lib.load().omnitok_decode_vae(self._engine, ctypes.c_void_p(z.data_ptr()), channel_first, B, T, h, w,
                                              ctypes.c_void_p(out.data_ptr()),
                                              torch.cuda.current_stream().cuda_stream), "decode_vae")
@@ -316,9 +330,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         if is_image and T != 1:
             raise ValueError("is_image=True expects a single latent frame")
         c = self.cfg
-        F = 1 + (T - 1) * c.temporal_patch_size
-        out = torch.empty(B, c.image_channels, F, h * c.patch_size, w * c.patch_size, device=ids.device,
-                          dtype=torch.float32)
+        F, Ho, Wo = self._shape("decode", T, h, w)
+        out = torch.empty(B, c.image_channels, F, Ho, Wo, device=ids.device, dtype=torch.float32)
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
         check(lib.omnitok_decode(self._engine, ctypes.c_void_p(ids.data_ptr()), B, T, h, w,

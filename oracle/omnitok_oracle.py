@@ -192,6 +192,19 @@ def feed_forward(sd, p, x):
     return F.linear(F.gelu(gate) * val, sd[f"{p}.4.weight"])
 
 
+def pooling(sd, p, x, kind):
+    """reference attention.py:83-113 Pooling.forward on [B, N, C] tokens of a sqrt(N) x sqrt(N) grid:
+    'a' AvgPool2d(2), 'm' MaxPool2d(2); 'l' Linear(4C -> C) on x.view(B, N/4, 4C), i.e. on four
+    CONSECUTIVE tokens of the row-major sequence (not a 2x2 window)."""
+    B, N, C = x.shape
+    if kind in "am":
+        H = W = int(math.sqrt(N))
+        y = x.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        y = F.avg_pool2d(y, 2) if kind == "a" else F.max_pool2d(y, 2)
+        return y.view(B, C, -1).transpose(1, 2).contiguous()
+    return F.linear(x.reshape(B, N // 4, 4 * C), sd[f"{p}.pool.weight"], sd[f"{p}.pool.bias"])
+
+
 def transformer(sd, prefix, x, block, video_shape, cfg, is_spatial, causal, spatial_pos, taps=None):
     """reference attention.py:655-689 Transformer.forward: per block PEG(+res) -> attention(+res)
     -> FF(+res); final custom LayerNorm."""
@@ -203,9 +216,15 @@ def transformer(sd, prefix, x, block, video_shape, cfg, is_spatial, causal, spat
             x = attention(sd, f"{p}.1", x, cfg, is_spatial, causal, spatial_pos) + x
         elif c == "w":
             x = window_attention(sd, f"{p}.1", x, cfg) + x
+        elif c in "aml":
+            x = pooling(sd, f"{p}.1", x, c)  # no residual, attention.py:674
         else:
+            # 'n' / 'r' (Up) blocks: the reference decoder itself raises on them (einops shape
+            # mismatch at omnitokenizer.py:1078, probed), so there is nothing to restate
             raise NotImplementedError(c)
         x = feed_forward(sd, f"{p}.3", x) + x
+        if c in "aml":  # attention.py:683-684
+            video_shape = (video_shape[0], video_shape[1], video_shape[2] // 2, video_shape[3] // 2)
         if taps is not None:
             taps[f"{prefix}.layers.{i}"] = x
     return layer_norm(x, sd[f"{prefix}.norm_out.gamma"], sd[f"{prefix}.norm_out.beta"])
@@ -234,17 +253,26 @@ def unpatchify(tok, C, p, pt):
 
 def patch_embed(sd, video, cfg):
     """reference omnitokenizer.py:806-822, 934-945: separate weights for frame 0 and the rest."""
+    p_enc, pt_enc = cfg.enc_patch_size, cfg.enc_temporal_patch_size
+
     def emb(name, frames, pt):
-        t = patchify(frames, cfg.patch_size, pt)
+        if cfg.patch_embed == "cnn":
+            # :823-838 Conv3d(kernel = stride = (pt, p, p)) -> SyncBatchNorm (eval: running stats)
+            n = f"encoder.{name}"
+            t = F.conv3d(frames, sd[f"{n}.0.weight"], sd[f"{n}.0.bias"], stride=(pt, p_enc, p_enc))
+            t = F.batch_norm(t, sd[f"{n}.1.running_mean"], sd[f"{n}.1.running_var"], sd[f"{n}.1.weight"],
+                             sd[f"{n}.1.bias"], False, 0.1, 1e-5)
+            return t.permute(0, 2, 3, 4, 1)
+        t = patchify(frames, p_enc, pt)
         t = layer_norm(t, sd[f"encoder.{name}.1.weight"], sd[f"encoder.{name}.1.bias"])
         t = F.linear(t, sd[f"encoder.{name}.2.weight"], sd[f"encoder.{name}.2.bias"])
         return layer_norm(t, sd[f"encoder.{name}.3.weight"], sd[f"encoder.{name}.3.bias"])
     f = video.shape[2]
-    assert (f - 1) % cfg.temporal_patch_size == 0, \
+    assert (f - 1) % pt_enc == 0, \
         f"number of frames ({f}) minus one must be divisible by temporal patch size"
     tok = emb("to_patch_emb_first_frame", video[:, :, :1], 1)
     if f > 1:
-        tok = torch.cat([tok, emb("to_patch_emb", video[:, :, 1:], cfg.temporal_patch_size)], dim=1)
+        tok = torch.cat([tok, emb("to_patch_emb", video[:, :, 1:], pt_enc)], dim=1)
     return tok  # b t h w d
 
 
@@ -262,10 +290,20 @@ def encoder(sd, x, is_image, cfg, taps=None):
                     True, False, cfg.spatial_pos, taps)
     if taps is not None:
         taps["enc_spatial"] = s
+    h = w = int(math.sqrt(s.shape[1]))  # :898-899 (pooling blocks shrink the grid)
+    shape = (b, t, h, w)
     s = s.reshape(b, t, h, w, d).permute(0, 2, 3, 1, 4).reshape(b * h * w, t, d)
     s = transformer(sd, "encoder.enc_temporal_transformer", s, "t" * cfg.temporal_depth, shape, cfg,
                     False, cfg.causal_in_temporal_transformer, "rel", taps)
-    return s.reshape(b, h, w, t, d).permute(0, 3, 1, 2, 4).contiguous()
+    tok = s.reshape(b, h, w, t, d).permute(0, 3, 1, 2, 4).contiguous()
+    if cfg.patch_embed == "linear" and (cfg.defer_spatial_pool or cfg.defer_temporal_pool):
+        y = tok.permute(0, 4, 1, 2, 3)  # b d t h w, :907-914
+        if cfg.defer_spatial_pool:
+            y = F.avg_pool3d(y, (1, 2, 2))
+        if cfg.defer_temporal_pool and y.shape[2] > 1:
+            y = torch.cat([y[:, :, :1], F.avg_pool3d(y[:, :, 1:], (2, 1, 1))], dim=2)
+        tok = y.permute(0, 2, 3, 4, 1).contiguous()
+    return tok
 
 
 def pre_vq(sd, tok, cfg):
@@ -363,6 +401,13 @@ def decode(sd, ids, is_image, cfg, taps=None):
 
 def _decode_tokens(sd, tok, is_image, cfg, taps):
     """decoder on post_vq tokens [b,t,h,w,d] (reference omnitokenizer.py:1101-1118 / 1059-1098)."""
+    if cfg.patch_embed == "linear" and (cfg.defer_spatial_pool or cfg.defer_temporal_pool):
+        y = tok.permute(0, 4, 1, 2, 3)  # b d t h w, omnitokenizer.py:1101-1110
+        if cfg.defer_temporal_pool and y.shape[2] > 1:
+            y = torch.cat([y[:, :, :1], F.interpolate(y[:, :, 1:], scale_factor=(2, 1, 1), mode="nearest")], dim=2)
+        if cfg.defer_spatial_pool:
+            y = F.interpolate(y, scale_factor=(1, 2, 2), mode="nearest")
+        tok = y.permute(0, 2, 3, 4, 1).contiguous()
     b, t, h, w, d = tok.shape
     shape = (b, t, h, w)
     s = tok.permute(0, 2, 3, 1, 4).reshape(b * h * w, t, d)
@@ -374,13 +419,21 @@ def _decode_tokens(sd, tok, is_image, cfg, taps):
     s = s.reshape(b, t, h, w, d)
     if taps is not None:
         taps["dec_tokens"] = s
-    C, p, pt = cfg.image_channels, cfg.patch_size, cfg.temporal_patch_size
-    f0 = F.linear(s[:, :1], sd["decoder.to_pixels_first_frame.0.weight"],
-                  sd["decoder.to_pixels_first_frame.0.bias"])
-    out = unpatchify(f0, C, p, 1)
+    C, p, pt = cfg.image_channels, cfg.dec_patch_size, cfg.dec_temporal_patch_size
+
+    def pixels(name, toks, ptk):
+        n = f"decoder.{name}"
+        if cfg.patch_embed == "cnn":
+            # :1019-1033 ConvTranspose3d(kernel = stride) -> SyncBatchNorm(3) (eval)
+            y = F.conv_transpose3d(toks.permute(0, 4, 1, 2, 3), sd[f"{n}.1.weight"], sd[f"{n}.1.bias"],
+                                   stride=(ptk, p, p))
+            return F.batch_norm(y, sd[f"{n}.2.running_mean"], sd[f"{n}.2.running_var"], sd[f"{n}.2.weight"],
+                                sd[f"{n}.2.bias"], False, 0.1, 1e-5)
+        return unpatchify(F.linear(toks, sd[f"{n}.0.weight"], sd[f"{n}.0.bias"]), C, p, ptk)
+
+    out = pixels("to_pixels_first_frame", s[:, :1], 1)
     if t > 1:
-        fr = F.linear(s[:, 1:], sd["decoder.to_pixels.0.weight"], sd["decoder.to_pixels.0.bias"])
-        out = torch.cat([out, unpatchify(fr, C, p, pt)], dim=2)
+        out = torch.cat([out, pixels("to_pixels", s[:, 1:], pt)], dim=2)
     return out[:, :, 0] if is_image else out
 
 

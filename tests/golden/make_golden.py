@@ -50,6 +50,22 @@ CASES = [
 ]
 
 
+# config coverage beyond the released checkpoints (SURVEY.md 8(a) rows a4', a18 and the deferred
+# pools / gen_upscale of omnitokenizer.py:792-804, 957-959); same fixture format as CASES
+VARIANT_CASES = [
+    ("var_pool_a_r128_vid", 2, "sdpa", dict(resolution=128, enc_block="tawt"), 1, 5, 1),
+    ("var_pool_m_r128_img", 2, "sdpa", dict(resolution=128, enc_block="tmwt"), 2, 1, 1),
+    ("var_pool_l_r128_vid", 2, "sdpa", dict(resolution=128, enc_block="tlwt"), 1, 5, 1),
+    ("var_cnn_r128_img", 2, "sdpa", dict(resolution=128, patch_embed="cnn"), 2, 1, 2),
+    ("var_cnn_r128_vid", 1, "legacy", dict(resolution=128, patch_embed="cnn"), 1, 5, 2),
+    ("var_defer_t_r128_vid", 2, "sdpa", dict(resolution=128, defer_temporal_pool=True), 1, 9, 2),
+    ("var_defer_s_r128_vid", 2, "sdpa", dict(resolution=128, defer_spatial_pool=True), 1, 5, 2),
+    ("var_defer_ts_r128_img", 2, "sdpa", dict(resolution=128, defer_spatial_pool=True, defer_temporal_pool=True),
+     1, 1, 2),
+    ("var_genup2_r64_vid", 2, "sdpa", dict(resolution=64, gen_upscale=2), 1, 5, 2),
+]
+
+
 def run_case(name, stage, mode, overrides, batch, frames, stride):
     args = make_args(stage, **overrides)
     cfg = OmniTokConfig.from_args(args, attention_mode=mode)
@@ -66,9 +82,10 @@ def run_case(name, stage, mode, overrides, batch, frames, stride):
         h = model.pre_vq_conv(model.encoder(x, is_image))
         z = torch.nn.functional.normalize(h, p=2, dim=1)
         recon = model.decode(ids, is_image)
-        flat = ids.reshape(ids.shape[0], -1)
-        recon_flat = model.decode(flat, is_image)
-    assert torch.equal(recon, recon_flat)  # flat-id decode == 4-D-id decode
+        if is_image or ids.shape[-1] == cfg.resolution // cfg.patch_size:
+            flat = ids.reshape(ids.shape[0], -1)
+            # flat-id decode == 4-D-id decode; video needs the un-pooled grid (:284)
+            assert torch.equal(recon, model.decode(flat, is_image))
     assert int(ids.max()) < 32768
     sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
     np.savez_compressed(
@@ -173,6 +190,9 @@ if __name__ == "__main__":
         make_vq_kat()
     if only in (None, "e2e"):
         for c in CASES:
+            run_case(*c)
+    if only in (None, "variants"):
+        for c in VARIANT_CASES:
             run_case(*c)
     if only in (None, "vae"):
         for c in VAE_CASES:

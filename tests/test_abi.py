@@ -83,11 +83,19 @@ def test_state_dict_contract(lib):
 def test_config_rejects_unbuilt_variants():
     from omnitokenizer_amd import make_args
     from omnitokenizer_amd.config import OmniTokConfig
-    for bad in (dict(patch_embed="cnn"), dict(enc_block="ttaw"), dict(use_external_codebook=True),
-                dict(dim_head=32)):
+    # 'n'/'r' Up blocks make the reference decoder itself raise (omnitokenizer.py:1078); GroupNorm(32)
+    # over the cnn decoder's 3 channels cannot be constructed (base.py:274); external VectorQuantize's
+    # decode() is broken in the reference
+    for bad in (dict(dec_block="tntt"), dict(dec_block="trtt"), dict(dec_block="tatt"), dict(enc_block="ttnw"),
+                dict(patch_embed="cnn", norm_type="group"), dict(patch_embed="conv"),
+                dict(use_external_codebook=True), dict(dim_head=32)):
         with pytest.raises((NotImplementedError, ValueError)):
             OmniTokConfig.from_args(make_args(2, **bad))
     assert OmniTokConfig.from_args(make_args(2, use_vae=True)).use_vae
+    c = OmniTokConfig.from_args(make_args(2, defer_spatial_pool=True, defer_temporal_pool=True, gen_upscale=2))
+    assert (c.enc_patch_size, c.enc_temporal_patch_size, c.dec_patch_size, c.enc_grid_divisor) == (4, 2, 8, 2)
+    c = OmniTokConfig.from_args(make_args(2, patch_embed="cnn", defer_spatial_pool=True, enc_block="tawl"))
+    assert (c.enc_patch_size, c.dec_patch_size, c.enc_grid_divisor) == (8, 8, 4)  # defer_* ignored for cnn
 
 
 def test_vae_state_dict_contract(lib):

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import omnitok_oracle as orc
-from tests.helpers import E2E_CASES, VAE_CASES, GoldenCase
+from tests.helpers import E2E_CASES, VAE_CASES, VARIANT_CASES, GoldenCase
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,7 @@ def assert_ids_match_or_near_tie(ids, ids_ref, z_ours, codebook, name):
     return int(bad.numel())
 
 
-@pytest.mark.parametrize("name", E2E_CASES)
+@pytest.mark.parametrize("name", E2E_CASES + VARIANT_CASES)
 def test_encode_decode_vs_reference_golden(models, name):
     c = GoldenCase(name)
     m = models(c)

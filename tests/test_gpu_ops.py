@@ -364,6 +364,40 @@ def test_pre_vq_and_dequant(ops):
         ops.dequant_post_vq(dev(bad), dev(E), dev(pw), dev(pb))
 
 
+def test_token_resample(ops):
+    """pooling blocks / deferred pools vs the torch ops the reference calls (bit-exact: adds and
+    power-of-two scalings in the same order)."""
+    x = rnd(3, 8, 8, 128, seed=96)  # n gh gw D
+    nchw = x.permute(0, 3, 1, 2)
+    assert torch.equal(ops.token_resample(dev(x), "avg2d").cpu(), F.avg_pool2d(nchw, 2).permute(0, 2, 3, 1))
+    assert torch.equal(ops.token_resample(dev(x), "max2d").cpu(), F.max_pool2d(nchw, 2).permute(0, 2, 3, 1))
+    up = F.interpolate(nchw, scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(ops.token_resample(dev(x), "up2d").cpu(), up)
+    for T in (1, 2, 4, 5):
+        v = rnd(2, T, 12, 64, seed=97 + T)  # B T S D
+        y = v.permute(0, 3, 1, 2).unsqueeze(-1)  # b d t s 1
+        want = y[:, :, :1]
+        if T > 1 and (T - 1) // 2 > 0:
+            want = torch.cat([want, F.avg_pool3d(y[:, :, 1:], (2, 1, 1))], dim=2)
+        got = ops.token_resample(dev(v), "avg_t").cpu()
+        assert torch.equal(got, want.squeeze(-1).permute(0, 2, 3, 1)), T
+        want = y[:, :, :1]
+        if T > 1:
+            want = torch.cat([want, F.interpolate(y[:, :, 1:], scale_factor=(2, 1, 1), mode="nearest")], dim=2)
+        got = ops.token_resample(dev(v), "up_t").cpu()
+        assert torch.equal(got, want.squeeze(-1).permute(0, 2, 3, 1)), T
+
+
+def test_patchify_raw_and_padded(ops):
+    v = rnd(2, 3, 5, 16, 16, seed=98)
+    raw = ops.patchify_ln(dev(v), 1, 2, 2, 4)  # no LayerNorm: the Conv3d(kernel == stride) im2col rows
+    assert torch.equal(raw.cpu(), orc.patchify(v[:, :, 1:], 4, 2).reshape(-1, 96))
+    g, b = rnd(48, seed=99) + 1.0, rnd(48, seed=100)
+    pad = ops.patchify_ln(dev(v), 0, 1, 1, 4, dev(g), dev(b), ldo=64)
+    want = F.layer_norm(orc.patchify(v[:, :, :1], 4, 1).reshape(-1, 48), (48,), g, b, 1e-5)
+    assert maxerr(pad[:, :48], want) < 1e-5 and (pad[:, 48:] == 0).all()
+
+
 def test_vae_sample_and_post_vq(ops):
     """--use_vae kernels against the oracle's DiagonalGaussianDistribution restatement."""
     c = GoldenCase("vae_s2_sdpa_r64_vid")

@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, GOLDEN, VAE_CASES
+from tests.helpers import GoldenCase, E2E_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -28,7 +28,7 @@ def test_vq_torch_oracle_matches_reference_kat(n_codes):
     assert np.array_equal(ids, g["ids"].astype(np.int64))
 
 
-@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"])
+@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"] + VARIANT_CASES)
 def test_oracle_end_to_end_matches_reference(name):
     c = GoldenCase(name)
     with torch.no_grad():
@@ -39,7 +39,7 @@ def test_oracle_end_to_end_matches_reference(name):
     assert (taps["z"] - c.z).abs().max().item() < 2e-6
     assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
     # flat ids decode identically (reference omnitokenizer.py:272-286)
-    if c.cfg.resolution // c.cfg.patch_size == c.ids.shape[-1]:
+    if c.is_image or c.cfg.resolution // c.cfg.patch_size == c.ids.shape[-1]:
         recon_flat = orc.decode(c.sd, c.ids.reshape(c.ids.shape[0], -1), c.is_image, c.cfg)
         assert torch.equal(recon_flat, recon)
 
