@@ -154,6 +154,9 @@ def main():
             if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
                 roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
                 roofline["traffic_source"] = pmc[dom]["source"]
+                if "mfma_busy_pct" in pmc[dom]:  # matrix-pipe busy cycles from the committed PMC pass
+                    roofline["mfma_busy_pct_pmc"] = pmc[dom]["mfma_busy_pct"]
+                    roofline["mfma_busy_source"] = pmc[dom]["mfma_source"]
                 alg_bytes = {"gemm_ff_in": (B * tokens_per_clip) * (512 + 1408) * 4 + 2816 * 512 * 4}.get(dom)
                 if alg_bytes:
                     roofline["algorithmic_bytes"] = alg_bytes
