@@ -43,7 +43,9 @@ const char *omnitok_last_error(void);
 /* "omnitok <version> gfx950 ..." */
 const char *omnitok_version(void);
 /* Tuning knobs for A/B measurements (process-global; not part of the functional contract):
- * "gemm_variant" (0|1), "gemm_lds_pad_kb". Unknown names return OMNITOK_ERR_INVALID. */
+ * "gemm_variant" (0 one tile per workgroup | 1 persistent 128x128 | 2 persistent 256x128, +4 forces it
+ * whatever the size), "gemm_small" (1: 64x128 tiles when the 128x128 tiling has fewer workgroups
+ * than CUs), "gemm_lds_pad_kb", "peg_variant". Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* Measurement only: pure v_mfma_f32_32x32x2_f32 stream (4 accumulators per wave, operands from
  * `in`[4096]) to find the sustained fp32-MFMA ceiling of the chip. out[blocks*256]. */

@@ -16,6 +16,7 @@ void set_error(const char *fmt, ...) {
 namespace omnitok {
 extern int g_gemm_variant;
 extern int g_gemm_lds_pad_kb;
+extern int g_gemm_small;
 extern long long *g_gemm_trace;
 extern int g_peg_variant;
 }  // namespace omnitok
@@ -24,6 +25,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     if (!name) return OMNITOK_ERR_INVALID;
     if (!strcmp(name, "gemm_variant")) omnitok::g_gemm_variant = value;
     else if (!strcmp(name, "gemm_lds_pad_kb")) omnitok::g_gemm_lds_pad_kb = value;
+    else if (!strcmp(name, "gemm_small")) omnitok::g_gemm_small = value;
     else if (!strcmp(name, "peg_variant")) omnitok::g_peg_variant = value;
     else {
         omnitok::set_error("set_option: unknown option %s", name);

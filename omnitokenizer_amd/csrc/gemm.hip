@@ -25,6 +25,7 @@ namespace omnitok {
 // 256x128 x 8 waves), +4 = force; "gemm_lds_pad_kb" extra dynamic LDS per workgroup (variants 0, 1).
 int g_gemm_variant = 1;
 int g_gemm_lds_pad_kb = 0;
+int g_gemm_small = 1;  // "gemm_small": 64x128 tiles when the 128x128 tiling cannot fill the chip
 long long *g_gemm_trace = nullptr;
 
 template <int FLAGS, bool NEDGE>
@@ -122,6 +123,122 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
     gemm_epilogue<FLAGS, NEDGE>(p, acc, bm, bn, wm, wn, r32, hi);
 }
 
+
+// Small-problem variant (launch-latency regime, e.g. one 256x256 image = 1024 tokens): when the
+// 128x128 tiling gives fewer workgroups than CUs, the time of a GEMM is the serial MFMA chain of one
+// wave.  64x128 tiles with 32x64 wave tiles halve that chain and double the workgroup count; the
+// GEGLU value/gate pairing (two adjacent 32-column blocks) still lives inside one wave.
+constexpr int SM_BM = 64;
+constexpr int SMALL_LDS_BYTES = 2 * (SM_BM + BN) * LDT * 4;
+
+template <int FLAGS>
+__global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = (SM_BM + BN) * LDT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int64_t bm = blockIdx.x / p.nbn;
+    const int bn = blockIdx.x % p.nbn;
+
+    const int lrow = tid >> 3, lc4 = tid & 7;
+    const float *ap[2];
+    const float *wp[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int64_t gr = bm * SM_BM + lrow + 32 * i;
+        if (gr > p.M - 1) gr = p.M - 1;
+        int64_t ar = gr;
+        if (p.a_rpg > 0) ar = (gr / p.a_rpg) * p.a_stride + p.a_off + (gr % p.a_rpg);
+        ap[i] = p.a + ar * p.lda + lc4 * 4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int wr = bn * BN + lrow + 32 * i;
+        if (wr > p.N - 1) wr = p.N - 1;
+        wp[i] = p.w + (int64_t)wr * p.ldw + lc4 * 4;
+    }
+    const int st_off = lrow * LDT + lc4 * 4;
+    f32x4 ra[2], rb[4];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
+    };
+    auto lstore = [&](int buf) {
+        float *As = smem + buf * STAGE;
+        float *Bs = As + SM_BM * LDT;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    const int nk = p.K / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int a_frag_off = (wm * 32 + r32) * LDT + hi * 16;
+    const int b_frag_off = (wn * 64 + r32) * LDT + hi * 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload((kt + 1) * BK);
+        const float *As = smem + buf * STAGE;
+        const float *Bs = As + SM_BM * LDT;
+        f32x4 af[4], bf[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            af[j] = *reinterpret_cast<const f32x4 *>(As + a_frag_off + 4 * j);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                bf[nb][j] = *reinterpret_cast<const f32x4 *>(Bs + b_frag_off + nb * 32 * LDT + 4 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bf[nb][j][e], acc[nb], 0, 0, 0);
+        if (kt + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int64_t row0 = bm * SM_BM + wm * 32;
+    if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
+        const int ocol = (bn * 2 + wn) * 32 + r32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row0 + mfma32_row(r, hi);
+            if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[1][r]) * acc[0][r];
+        }
+    } else {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int col = bn * BN + wn * 64 + nb * 32 + r32;
+            const bool colok = col < p.N;
+            float bv = 0.0f;
+            if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = colok ? p.bias[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = row0 + mfma32_row(r, hi);
+                if (row < p.M && colok) {
+                    float v = acc[nb][r];
+                    if constexpr (FLAGS & OMNITOK_GEMM_BIAS) v += bv;
+                    if constexpr (FLAGS & OMNITOK_GEMM_LEAKY) v = v > 0.0f ? v : 0.1f * v;
+                    if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) v += p.residual[row * p.ldr + col];
+                    p.c[row * p.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
 
 // Persistent variant: workgroups walk the tile list (tile = blockIdx.x + i * gridDim.x, then
 // XCD-remapped); the global->register->LDS pipeline runs ACROSS tile boundaries, so per tile there
@@ -372,6 +489,19 @@ static int launch_gemm(GemmParams p, hipStream_t stream) {
     if (variant == 1 && !force && (FLAGS & OMNITOK_GEMM_GEGLU)) variant = 2;
     if (variant == 2) return launch_persistent<FLAGS, 4>(p, n_cu, stream);
     if (variant == 1) return launch_persistent<FLAGS, 2>(p, n_cu, stream);
+    if (nwg < n_cu && g_gemm_small && !force) {
+        // fewer 128x128 tiles than CUs: 64x128 tiles, 32x64 per wave (half the serial MFMA chain)
+        static int small_attr = 0;
+        if (!small_attr) {
+            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_small<FLAGS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
+            small_attr = 1;
+        }
+        const int64_t nwg_s = ((p.M + SM_BM - 1) / SM_BM) * p.nbn;
+        hipLaunchKernelGGL((gemm_f32_mfma_small<FLAGS>), dim3((unsigned)nwg_s), dim3(256), SMALL_LDS_BYTES, stream, p);
+        OT_LAUNCH_CHECK("gemm_f32_mfma_small");
+        return OMNITOK_OK;
+    }
     const int lds = GEMM_LDS_BYTES + g_gemm_lds_pad_kb * 1024;
     const bool nedge = (p.N % 64) != 0;
     if (attr_bytes < lds) {

@@ -315,3 +315,33 @@ def test_vae_full_size_round_trip(models):
         rec_ref = orc.decode_vae(c.sd, z[:1].permute(0, 2, 3, 4, 1).cpu(), False, c.cfg)
     assert (z[:1].cpu() - z_ref).abs().max().item() < VAE_Z_TOL
     assert (rec[:1].cpu() - rec_ref).abs().max().item() < PIXEL_TOL
+
+
+def test_hip_graph_capture_and_side_stream(models):
+    """The engine launches everything on the caller's stream with no hidden synchronisation once
+    its caches are warm, so encode+decode can be captured into one HIP graph (the launch-bound
+    small-batch case) and can run on a non-default stream."""
+    c = GoldenCase("s2_sdpa_r64_vid")
+    m = models(c)
+    x = c.x.cuda()
+    ids0 = m.encode(x, False)
+    rec0 = m.decode(ids0, False)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ids_s = m.encode(x, False)
+        rec_s = m.decode(ids_s, False)
+    torch.cuda.current_stream().wait_stream(s)
+    assert torch.equal(ids_s, ids0) and torch.equal(rec_s, rec0)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        ids_g = m.encode(x, False)
+        rec_g = m.decode(ids_g, False)
+    x2 = torch.roll(x, 1, dims=0).contiguous()
+    ids2 = m.encode(x2, False)
+    rec2 = m.decode(ids2, False)
+    x.copy_(x2)  # new input in the captured buffer
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ids_g, ids2) and torch.equal(rec_g, rec2)
+    assert torch.equal(ids2.cpu(), torch.roll(c.ids, 1, dims=0))

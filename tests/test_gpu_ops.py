@@ -24,9 +24,10 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=[4, 5, 6], ids=["tile_per_wg", "persistent_128x128", "persistent_256x128"])
+@pytest.fixture(params=[0, 4, 5, 6], ids=["auto_small_tiles", "tile_per_wg", "persistent_128x128", "persistent_256x128"])
 def gemm_variant(request):
-    """Runs a test once per GEMM kernel variant (forced whatever the problem size)."""
+    """Runs a test once per GEMM kernel variant (4-6: forced whatever the problem size; 0: the
+    size-based choice between the 64x128 small-problem kernel and one 128x128 tile per workgroup)."""
     from omnitokenizer_amd import _lib
     _lib.set_option("gemm_variant", request.param)
     yield request.param
