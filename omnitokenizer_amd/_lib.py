@@ -26,6 +26,11 @@ class OmnitokConfig(Structure):
     ]
 
 
+class OmnitokLmConfig(Structure):
+    _fields_ = [("vocab_size", c_int), ("block_size", c_int), ("n_layer", c_int), ("n_head", c_int),
+                ("n_embd", c_int)]
+
+
 class OmnitokError(RuntimeError):
     pass
 
@@ -74,6 +79,16 @@ _PROTOS = {
     "omnitok_engine_workspace_bytes": [P],
     "omnitok_engine_set_timing": [P, c_int],
     "omnitok_engine_timing_report": [P, c_char_p, c_int],
+    # include/omnitok_lm.h
+    "omnitok_lm_create": [POINTER(OmnitokLmConfig), POINTER(P)],
+    "omnitok_lm_destroy": [P],
+    "omnitok_lm_set_weight": [P, c_char_p, P, POINTER(I64), c_int, P],
+    "omnitok_lm_finalize": [P, P],
+    "omnitok_lm_alloc_cache": [P, c_int, c_int],
+    "omnitok_lm_cache_bytes": [P],
+    "omnitok_lm_step": [P, P, P, P, c_int, P, c_int, P],
+    "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
+    "omnitok_lm_attn_decode": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
     "omnitok_set_option": [c_char_p, c_int],
     "omnitok_debug_set_gemm_trace": [P],
     "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
@@ -81,7 +96,8 @@ _PROTOS = {
     "omnitok_version": [],
 }
 _RESTYPES = {"omnitok_last_error": c_char_p, "omnitok_version": c_char_p,
-             "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64}
+             "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64,
+             "omnitok_lm_destroy": None, "omnitok_lm_cache_bytes": c_int64}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

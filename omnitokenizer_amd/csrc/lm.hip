@@ -1,0 +1,607 @@
+// LM consumer of the token path: KV-cached decode step of the reference's minGPT
+// (OmniTokenizer/modules/gpt.py:74-275) for sample_with_past (gpt.py:327-359).
+//
+// One token per stream per step, so every matrix product is a GEMV over fp32 weights: the step is
+// HBM-bound (24 layers x 12 C^2 x 4 B = 2.7 GB of weights at C = 1536, plus the K/V cache), not
+// MFMA-bound.  Kernels:
+//   lm_embed_kernel        x = tok_emb[idx] + pos_emb[pos]
+//   lm_gemv_kernel         y = act(LN(x) W^T + b) (+ residual): one wave streams ROWS weight rows with
+//                          16-byte loads (each row read exactly once for up to 8 batch rows), LayerNorm
+//                          of the (tiny, L2-resident) activations fused into the prologue, bias / exact
+//                          GELU / residual fused into the epilogue
+//   lm_attn_decode_kernel  flash-decode over the K/V cache: 256-key chunks per workgroup, 8 lanes per
+//                          key (coalesced 128-byte row segments), online softmax, partial (m, l, o)
+//   lm_attn_merge_kernel   merges the chunk partials
+//   lm_advance_kernel      cache_len++, pos++ on the device
+// Shapes and launch grids do not depend on the position (chunks beyond the cache length exit at
+// once), so a step can be captured once in a HIP graph and replayed for every token.
+#include "common.h"
+#include "gemm_common.h"  // gelu_erf
+#include "../../include/omnitok_lm.h"
+
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstring>
+
+namespace omnitok {
+
+constexpr int LM_CHUNK = 256;   // keys per attention workgroup
+constexpr int LM_MAX_BQ = 8;    // batch rows sharing one pass over a weight matrix
+
+__global__ __launch_bounds__(256) void lm_embed_kernel(const int64_t *__restrict__ idx, const int32_t *__restrict__ pos,
+                                                       const float *__restrict__ tok, const float *__restrict__ pe,
+                                                       float *__restrict__ x, int C, int vocab, int block_size) {
+    const int b = blockIdx.x;
+    int64_t id = idx[b];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    int p = pos[b];
+    p = p < 0 ? 0 : (p >= block_size ? block_size - 1 : p);
+    for (int i = threadIdx.x * 4; i < C; i += 256 * 4) {
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(tok + id * C + i);
+        const f32x4 c = *reinterpret_cast<const f32x4 *>(pe + (int64_t)p * C + i);
+        *reinterpret_cast<f32x4 *>(x + (int64_t)b * C + i) = a + c;
+    }
+}
+
+template <int BQ, int ROWS, int ACT, bool LN>
+__global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                      const float *__restrict__ bias, const float *residual,
+                                                      const float *__restrict__ g, const float *__restrict__ beta,
+                                                      float *y, int N, int K) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * ROWS;
+    if (row0 >= N) return;
+    float mean[BQ], rstd[BQ];
+    if (LN) {
+        // nn.LayerNorm statistics of each activation row (two-pass, like ATen): the rows are a few KB
+        // and L2-resident, every wave recomputes them instead of a separate launch
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            float s = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            mean[b] = wave_allsum(s) / (float)K;
+            float q = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
+                const float a0 = v[0] - mean[b], a1 = v[1] - mean[b], a2 = v[2] - mean[b], a3 = v[3] - mean[b];
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            rstd[b] = 1.0f / sqrtf(wave_allsum(q) / (float)K + 1e-5f);
+        }
+    }
+    const float *wr[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) wr[r] = w + (int64_t)(row0 + r < N ? row0 + r : N - 1) * K + lane * 4;
+    float acc[ROWS][BQ];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) acc[r][b] = 0.0f;
+    for (int k0 = 0; k0 < K; k0 += 256) {
+        f32x4 wv[ROWS];
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wr[r] + k0));
+        f32x4 g4, b4;
+        if (LN) {
+            g4 = *reinterpret_cast<const f32x4 *>(g + k0 + lane * 4);
+            b4 = *reinterpret_cast<const f32x4 *>(beta + k0 + lane * 4);
+        }
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            f32x4 xv = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k0 + lane * 4);
+            if (LN) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mean[b]) * rstd[b] * g4[e] + b4[e];
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r) {
+                acc[r][b] = fmaf(wv[r][0], xv[0], acc[r][b]);
+                acc[r][b] = fmaf(wv[r][1], xv[1], acc[r][b]);
+                acc[r][b] = fmaf(wv[r][2], xv[2], acc[r][b]);
+                acc[r][b] = fmaf(wv[r][3], xv[3], acc[r][b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) acc[r][b] = wave_allsum(acc[r][b]);
+    // lane (r * BQ + b) finishes and stores output (b, row0 + r)
+    float mine = 0.0f;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+        for (int b = 0; b < BQ; ++b)
+            if (lane == r * BQ + b) mine = acc[r][b];
+    if (lane < ROWS * BQ) {
+        const int r = lane / BQ, b = lane % BQ, n = row0 + r;
+        if (n < N) {
+            float v = mine;
+            if (bias) v += bias[n];
+            if (ACT == 1) v = gelu_erf(v);
+            if (residual) v += residual[(int64_t)b * N + n];
+            y[(int64_t)b * N + n] = v;
+        }
+    }
+}
+
+// F4 = head_dim / 32 float4 per lane: 8 lanes cover one K/V row of head_dim floats
+template <int F4>
+__global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
+                                                             const int32_t *__restrict__ cache_len, int n_head,
+                                                             int max_len, int max_batch_stride /*unused*/,
+                                                             float *__restrict__ part, int nchunk) {
+    constexpr int HD = F4 * 32;
+    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int len = cache_len[b];        // entries already in the cache; the new token goes to index len
+    const int total = len + 1;
+    if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
+    const int C = n_head * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane >> 3, ds = lane & 7;  // key slot 0..7, dim slot 0..7
+    const float *qn = qkv + (int64_t)b * 3 * C + h * HD;
+    const float *kn = qn + C, *vn = qn + 2 * C;
+    float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
+    float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
+    // append the new token's K/V (only the workgroup whose chunk holds index len)
+    if (len >= c * LM_CHUNK && len < (c + 1) * LM_CHUNK && len < max_len) {
+        for (int d = tid; d < HD; d += 256) {
+            krow[(int64_t)len * HD + d] = kn[d];
+            vrow[(int64_t)len * HD + d] = vn[d];
+        }
+    }
+    f32x4 q[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(qn + (ds + 8 * i) * 4);
+    const float scale = 1.0f / sqrtf((float)HD);
+    float m = -INFINITY, l = 0.0f;
+    f32x4 o[F4];
+#pragma unroll
+    for (int i = 0; i < F4; ++i) o[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    const int kbase = c * LM_CHUNK + wave * 64;
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int key = kbase + it * 8 + slot;
+        const bool valid = key < total;
+        // the new token's row is read from qkv (its cache copy is being written by this kernel)
+        const float *kp = key == len ? kn : krow + (int64_t)(valid ? key : 0) * HD;
+        const float *vp = key == len ? vn : vrow + (int64_t)(valid ? key : 0) * HD;
+        float s = 0.0f;
+        f32x4 vv[F4];
+#pragma unroll
+        for (int i = 0; i < F4; ++i) {
+            const f32x4 kv = *reinterpret_cast<const f32x4 *>(kp + (ds + 8 * i) * 4);
+            vv[i] = *reinterpret_cast<const f32x4 *>(vp + (ds + 8 * i) * 4);
+            s = fmaf(q[i][0], kv[0], s);
+            s = fmaf(q[i][1], kv[1], s);
+            s = fmaf(q[i][2], kv[2], s);
+            s = fmaf(q[i][3], kv[3], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s = valid ? s * scale : -INFINITY;
+        const float mn = fmaxf(m, s);
+        if (mn > -INFINITY) {
+            const float corr = expf(m - mn), p = expf(s - mn);
+            l = l * corr + p;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) o[i] = o[i] * corr + vv[i] * p;
+            m = mn;
+        }
+    }
+    // merge the 8 key slots of the wave (lanes with equal dim slot: xor 8, 16, 32)
+    float ma = m;
+    ma = fmaxf(ma, __shfl_xor(ma, 8));
+    ma = fmaxf(ma, __shfl_xor(ma, 16));
+    ma = fmaxf(ma, __shfl_xor(ma, 32));
+    const float sc = ma > -INFINITY ? expf(m - ma) : 0.0f;
+    l *= sc;
+#pragma unroll
+    for (int i = 0; i < F4; ++i) o[i] = o[i] * sc;
+#pragma unroll
+    for (int sh = 8; sh <= 32; sh <<= 1) {
+        l += __shfl_xor(l, sh);
+#pragma unroll
+        for (int i = 0; i < F4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[i][e] += __shfl_xor(o[i][e], sh);
+    }
+    // merge the 4 waves through LDS
+    __shared__ float s_m[4], s_l[4];
+    __shared__ __attribute__((aligned(16))) float s_o[4][HD];
+    if (lane < 8) {
+#pragma unroll
+        for (int i = 0; i < F4; ++i) *reinterpret_cast<f32x4 *>(&s_o[wave][(lane + 8 * i) * 4]) = o[i];
+        if (lane == 0) {
+            s_m[wave] = ma;
+            s_l[wave] = l;
+        }
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float L = 0.0f, O = 0.0f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            const float f = s_m[wv] > -INFINITY ? expf(s_m[wv] - M) : 0.0f;
+            L += s_l[wv] * f;
+            O += s_o[wv][tid] * f;
+        }
+        float *pp = part + (((int64_t)b * n_head + h) * nchunk + c) * (2 + HD);
+        pp[2 + tid] = O;
+        if (tid == 0) {
+            pp[0] = M;
+            pp[1] = L;
+        }
+    }
+}
+
+__global__ void lm_attn_merge_kernel(const float *__restrict__ part, const int32_t *__restrict__ cache_len, int n_head,
+                                     int HD, int nchunk, float *__restrict__ out) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    if (d >= HD) return;
+    const int total = cache_len[b] + 1;
+    const int used = (total + LM_CHUNK - 1) / LM_CHUNK;
+    const float *pp = part + ((int64_t)b * n_head + h) * nchunk * (2 + HD);
+    float M = -INFINITY;
+    for (int c = 0; c < used; ++c) M = fmaxf(M, pp[c * (2 + HD)]);
+    float L = 0.0f, O = 0.0f;
+    for (int c = 0; c < used; ++c) {
+        const float f = expf(pp[c * (2 + HD)] - M);
+        L += pp[c * (2 + HD) + 1] * f;
+        O += pp[c * (2 + HD) + 2 + d] * f;
+    }
+    out[((int64_t)b * n_head + h) * HD + d] = O / L;
+}
+
+__global__ void lm_advance_kernel(int32_t *pos, int32_t *cache_len, int B) {
+    const int b = threadIdx.x;
+    if (b < B) {
+        pos[b] += 1;
+        cache_len[b] += 1;
+    }
+}
+
+// rows of a (key | query | value) trio concatenated as (query | key | value) [3C, C] / [3C]
+__global__ void lm_concat3_kernel(const float *a, const float *b, const float *c, int64_t n, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    out[i] = i < n ? a[i] : (i < 2 * n ? b[i - n] : c[i - 2 * n]);
+}
+
+template <int BQ, int ACT, bool LN>
+static void launch_gemv_rows(const float *x, const float *w, const float *bias, const float *residual, const float *g,
+                             const float *beta, float *y, int N, int K, hipStream_t stream) {
+    // 4 rows per wave once there are enough rows to fill the chip, 2 otherwise (more waves in flight)
+    if (N >= 4096 && BQ <= 4) {
+        const int rows_per_wg = 16;
+        hipLaunchKernelGGL((lm_gemv_kernel<BQ, 4, ACT, LN>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256), 0,
+                           stream, x, w, bias, residual, g, beta, y, N, K);
+    } else {
+        const int rows_per_wg = 8;
+        hipLaunchKernelGGL((lm_gemv_kernel<BQ, 2, ACT, LN>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256), 0,
+                           stream, x, w, bias, residual, g, beta, y, N, K);
+    }
+}
+
+template <int BQ>
+static void launch_gemv_bq(const float *x, const float *w, const float *bias, const float *residual, const float *g,
+                           const float *beta, float *y, int N, int K, int act, hipStream_t stream) {
+    if (g) {
+        if (act) launch_gemv_rows<BQ, 1, true>(x, w, bias, residual, g, beta, y, N, K, stream);
+        else launch_gemv_rows<BQ, 0, true>(x, w, bias, residual, g, beta, y, N, K, stream);
+    } else {
+        if (act) launch_gemv_rows<BQ, 1, false>(x, w, bias, residual, g, beta, y, N, K, stream);
+        else launch_gemv_rows<BQ, 0, false>(x, w, bias, residual, g, beta, y, N, K, stream);
+    }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+extern "C" int omnitok_lm_gemv(const float *x, const float *w, const float *bias, const float *residual,
+                               const float *ln_gamma, const float *ln_beta, float *y, int B, int N, int K, int act,
+                               omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(x && w && y, "lm_gemv: null pointer");
+    OT_CHECK_ARG(B > 0 && B <= 16 && N > 0 && K > 0 && K % 256 == 0, "lm_gemv: bad sizes B=%d N=%d K=%d", B, N, K);
+    OT_CHECK_ARG((ln_gamma != nullptr) == (ln_beta != nullptr), "lm_gemv: ln_gamma / ln_beta must come together");
+    OT_CHECK_ARG(act == 0 || act == 1, "lm_gemv: act %d", act);
+    OT_CHECK_ARG(aligned16(x) && aligned16(w), "lm_gemv: unaligned");
+    // batch rows in groups of up to 8 per pass over the weights
+    for (int b0 = 0; b0 < B;) {
+        const int left = B - b0;
+        const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
+        const float *xb = x + (int64_t)b0 * K, *rb = residual ? residual + (int64_t)b0 * N : nullptr;
+        float *yb = y + (int64_t)b0 * N;
+        switch (bq) {
+            case 8: launch_gemv_bq<8>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
+            case 4: launch_gemv_bq<4>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
+            case 2: launch_gemv_bq<2>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
+            default: launch_gemv_bq<1>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
+        }
+        OT_LAUNCH_CHECK("lm_gemv");
+        b0 += bq;
+    }
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B,
+                                      int n_head, int head_dim, int max_len, float *scratch, float *out,
+                                      omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(qkv && kc && vc && cache_len && scratch && out, "lm_attn_decode: null pointer");
+    OT_CHECK_ARG(head_dim == 64 || head_dim == 96 || head_dim == 128, "lm_attn_decode: head_dim %d (64 | 96 | 128)",
+                 head_dim);
+    OT_CHECK_ARG(max_len > 0 && n_head > 0, "lm_attn_decode: bad sizes");
+    const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
+    const dim3 grid(nchunk, n_head, B);
+    switch (head_dim) {
+        case 64:
+            hipLaunchKernelGGL(lm_attn_decode_kernel<2>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
+                               max_len, 0, scratch, nchunk);
+            break;
+        case 96:
+            hipLaunchKernelGGL(lm_attn_decode_kernel<3>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
+                               max_len, 0, scratch, nchunk);
+            break;
+        default:
+            hipLaunchKernelGGL(lm_attn_decode_kernel<4>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
+                               max_len, 0, scratch, nchunk);
+            break;
+    }
+    OT_LAUNCH_CHECK("lm_attn_decode");
+    hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(n_head, B), dim3(128), 0, stream, scratch, cache_len, n_head, head_dim,
+                       nchunk, out);
+    OT_LAUNCH_CHECK("lm_attn_merge");
+    return OMNITOK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------
+struct LmLayer {
+    const float *ln1w, *ln1b, *ln2w, *ln2b;
+    float *wqkv, *bqkv;  // (query | key | value) concatenated at finalize
+    const float *wproj, *bproj, *w1, *b1, *w2, *b2;
+};
+
+struct omnitok_lm {
+    omnitok_lm_config cfg;
+    std::map<std::string, std::vector<int64_t>> spec;
+    std::map<std::string, float *> w;
+    std::vector<void *> owned;
+    std::vector<LmLayer> layers;
+    bool finalized = false;
+    // cache + workspaces
+    float *kv = nullptr;
+    int max_batch = 0, max_len = 0;
+    float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *part = nullptr;
+    int64_t cache_bytes = 0;
+};
+
+static const float *LW(omnitok_lm *lm, const std::string &k) {
+    auto it = lm->w.find(k);
+    return it == lm->w.end() ? nullptr : it->second;
+}
+
+extern "C" int omnitok_lm_create(const omnitok_lm_config *cfg, omnitok_lm **out) {
+    OT_CHECK_ARG(cfg && out, "lm_create: null pointer");
+    const omnitok_lm_config &c = *cfg;
+    OT_CHECK_ARG(c.n_layer > 0 && c.n_head > 0 && c.n_embd > 0 && c.vocab_size > 0 && c.block_size > 0,
+                 "lm_create: bad config");
+    const int hd = c.n_embd / c.n_head;
+    if (c.n_embd % c.n_head || (hd != 64 && hd != 96 && hd != 128) || c.n_embd % 256) {
+        set_error("lm_create: n_embd %d / n_head %d: head_dim must be 64, 96 or 128 and n_embd %% 256 == 0", c.n_embd,
+                  c.n_head);
+        return OMNITOK_ERR_UNSUPPORTED;
+    }
+    omnitok_lm *lm = new omnitok_lm();
+    lm->cfg = c;
+    const int64_t C = c.n_embd, V = c.vocab_size;
+    lm->spec["pos_emb"] = {1, c.block_size, C};
+    lm->spec["tok_emb.weight"] = {V, C};
+    for (int i = 0; i < c.n_layer; ++i) {
+        const std::string p = "blocks." + std::to_string(i);
+        for (const char *n : {".ln1", ".ln2"}) {
+            lm->spec[p + n + ".weight"] = {C};
+            lm->spec[p + n + ".bias"] = {C};
+        }
+        for (const char *n : {".attn.key", ".attn.query", ".attn.value", ".attn.proj"}) {
+            lm->spec[p + n + ".weight"] = {C, C};
+            lm->spec[p + n + ".bias"] = {C};
+        }
+        lm->spec[p + ".mlp.0.weight"] = {4 * C, C};
+        lm->spec[p + ".mlp.0.bias"] = {4 * C};
+        lm->spec[p + ".mlp.2.weight"] = {C, 4 * C};
+        lm->spec[p + ".mlp.2.bias"] = {C};
+    }
+    lm->spec["ln_f.weight"] = {C};
+    lm->spec["ln_f.bias"] = {C};
+    lm->spec["head.weight"] = {V, C};
+    *out = lm;
+    return OMNITOK_OK;
+}
+
+static void lm_free_cache(omnitok_lm *lm) {
+    for (float **p : {&lm->kv, &lm->x, &lm->qkv, &lm->att, &lm->hid, &lm->part})
+        if (*p) {
+            (void)hipFree(*p);
+            *p = nullptr;
+        }
+}
+
+extern "C" void omnitok_lm_destroy(omnitok_lm *lm) {
+    if (!lm) return;
+    for (auto &kv : lm->w)
+        if (kv.second) (void)hipFree(kv.second);
+    for (void *p : lm->owned) (void)hipFree(p);
+    lm_free_cache(lm);
+    delete lm;
+}
+
+extern "C" int omnitok_lm_set_weight(omnitok_lm *lm, const char *name, const void *dev_ptr, const int64_t *shape,
+                                     int ndim, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(lm && name && dev_ptr && shape, "lm_set_weight: null pointer");
+    auto it = lm->spec.find(name);
+    if (it == lm->spec.end()) return 1;
+    std::vector<int64_t> shp(shape, shape + ndim);
+    if (shp != it->second) {
+        std::string want, got;
+        for (auto s : it->second) want += std::to_string(s) + ",";
+        for (auto s : shp) got += std::to_string(s) + ",";
+        set_error("lm_set_weight: size mismatch for %s: expected [%s] got [%s]", name, want.c_str(), got.c_str());
+        return OMNITOK_ERR_INVALID;
+    }
+    int64_t n = 1;
+    for (auto s : shp) n *= s;
+    float *&p = lm->w[name];
+    if (!p) OT_HIP(hipMalloc(reinterpret_cast<void **>(&p), (size_t)n * 4));
+    OT_HIP(hipMemcpyAsync(p, dev_ptr, (size_t)n * 4, hipMemcpyDeviceToDevice, stream));
+    lm->finalized = false;
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_finalize(omnitok_lm *lm, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(lm, "lm_finalize: null");
+    for (auto &kv : lm->spec)
+        if (!lm->w.count(kv.first)) {
+            set_error("lm_finalize: missing weight %s", kv.first.c_str());
+            return OMNITOK_ERR_STATE;
+        }
+    for (auto &kv : lm->w)
+        if (!kv.second) {  // q/k/v were folded into wqkv by an earlier finalize and released
+            set_error("lm_finalize: %s was released by a previous finalize; set all weights again", kv.first.c_str());
+            return OMNITOK_ERR_STATE;
+        }
+    OT_HIP(hipStreamSynchronize(stream));
+    for (void *p : lm->owned) (void)hipFree(p);
+    lm->owned.clear();
+    lm->layers.clear();
+    const int64_t C = lm->cfg.n_embd;
+    for (int i = 0; i < lm->cfg.n_layer; ++i) {
+        const std::string p = "blocks." + std::to_string(i);
+        LmLayer L;
+        L.ln1w = LW(lm, p + ".ln1.weight");
+        L.ln1b = LW(lm, p + ".ln1.bias");
+        L.ln2w = LW(lm, p + ".ln2.weight");
+        L.ln2b = LW(lm, p + ".ln2.bias");
+        void *wq = nullptr, *bq = nullptr;
+        OT_HIP(hipMalloc(&wq, (size_t)3 * C * C * 4));
+        OT_HIP(hipMalloc(&bq, (size_t)3 * C * 4));
+        lm->owned.push_back(wq);
+        lm->owned.push_back(bq);
+        L.wqkv = static_cast<float *>(wq);
+        L.bqkv = static_cast<float *>(bq);
+        hipLaunchKernelGGL(lm_concat3_kernel, dim3((unsigned)((3 * C * C + 255) / 256)), dim3(256), 0, stream,
+                           LW(lm, p + ".attn.query.weight"), LW(lm, p + ".attn.key.weight"),
+                           LW(lm, p + ".attn.value.weight"), C * C, L.wqkv);
+        hipLaunchKernelGGL(lm_concat3_kernel, dim3((unsigned)((3 * C + 255) / 256)), dim3(256), 0, stream,
+                           LW(lm, p + ".attn.query.bias"), LW(lm, p + ".attn.key.bias"), LW(lm, p + ".attn.value.bias"),
+                           C, L.bqkv);
+        OT_LAUNCH_CHECK("lm_concat3");
+        L.wproj = LW(lm, p + ".attn.proj.weight");
+        L.bproj = LW(lm, p + ".attn.proj.bias");
+        L.w1 = LW(lm, p + ".mlp.0.weight");
+        L.b1 = LW(lm, p + ".mlp.0.bias");
+        L.w2 = LW(lm, p + ".mlp.2.weight");
+        L.b2 = LW(lm, p + ".mlp.2.bias");
+        lm->layers.push_back(L);
+    }
+    // the separate q/k/v copies are no longer needed: free them (2.7 GB model -> no duplicate)
+    OT_HIP(hipStreamSynchronize(stream));
+    for (int i = 0; i < lm->cfg.n_layer; ++i)
+        for (const char *n : {".attn.key", ".attn.query", ".attn.value"})
+            for (const char *s : {".weight", ".bias"}) {
+                const std::string k = "blocks." + std::to_string(i) + n + s;
+                // keep the map entry (finalize checks presence) but release the memory
+                if (lm->w[k]) {
+                    (void)hipFree(lm->w[k]);
+                    lm->w[k] = nullptr;
+                }
+            }
+    lm->finalized = true;
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_alloc_cache(omnitok_lm *lm, int max_batch, int max_len) {
+    OT_CHECK_ARG(lm && max_batch > 0 && max_batch <= 16 && max_len > 0, "lm_alloc_cache: bad sizes (max_batch <= 16)");
+    lm_free_cache(lm);
+    const omnitok_lm_config &c = lm->cfg;
+    const int64_t C = c.n_embd;
+    const int hd = c.n_embd / c.n_head;
+    const int64_t per_layer = (int64_t)max_batch * c.n_head * max_len * hd;  // floats per K (or V)
+    const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
+    auto alloc = [](float **p, int64_t n) { return hipMalloc(reinterpret_cast<void **>(p), (size_t)n * 4); };
+    OT_HIP(alloc(&lm->kv, per_layer * 2 * c.n_layer));
+    OT_HIP(alloc(&lm->x, max_batch * C));
+    OT_HIP(alloc(&lm->qkv, max_batch * 3 * C));
+    OT_HIP(alloc(&lm->att, max_batch * C));
+    OT_HIP(alloc(&lm->hid, max_batch * 4 * C));
+    OT_HIP(alloc(&lm->part, (int64_t)max_batch * c.n_head * nchunk * (2 + hd)));
+    lm->max_batch = max_batch;
+    lm->max_len = max_len;
+    lm->cache_bytes = per_layer * 2 * c.n_layer * 4;
+    return OMNITOK_OK;
+}
+
+extern "C" int64_t omnitok_lm_cache_bytes(omnitok_lm *lm) { return lm ? lm->cache_bytes : 0; }
+
+extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
+                               float *logits_out, int advance, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(lm, "lm_step: null engine");
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(idx && pos && cache_len, "lm_step: null pointer");
+    if (!lm->finalized) {
+        set_error("lm_step: engine not finalised (load the weights first)");
+        return OMNITOK_ERR_STATE;
+    }
+    if (!lm->kv || B > lm->max_batch) {
+        set_error("lm_step: cache not allocated for batch %d (omnitok_lm_alloc_cache)", B);
+        return OMNITOK_ERR_STATE;
+    }
+    const omnitok_lm_config &c = lm->cfg;
+    const int C = c.n_embd, hd = C / c.n_head;
+    const int64_t per_layer = (int64_t)lm->max_batch * c.n_head * lm->max_len * hd;
+    hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, stream, idx, pos, LW(lm, "tok_emb.weight"),
+                       LW(lm, "pos_emb"), lm->x, C, c.vocab_size, c.block_size);
+    OT_LAUNCH_CHECK("lm_embed");
+    for (int i = 0; i < c.n_layer; ++i) {
+        const LmLayer &L = lm->layers[i];
+        float *kc = lm->kv + (int64_t)(2 * i) * per_layer, *vc = kc + per_layer;
+        // x + proj(attn(ln1(x)))   (reference gpt.py:159-161)
+        if (int rc = omnitok_lm_gemv(lm->x, L.wqkv, L.bqkv, nullptr, L.ln1w, L.ln1b, lm->qkv, B, 3 * C, C, 0, stream))
+            return rc;
+        if (int rc = omnitok_lm_attn_decode(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, lm->att,
+                                            stream))
+            return rc;
+        if (int rc = omnitok_lm_gemv(lm->att, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, stream))
+            return rc;
+        // x + mlp(ln2(x))          (reference gpt.py:162, 150-155)
+        if (int rc = omnitok_lm_gemv(lm->x, L.w1, L.b1, nullptr, L.ln2w, L.ln2b, lm->hid, B, 4 * C, C, 1, stream))
+            return rc;
+        if (int rc = omnitok_lm_gemv(lm->hid, L.w2, L.b2, lm->x, nullptr, nullptr, lm->x, B, C, 4 * C, 0, stream))
+            return rc;
+    }
+    if (logits_out)  // ln_f + head (no bias), reference gpt.py:263-264
+        if (int rc = omnitok_lm_gemv(lm->x, LW(lm, "head.weight"), nullptr, nullptr, LW(lm, "ln_f.weight"),
+                                     LW(lm, "ln_f.bias"), logits_out, B, c.vocab_size, C, 0, stream))
+            return rc;
+    if (advance) {
+        hipLaunchKernelGGL(lm_advance_kernel, dim3(1), dim3(64), 0, stream, pos, cache_len, B);
+        OT_LAUNCH_CHECK("lm_advance");
+    }
+    return OMNITOK_OK;
+}

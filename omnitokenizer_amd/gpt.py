@@ -1,0 +1,365 @@
+"""Drop-in for the reference's `GPT` (OmniTokenizer/modules/gpt.py:170-275) on the KV-cached
+sampling path, plus its sampling loops `sample_with_past` (:327-359) and `sample_with_past_cfg`
+(:387-444) -- the LM consumer downstream of `OmniTokenizer_VQGAN.encode()` and upstream of
+`decode()` (lm_transformer.py:262,434).
+
+The class owns the parameters under the reference's state_dict key names; all arithmetic of a decode
+step runs in libomnitok.so (include/omnitok_lm.h, csrc/lm.hip): a preallocated K/V cache instead of
+the reference's per-step torch.cat of all pasts, GEMV kernels that stream each fp32 weight matrix
+once per step, flash-decode attention, and -- because the step's launch sequence does not depend on
+the position -- one captured HIP graph replayed per token.  Token selection (temperature, top-k /
+top-p filtering, multinomial) is the reference's own few torch ops on the GPU logits.
+Inference only; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import OmnitokLmConfig, check
+
+
+def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("Inf"), min_tokens_to_keep=1):
+    """reference gpt.py:19-51, same semantics (filters in place and returns logits)."""
+    if top_k > 0:
+        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
+        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = filter_value
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
+        cumulative_probs = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
+        remove = cumulative_probs > top_p
+        if min_tokens_to_keep > 1:
+            remove[..., :min_tokens_to_keep] = 0
+        remove[..., 1:] = remove[..., :-1].clone()
+        remove[..., 0] = 0
+        logits[remove.scatter(1, sorted_indices, remove)] = filter_value
+    return logits
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container; call GPT.forward / forward_with_past")
+
+
+class _PastHandle:
+    """What forward_with_past returns in place of the reference's stacked K/V tensor: the K/V live
+    in the engine's cache; the handle only identifies the stream so that the reference's calling
+    pattern (`past.append(present)`, gpt.py:343-346) keeps working."""
+
+    def __init__(self, model, length):
+        self.model, self.length = model, length
+
+
+class GPT(nn.Module):
+    def __init__(self, args, vocab_size, block_size, n_layer=12, n_head=8, n_embd=256, embd_pdrop=0.,
+                 resid_pdrop=0., attn_pdrop=0., n_unmasked=0, vtokens_pos=False):
+        """Same signature as the reference (gpt.py:172).  Dropouts are inference no-ops;
+        n_unmasked / vtokens_pos (unused by the released scripts) are not built."""
+        super().__init__()
+        if n_unmasked or vtokens_pos:
+            raise NotImplementedError("n_unmasked / vtokens_pos are not built (no released config uses them)")
+        self.block_size = block_size
+        self.vocab_size, self.n_layer, self.n_head, self.n_embd = vocab_size, n_layer, n_head, n_embd
+
+        class _Cfg:
+            pass
+        self.config = _Cfg()
+        self.config.vocab_size, self.config.block_size = vocab_size, block_size
+        self.config.n_layer, self.config.n_head, self.config.n_embd = n_layer, n_head, n_embd
+        C = n_embd
+        self.pos_emb = nn.Parameter(torch.zeros(1, block_size, C), requires_grad=False)
+
+        def lin(o, i, bias=True):
+            m = _Holder()
+            m.weight = nn.Parameter(torch.zeros(o, i), requires_grad=False)
+            if bias:
+                m.bias = nn.Parameter(torch.zeros(o), requires_grad=False)
+            return m
+
+        def ln():
+            m = _Holder()
+            m.weight = nn.Parameter(torch.ones(C), requires_grad=False)
+            m.bias = nn.Parameter(torch.zeros(C), requires_grad=False)
+            return m
+        self.tok_emb = _Holder()
+        self.tok_emb.weight = nn.Parameter(torch.zeros(vocab_size, C), requires_grad=False)
+        blocks = []
+        for _ in range(n_layer):
+            b = _Holder()
+            b.ln1, b.ln2 = ln(), ln()
+            b.attn = _Holder()
+            b.attn.key, b.attn.query, b.attn.value, b.attn.proj = lin(C, C), lin(C, C), lin(C, C), lin(C, C)
+            b.mlp = nn.ModuleList([lin(4 * C, C), _Holder(), lin(C, 4 * C)])  # keys mlp.0.* and mlp.2.*
+            blocks.append(b)
+        self.blocks = nn.ModuleList(blocks)
+        self.ln_f = ln()
+        self.head = lin(vocab_size, C, bias=False)
+        self._engine = None
+        self._engine_sig = None
+        self._cache_shape = (0, 0)
+        self._pos = self._len = None
+        self._graphs = {}
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return self.pos_emb.device
+
+    def get_block_size(self):
+        return self.block_size
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("omnitokenizer_amd GPT is inference-only")
+        return super().train(False)
+
+    def load_state_dict(self, state_dict, strict: bool = False, assign: bool = False):
+        """Accepts the reference GPT's state_dict; its causal-mask buffers (blocks.N.attn.mask) are
+        not parameters of the path and are dropped."""
+        sd = {k: v for k, v in state_dict.items() if not k.endswith(".attn.mask")}
+        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        self._engine_sig = None
+        return out
+
+    def __del__(self):
+        try:
+            if self._engine is not None:
+                _lib.load().omnitok_lm_destroy(self._engine)
+        except Exception:
+            pass
+
+    def _signature(self):
+        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+
+    def _sync_engine(self):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"GPT is on {dev}: move it to the GPU (.to('cuda')). The MI355X HIP path is the "
+                               "only implementation; there is no CPU fallback.")
+        sig = self._signature()
+        if self._engine is not None and sig == self._engine_sig:
+            return
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
+        if self._engine is None:
+            cfg = OmnitokLmConfig(self.vocab_size, self.block_size, self.n_layer, self.n_head, self.n_embd)
+            h = ctypes.c_void_p()
+            check(lib.omnitok_lm_create(ctypes.byref(cfg), ctypes.byref(h)), "lm_create")
+            self._engine = h
+        for name, t in self.state_dict(keep_vars=True).items():
+            t = t.detach()
+            if t.dtype != torch.float32:
+                raise TypeError(f"{name}: parameters must be float32 (the path computes in fp32 like the reference)")
+            t = t.contiguous()
+            shape = (ctypes.c_int64 * max(t.dim(), 1))(*t.shape)
+            check(lib.omnitok_lm_set_weight(self._engine, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim(),
+                                            stream), f"lm_set_weight({name})")
+        check(lib.omnitok_lm_finalize(self._engine, stream), "lm_finalize")
+        torch.cuda.current_stream().synchronize()
+        self._engine_sig = sig
+        self._graphs = {}
+
+    def _ensure_cache(self, batch, length):
+        mb, ml = self._cache_shape
+        if batch <= mb and length <= ml:
+            return
+        mb, ml = max(mb, batch), max(ml, min(max(length, 64), self.block_size + 1))
+        check(_lib.load().omnitok_lm_alloc_cache(self._engine, mb, ml), "lm_alloc_cache")
+        self._cache_shape = (mb, ml)
+        self._pos = torch.zeros(mb, dtype=torch.int32, device=self.device)
+        self._len = torch.zeros(mb, dtype=torch.int32, device=self.device)
+        self._graphs = {}
+
+    def cache_bytes(self) -> int:
+        return 0 if self._engine is None else int(_lib.load().omnitok_lm_cache_bytes(self._engine))
+
+    # ---- native stepping ----------------------------------------------------------------------------
+    def reset_streams(self, batch, max_len):
+        """Starts `batch` empty streams (cache length 0, position 0) with room for max_len tokens."""
+        self._sync_engine()
+        if batch > 16:
+            raise ValueError("at most 16 streams per engine")
+        self._ensure_cache(batch, max_len)
+        self._pos.zero_()
+        self._len.zero_()
+
+    def step(self, idx, logits=None, advance=True, want_logits=True):
+        """One decode step: idx [B] int64 (device) enters every stream at pos[b] / cache_len[b].
+        Returns logits [B, vocab] (or None if want_logits is False)."""
+        B = idx.shape[0]
+        if want_logits and logits is None:
+            logits = torch.empty(B, self.vocab_size, device=idx.device, dtype=torch.float32)
+        check(_lib.load().omnitok_lm_step(self._engine, ctypes.c_void_p(idx.data_ptr()),
+                                          ctypes.c_void_p(self._pos.data_ptr()), ctypes.c_void_p(self._len.data_ptr()),
+                                          B, None if not want_logits else ctypes.c_void_p(logits.data_ptr()),
+                                          int(advance), torch.cuda.current_stream().cuda_stream), "lm_step")
+        return logits if want_logits else None
+
+    def graph_step(self, B):
+        """(idx_buffer, logits_buffer, replay) for a captured decode step of B streams: write the next
+        tokens into idx_buffer, call replay(), read logits_buffer.  The step advances pos / cache_len on
+        the device, so replaying it walks down the sequence."""
+        if B not in self._graphs:
+            idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+            logits = torch.empty(B, self.vocab_size, device=self.device, dtype=torch.float32)
+            pos0, len0 = self._pos.clone(), self._len.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.step(idx, logits)  # warm-up outside the capture (lazy module loading)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step(idx, logits)
+            self._pos.copy_(pos0)  # the warm-up and the capture pass do not count
+            self._len.copy_(len0)
+            self._graphs[B] = (idx, logits, g)
+        idx, logits, g = self._graphs[B]
+        return idx, logits, g.replay
+
+    # ---- the reference's interface -----------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, idx, embeddings=None, targets=None, cbox=None, tbox=None):
+        """reference gpt.py:207-234: logits [B, T, V] of a whole sequence (teacher-forced), computed by
+        walking the KV-cached step over the T positions (same arithmetic as forward_with_past)."""
+        if embeddings is not None or cbox is not None or tbox is not None:
+            raise NotImplementedError("explicit embeddings / vtokens_pos boxes are not built")
+        B, T = idx.shape
+        assert T <= self.block_size, "Cannot forward, model block size is exhausted."
+        self.reset_streams(B, T)
+        idx = idx.to(self.device).long()
+        out = torch.empty(B, T, self.vocab_size, device=self.device, dtype=torch.float32)
+        for t in range(T):
+            out[:, t] = self.step(idx[:, t].contiguous())
+        loss = None
+        if targets is not None:
+            loss = F.cross_entropy(out.view(-1, out.size(-1)), targets.view(-1))
+        return out, loss
+
+    @torch.no_grad()
+    def forward_with_past(self, idx, embeddings=None, targets=None, past=None, past_length=None, cbox=None,
+                          forward_uncond=False):
+        """reference gpt.py:236-275.  past=None: idx [B, T] starts new streams (positions 0..T-1).
+        Otherwise idx [B, 1] continues them; `past` is the list of handles returned so far and its
+        total length must equal past_length like the reference asserts (:246-247).  The new token's
+        position embedding is pos_emb[past_length] (+1 with forward_uncond, :248)."""
+        if embeddings is not None or cbox is not None:
+            raise NotImplementedError("explicit embeddings / vtokens_pos boxes are not built")
+        idx = idx.to(self.device).long()
+        B, T = idx.shape
+        if past is None:
+            self.reset_streams(B, self.block_size + 1)
+            for t in range(T - 1):
+                self.step(idx[:, t].contiguous(), want_logits=False)
+            logits = self.step(idx[:, T - 1].contiguous())
+            out = torch.zeros(B, T, self.vocab_size, device=self.device) if T > 1 else None
+            if out is not None:
+                out[:, -1] = logits  # callers read logits[:, -1, :] (gpt.py:347)
+            return (out if out is not None else logits[:, None]), None, _PastHandle(self, T)
+        assert past_length is not None
+        have = sum(p.length for p in past)
+        assert have == past_length, f"{have} =/= {past_length}"
+        assert T == 1
+        self._pos[:B] = past_length + (1 if forward_uncond else 0)
+        logits = self.step(idx[:, 0].contiguous())
+        return logits[:, None], None, _PastHandle(self, 1)
+
+
+def _select(logits, sample_logits, top_k, top_p):
+    if top_k is not None:
+        logits = top_k_top_p_filtering(logits, top_k=top_k, top_p=1.0 if top_p is None else top_p)
+    probs = F.softmax(logits, dim=-1)
+    if not sample_logits:
+        return torch.topk(probs, k=1, dim=-1)[1]
+    return torch.multinomial(probs, num_samples=1)
+
+
+@torch.no_grad()
+def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, top_k=None, top_p=None,
+                     callback=None, cbox=None, use_graph=True, return_logits=False):
+    """reference gpt.py:327-359: x [B, cond_len] conditioning tokens -> [B, steps] sampled tokens.
+    The conditioning is fed through the same KV-cached step; each sampling step is one replay of
+    the captured HIP graph plus the token selection on the GPU, with no host synchronisation."""
+    if cbox is not None:
+        raise NotImplementedError("vtokens_pos boxes are not built")
+    x = x.to(model.device).long()
+    B, cond_len = x.shape
+    model.reset_streams(B, cond_len + steps)
+    for t in range(cond_len - 1):
+        model.step(x[:, t].contiguous(), want_logits=False)
+    if use_graph:
+        idx_buf, logits_buf, replay = model.graph_step(B)
+    nxt = x[:, -1].contiguous()
+    out = torch.empty(B, steps, dtype=torch.int64, device=model.device)
+    all_logits = [] if return_logits else None
+    for n in range(steps):
+        if callback is not None:
+            callback(n)
+        if use_graph:
+            idx_buf.copy_(nxt)
+            replay()
+            logits = logits_buf
+        else:
+            logits = model.step(nxt)
+        logits = logits / temperature
+        if return_logits:
+            all_logits.append(logits.clone())
+        nxt = _select(logits, sample_logits, top_k, top_p)[:, 0]
+        out[:, n] = nxt
+    return (out, torch.stack(all_logits, 1)) if return_logits else out
+
+
+@torch.no_grad()
+def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=True, top_k=None, top_p=None,
+                         callback=None, cbox=None, cfg_ratio=1.5, class_first=False, scale_cfg=False, use_graph=True,
+                         return_logits=False):
+    """reference gpt.py:387-444 (classifier-free guidance).  The conditional stream ([class+1, sos] or
+    [sos, class+1]) and the unconditional stream ([sos]) run as rows [0, B) and [B, 2B) of ONE batched
+    step: both see the same new token and the same position (the reference's forward_uncond shift,
+    gpt.py:248), only their cache lengths differ by one."""
+    if cbox is not None:
+        raise NotImplementedError("vtokens_pos boxes are not built")
+    x = x.to(model.device).long() + 1
+    B = x.shape[0]
+    sos = torch.zeros_like(x)
+    cond = torch.cat((x, sos), 1) if class_first else torch.cat((sos, x), 1)
+    cond_len = cond.shape[1]  # 2
+    model.reset_streams(2 * B, cond_len + steps)
+    # conditioning prefix of the conditional rows only (rows [B, 2B) stay empty): advance them by hand
+    for t in range(cond_len - 1):
+        tok = torch.cat((cond[:, t], sos[:, 0])).contiguous()
+        model.step(tok, want_logits=False, advance=False)
+        model._pos[:B] += 1
+        model._len[:B] += 1
+    model._pos[B:2 * B] = 0
+    nxt = torch.cat((cond[:, -1], sos[:, 0])).contiguous()
+    if use_graph:
+        idx_buf, logits_buf, replay = model.graph_step(2 * B)
+    out = torch.empty(B, steps, dtype=torch.int64, device=model.device)
+    all_logits = [] if return_logits else None
+    for n in range(steps):
+        if callback is not None:
+            callback(n)
+        if n == 1:
+            # after the first step the unconditional rows skip position 1 (forward_uncond, gpt.py:248)
+            model._pos[B:2 * B] = model._pos[:B]
+        if use_graph:
+            idx_buf.copy_(nxt)
+            replay()
+            logits = logits_buf
+        else:
+            logits = model.step(nxt)
+        lc, lu = logits[:B] / temperature, logits[B:] / temperature
+        t = cfg_ratio * (n if scale_cfg else 1)
+        blend = (1 + t) * lc - t * lu
+        if return_logits:
+            all_logits.append(blend.clone())
+        tok = _select(blend, sample_logits, top_k, top_p)[:, 0]
+        out[:, n] = tok
+        nxt = torch.cat((tok, tok)).contiguous()
+    return (out, torch.stack(all_logits, 1)) if return_logits else out

@@ -183,6 +183,47 @@ def make_vq_kat():
         print(f"vq_kat_{n_codes}: uniq {np.unique(ids).size}")
 
 
+GPT_CASES = [  # name, vocab, block_size, n_layer, n_head, n_embd (head_dim 64 / 96 / 128)
+    ("gpt_hd64", 320, 48, 2, 4, 256),
+    ("gpt_hd96", 520, 40, 2, 8, 768),
+    ("gpt_hd128", 300, 40, 3, 4, 512),
+]
+
+
+def make_gpt_golden():
+    """LM consumer: logits and greedy samples of the reference's own GPT class
+    (OmniTokenizer/modules/gpt.py, imported unmodified) on seeded weights."""
+    import argparse
+    import importlib
+    from oracle import gpt_oracle as go
+    rh.install_stubs()
+    gpt = importlib.import_module("OmniTokenizer.modules.gpt")
+    for name, V, BS, L, H, C in GPT_CASES:
+        sd = go.synth_gpt_state(V, BS, L, H, C, seed=2)
+        m = gpt.GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C).eval()
+        missing = m.load_state_dict(sd, strict=False)
+        assert not missing.unexpected_keys and all(k.endswith("attn.mask") for k in missing.missing_keys)
+        g = torch.Generator().manual_seed(5)
+        idx = torch.randint(0, V, (2, 16), generator=g)
+        cls = torch.randint(0, 100, (2, 1), generator=g)
+        steps = 14
+        with torch.no_grad():
+            logits, _ = m(idx)
+            greedy = gpt.sample_with_past(idx[:, :3].clone(), m, steps, temperature=0.9, sample_logits=False,
+                                          top_k=50, top_p=0.9)
+            cfg_a = gpt.sample_with_past_cfg(cls.clone(), m, steps, sample_logits=False, top_k=64, top_p=1.0,
+                                             cfg_ratio=1.5, class_first=True)
+            cfg_b = gpt.sample_with_past_cfg(cls.clone(), m, steps, sample_logits=False, top_k=64, top_p=0.95,
+                                             cfg_ratio=0.5, class_first=False, scale_cfg=True)
+        crc = 0
+        for k in sd:
+            crc = __import__("zlib").crc32(sd[k].numpy().tobytes(), crc)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), vocab=V, block_size=BS, n_layer=L, n_head=H, n_embd=C,
+                            weight_seed=2, state_crc=np.uint32(crc), idx=idx.numpy(), cls=cls.numpy(), steps=steps,
+                            logits=logits.numpy(), greedy=greedy.numpy(), cfg_a=cfg_a.numpy(), cfg_b=cfg_b.numpy())
+        print(f"{name}: logits {tuple(logits.shape)} absmax {logits.abs().max().item():.2f} greedy {greedy[0, :6].tolist()}")
+
+
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -194,6 +235,8 @@ if __name__ == "__main__":
     if only in (None, "variants"):
         for c in VARIANT_CASES:
             run_case(*c)
+    if only in (None, "gpt"):
+        make_gpt_golden()
     if only in (None, "vae"):
         for c in VAE_CASES:
             run_vae_case(*c)

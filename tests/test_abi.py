@@ -18,7 +18,8 @@ def lib():
 
 def test_header_symbols_exported(lib):
     from omnitokenizer_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "omnitok.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "omnitok.h")).read() + \
+        open(os.path.join(ROOT, "include", "omnitok_lm.h")).read()
     declared = set(re.findall(r"\b(omnitok_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"omnitok_stream_t"}
     assert len(declared) >= 30

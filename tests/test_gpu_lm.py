@@ -1,0 +1,163 @@
+"""GPU (-m gpu): the LM consumer (include/omnitok_lm.h, omnitokenizer_amd/gpt.py) against the
+committed outputs of the reference's GPT class and the CPU oracle."""
+import argparse
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import gpt_oracle as go
+from tests.test_oracle_gpt import GPT_CASES, load_gpt_case
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from omnitokenizer_amd import _lib
+    return _lib.load()
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 11])
+@pytest.mark.parametrize("N,K", [(1536, 1536), (6144, 1536), (1536, 6144), (300, 256), (8193, 768)])
+def test_gemv(lib, B, N, K):
+    x, w, bias, res = rnd(B, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(B, N, seed=4)
+    g, beta = rnd(K, seed=5, scale=0.1) + 1.0, rnd(K, seed=6, scale=0.1)
+    s = torch.cuda.current_stream().cuda_stream
+    xd, wd, bd, rd, gd, betad = (t.cuda() for t in (x, w, bias, res, g, beta))
+    tol = 2e-5 * math.sqrt(K / 1536)
+    # plain + bias
+    y = torch.empty(B, N, device="cuda")
+    assert lib.omnitok_lm_gemv(_p(xd), _p(wd), _p(bd), None, None, None, _p(y), B, N, K, 0, s) == 0
+    assert (y.cpu() - F.linear(x, w, bias)).abs().max().item() < tol
+    # LayerNorm prologue + GELU epilogue
+    assert lib.omnitok_lm_gemv(_p(xd), _p(wd), _p(bd), None, _p(gd), _p(betad), _p(y), B, N, K, 1, s) == 0
+    ref = F.gelu(F.linear(F.layer_norm(x, (K,), g, beta), w, bias))
+    assert (y.cpu() - ref).abs().max().item() < tol
+    # residual, in place
+    y = rd.clone()
+    assert lib.omnitok_lm_gemv(_p(xd), _p(wd), None, _p(y), None, None, _p(y), B, N, K, 0, s) == 0
+    assert (y.cpu() - (F.linear(x, w) + res)).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("hd", [64, 96, 128])
+def test_attn_decode(lib, hd):
+    B, H, max_len = 3, 4, 700
+    C = H * hd
+    nchunk = (max_len + 255) // 256
+    s = torch.cuda.current_stream().cuda_stream
+    kc = rnd(B, H, max_len, hd, seed=7).cuda()
+    vc = rnd(B, H, max_len, hd, seed=8).cuda()
+    scratch = torch.empty(B * H * nchunk * (2 + hd), device="cuda")
+    out = torch.empty(B, C, device="cuda")
+    for lens in ([0, 1, 5], [255, 256, 257], [511, 640, 699]):
+        qkv = rnd(B, 3 * C, seed=9 + lens[0])
+        cl = torch.tensor(lens, dtype=torch.int32, device="cuda")
+        kc0, vc0 = kc.clone(), vc.clone()
+        assert lib.omnitok_lm_attn_decode(_p(qkv.cuda()), _p(kc), _p(vc), _p(cl), B, H, hd, max_len, _p(scratch),
+                                          _p(out), s) == 0
+        q, kn, vn = (t.reshape(B, H, hd) for t in qkv.split(C, dim=1))
+        for b, ln in enumerate(lens):
+            k = torch.cat([kc0[b, :, :ln].cpu(), kn[b][:, None]], 1)  # H, ln+1, hd
+            v = torch.cat([vc0[b, :, :ln].cpu(), vn[b][:, None]], 1)
+            att = torch.softmax((q[b][:, None] @ k.transpose(-1, -2)) / math.sqrt(hd), -1)
+            ref = (att @ v).reshape(C)
+            assert (out[b].cpu() - ref).abs().max().item() < 2e-5, (hd, ln)
+            # the new token's K/V were appended at index ln, nothing else changed
+            assert torch.equal(kc[b, :, ln].cpu(), kn[b]) and torch.equal(vc[b, :, ln].cpu(), vn[b])
+            assert torch.equal(kc[b, :, :ln], kc0[b, :, :ln]) and torch.equal(kc[b, :, ln + 1:], kc0[b, :, ln + 1:])
+
+
+@pytest.fixture(scope="module")
+def gpts():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            from omnitokenizer_amd.gpt import GPT
+            g, sd, (V, BS, L, H, C) = load_gpt_case(name)
+            m = GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C)
+            res = m.load_state_dict(sd, strict=True)
+            assert not res.missing_keys and not res.unexpected_keys
+            cache[name] = (m.cuda().eval(), g, sd, H)
+        return cache[name]
+    return get
+
+
+@pytest.mark.parametrize("name", GPT_CASES)
+def test_gpt_vs_reference_golden(gpts, name):
+    from omnitokenizer_amd import gpt as og
+    m, g, sd, H = gpts(name)
+    idx, cls, steps = torch.from_numpy(g["idx"]).cuda(), torch.from_numpy(g["cls"]).cuda(), int(g["steps"])
+    logits, _ = m(idx)
+    err = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
+    assert err < LOGIT_TOL, f"logits differ from the reference by {err:.2e}"
+    for use_graph in (False, True):
+        greedy = og.sample_with_past(idx[:, :3].clone(), m, steps, temperature=0.9, sample_logits=False, top_k=50,
+                                     top_p=0.9, use_graph=use_graph)
+        assert np.array_equal(greedy.cpu().numpy(), g["greedy"]), f"greedy sample differs (graph={use_graph})"
+        a = og.sample_with_past_cfg(cls.clone(), m, steps, sample_logits=False, top_k=64, top_p=1.0, cfg_ratio=1.5,
+                                    class_first=True, use_graph=use_graph)
+        b = og.sample_with_past_cfg(cls.clone(), m, steps, sample_logits=False, top_k=64, top_p=0.95, cfg_ratio=0.5,
+                                    class_first=False, scale_cfg=True, use_graph=use_graph)
+        assert np.array_equal(a.cpu().numpy(), g["cfg_a"]) and np.array_equal(b.cpu().numpy(), g["cfg_b"])
+    print(f"{name}: logits err {err:.1e}")
+
+
+def test_gpt_reference_calling_pattern_and_logits(gpts):
+    """The reference's own loop body (gpt.py:334-357) runs unchanged on the drop-in class, and the
+    per-step logits match the oracle's."""
+    m, g, sd, H = gpts("gpt_hd96")
+    x = torch.from_numpy(g["idx"])[:, :4]
+    steps = 10
+    ref_tok, ref_logits = go.sample_with_past(sd, x, H, steps, sample_logits=False, return_logits=True)
+    sample = xc = x.cuda()
+    cond_len, past, errs = xc.shape[1], None, []
+    for n in range(steps):
+        logits, _, present = m.forward_with_past(xc, past=past, past_length=(n + cond_len - 1))
+        past = [present] if past is None else past + [present]
+        logits = logits[:, -1, :] / 1.0
+        errs.append((logits.cpu() - ref_logits[:, n]).abs().max().item())
+        _, xc = torch.topk(F.softmax(logits, dim=-1), k=1, dim=-1)
+        sample = torch.cat((sample, xc), dim=1)
+    assert max(errs) < LOGIT_TOL
+    assert torch.equal(sample[:, cond_len:].cpu(), ref_tok)
+
+
+def test_gpt_stochastic_sampling_statistics(gpts):
+    """multinomial sampling: tokens are valid, reproducible under a seed, and respect top-k."""
+    from omnitokenizer_amd import gpt as og
+    m, g, sd, H = gpts("gpt_hd64")
+    x = torch.from_numpy(g["idx"])[:, :2].cuda()
+    torch.manual_seed(3)
+    a, la = og.sample_with_past(x, m, 20, temperature=1.0, top_k=8, top_p=1.0, return_logits=True)
+    torch.manual_seed(3)
+    b = og.sample_with_past(x, m, 20, temperature=1.0, top_k=8, top_p=1.0)
+    assert torch.equal(a, b) and a.min() >= 0 and a.max() < m.vocab_size
+    top8 = la.topk(8, dim=-1)[1]
+    assert (top8 == a[..., None]).any(-1).all()
+
+
+def test_gpt_errors(gpts, lib):
+    m, g, sd, H = gpts("gpt_hd64")
+    with pytest.raises(AssertionError):
+        m(torch.zeros(1, m.block_size + 1, dtype=torch.long, device="cuda"))
+    with pytest.raises(ValueError):
+        m.reset_streams(17, 8)
+    from omnitokenizer_amd._lib import OmnitokLmConfig
+    h = ctypes.c_void_p()
+    cfg = OmnitokLmConfig(100, 16, 1, 3, 300)
+    assert lib.omnitok_lm_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    assert b"head_dim" in lib.omnitok_last_error()
