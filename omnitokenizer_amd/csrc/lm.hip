@@ -45,68 +45,163 @@ __global__ __launch_bounds__(256) void lm_embed_kernel(const int64_t *__restrict
     }
 }
 
-template <int BQ, int ROWS, int ACT, bool LN>
+// One workgroup = 4 waves x ROWS weight rows.  The activations (BQ rows of K floats, a few KB, L2-
+// resident) are staged once per workgroup in LDS in panels of LM_KP floats -- layer-normalised on the
+// way in when LN -- so the waves only stream weights from HBM: U chunks (256 floats) of each of the
+// wave's ROWS rows are in flight while the previous U are multiplied (register double buffer).
+//
+// attention-merge staging (XM): x is not a tensor but the flash-decode chunk partials of
+// lm_attn_decode_kernel; the workgroup merges them while it stages its activations, so the chunked
+// attention needs neither a merge launch nor cross-workgroup fences.
+constexpr int LM_KP = 2048;        // K panel staged in LDS (BQ * LM_KP * 4 B <= 64 KiB)
+constexpr int LM_MAX_CHUNKS = 32;  // attention chunks per sequence: max_len <= 8192
+constexpr int LM_MAX_HEADS = 32;   // (bounds the merge-weight table in LDS: B * heads * chunks floats)
+
+struct LmMerge {
+    const float *part;         // [B][n_head][nchunk][2 + hd]
+    const int32_t *cache_len;  // [B]
+    int n_head, hd, nchunk;
+};
+
+template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
 __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ bias, const float *residual,
                                                       const float *__restrict__ g, const float *__restrict__ beta,
-                                                      float *y, int N, int K) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                                      float *y, int N, int K, LmMerge mg) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [BQ][kp]
+    __shared__ float s_mean[BQ], s_rstd[BQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * ROWS;
-    if (row0 >= N) return;
-    float mean[BQ], rstd[BQ];
-    if (LN) {
-        // nn.LayerNorm statistics of each activation row (two-pass, like ATen): the rows are a few KB
-        // and L2-resident, every wave recomputes them instead of a separate launch
-#pragma unroll
-        for (int b = 0; b < BQ; ++b) {
-            float s = 0.0f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-            mean[b] = wave_allsum(s) / (float)K;
-            float q = 0.0f;
-            for (int k = lane * 4; k < K; k += 256) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
-                const float a0 = v[0] - mean[b], a1 = v[1] - mean[b], a2 = v[2] - mean[b], a3 = v[3] - mean[b];
-                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            }
-            rstd[b] = 1.0f / sqrtf(wave_allsum(q) / (float)K + 1e-5f);
-        }
-    }
+    const int kp = K < LM_KP ? K : LM_KP;
+    const int nch = K >> 8;  // 256-float chunks
+    float *s_f = xs + BQ * kp;  // XM: [b][h][c] merge weights e^(M_c - M) / L
     const float *wr[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) wr[r] = w + (int64_t)(row0 + r < N ? row0 + r : N - 1) * K + lane * 4;
+    auto load_w = [&](f32x4 (&dst)[ROWS][U], int c0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u < nch ? c0 + u : nch - 1;  // tail chunks re-read the last one, masked below
+#pragma unroll
+            for (int r = 0; r < ROWS; ++r)
+                dst[r][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wr[r] + c * 256));
+        }
+    };
+    f32x4 wa[ROWS][U], wb[ROWS][U];
+    load_w(wa, 0);  // in flight while the LayerNorm statistics / merge weights are computed
+    if (XM) {
+        // per (b, h): global max over the chunks that hold keys, then f_c = e^(M_c - M) / sum_c L_c e^(M_c - M)
+        for (int i = tid; i < BQ * mg.n_head; i += 256) {
+            const int b = i / mg.n_head, h = i - b * mg.n_head;
+            const int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+            const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * (2 + mg.hd);
+            float M = -INFINITY;
+            for (int c = 0; c < used; ++c) M = fmaxf(M, pp[c * (2 + mg.hd)]);
+            float L = 0.0f;
+            for (int c = 0; c < used; ++c) L += pp[c * (2 + mg.hd) + 1] * expf(pp[c * (2 + mg.hd)] - M);
+            for (int c = 0; c < used; ++c)
+                s_f[(b * mg.n_head + h) * mg.nchunk + c] = expf(pp[c * (2 + mg.hd)] - M) / L;
+        }
+    }
+    if (LN) {
+        // nn.LayerNorm statistics (two-pass, like ATen): wave w owns activation rows w and w + 4
+        for (int b = wave; b < BQ; b += 4) {
+            float sum = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            const float mean = wave_allsum(sum) / (float)K;
+            float q = 0.0f;
+            for (int k = lane * 4; k < K; k += 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
+                const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+                q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            }
+            const float var = wave_allsum(q) / (float)K;
+            if (lane == 0) {
+                s_mean[b] = mean;
+                s_rstd[b] = 1.0f / sqrtf(var + 1e-5f);
+            }
+        }
+    }
     float acc[ROWS][BQ];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int b = 0; b < BQ; ++b) acc[r][b] = 0.0f;
-    for (int k0 = 0; k0 < K; k0 += 256) {
-        f32x4 wv[ROWS];
+
+    auto consume = [&](const f32x4 (&wv)[ROWS][U], int c0, int cbase) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) wv[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wr[r] + k0));
-        f32x4 g4, b4;
-        if (LN) {
-            g4 = *reinterpret_cast<const f32x4 *>(g + k0 + lane * 4);
-            b4 = *reinterpret_cast<const f32x4 *>(beta + k0 + lane * 4);
-        }
+        for (int u = 0; u < U; ++u) {
+            if (c0 + u < nch) {
+                const int off = (c0 + u - cbase) * 256 + lane * 4;
 #pragma unroll
-        for (int b = 0; b < BQ; ++b) {
-            f32x4 xv = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k0 + lane * 4);
-            if (LN) {
+                for (int b = 0; b < BQ; ++b) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(xs + b * kp + off);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) xv[e] = (xv[e] - mean[b]) * rstd[b] * g4[e] + b4[e];
+                    for (int r = 0; r < ROWS; ++r) {
+                        acc[r][b] = fmaf(wv[r][u][0], xv[0], acc[r][b]);
+                        acc[r][b] = fmaf(wv[r][u][1], xv[1], acc[r][b]);
+                        acc[r][b] = fmaf(wv[r][u][2], xv[2], acc[r][b]);
+                        acc[r][b] = fmaf(wv[r][u][3], xv[3], acc[r][b]);
+                    }
+                }
             }
+        }
+    };
+
+    constexpr int CPP = LM_KP / 256;  // chunks per panel (a multiple of 2 * U)
+    for (int p0 = 0; p0 < nch; p0 += CPP) {
+        __syncthreads();  // previous panel fully consumed (and s_mean / s_rstd / s_f visible)
+        const int pk = (nch - p0 < CPP ? nch - p0 : CPP) * 256;  // floats in this panel
+        for (int i = tid * 4; i < BQ * pk; i += 1024) {
+            const int b = i / pk, k = i - b * pk;
+            f32x4 v;
+            if (XM) {
+                const int col = p0 * 256 + k, h = col / mg.hd, d = col - h * mg.hd;  // hd % 4 == 0: one head per float4
+                const int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+                const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * (2 + mg.hd) + 2 + d;
+                const float *fw = s_f + (b * mg.n_head + h) * mg.nchunk;
+                v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                for (int c = 0; c < used; ++c) {
+                    const float f = fw[c];
+                    const float *q = pp + c * (2 + mg.hd);
+                    v[0] += q[0] * f;
+                    v[1] += q[1] * f;
+                    v[2] += q[2] * f;
+                    v[3] += q[3] * f;
+                }
+            } else {
+                v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + p0 * 256 + k);
+            }
+            if (LN) {
+                const f32x4 g4 = *reinterpret_cast<const f32x4 *>(g + p0 * 256 + k);
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(beta + p0 * 256 + k);
+                const float mean = s_mean[b], rstd = s_rstd[b];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                acc[r][b] = fmaf(wv[r][0], xv[0], acc[r][b]);
-                acc[r][b] = fmaf(wv[r][1], xv[1], acc[r][b]);
-                acc[r][b] = fmaf(wv[r][2], xv[2], acc[r][b]);
-                acc[r][b] = fmaf(wv[r][3], xv[3], acc[r][b]);
+                for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * g4[e] + b4[e];
+            }
+            *reinterpret_cast<f32x4 *>(xs + b * kp + k) = v;
+        }
+        __syncthreads();
+        const int pend = p0 + CPP < nch ? p0 + CPP : nch;
+        for (int c0 = p0; c0 < pend; c0 += 2 * U) {
+            load_w(wb, c0 + U);  // may belong to the next panel: only the weights are prefetched
+            consume(wa, c0, p0);
+            if (c0 + U < pend) {
+                load_w(wa, c0 + 2 * U);
+                consume(wb, c0 + U, p0);
+            } else {
+                // wb holds the first group of the next panel: rotate it into wa
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) wa[r][u] = wb[r][u];
             }
         }
     }
+    if (row0 >= N) return;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
@@ -275,31 +370,65 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
     out[i] = i < n ? a[i] : (i < 2 * n ? b[i - n] : c[i - 2 * n]);
 }
 
-template <int BQ, int ACT, bool LN>
+template <int BQ, int ACT, bool LN, bool XM>
 static void launch_gemv_rows(const float *x, const float *w, const float *bias, const float *residual, const float *g,
-                             const float *beta, float *y, int N, int K, hipStream_t stream) {
-    // 4 rows per wave once there are enough rows to fill the chip, 2 otherwise (more waves in flight)
-    if (N >= 4096 && BQ <= 4) {
-        const int rows_per_wg = 16;
-        hipLaunchKernelGGL((lm_gemv_kernel<BQ, 4, ACT, LN>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256), 0,
-                           stream, x, w, bias, residual, g, beta, y, N, K);
-    } else {
-        const int rows_per_wg = 8;
-        hipLaunchKernelGGL((lm_gemv_kernel<BQ, 2, ACT, LN>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256), 0,
-                           stream, x, w, bias, residual, g, beta, y, N, K);
+                             const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
+    // 2 rows x 2 chunks (x2 register buffers) per wave: 8 KiB of weights in flight per wave
+    constexpr int ROWS = 2, U = 2;
+    const int kp = K < LM_KP ? K : LM_KP;
+    const int lds = (BQ * kp + (XM ? BQ * mg.n_head * mg.nchunk : 0)) * 4;
+    const int rows_per_wg = 4 * ROWS;
+    static int attr = 65536;  // per instantiation
+    if (lds > attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr = lds;
     }
+    hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256),
+                       lds, stream, x, w, bias, residual, g, beta, y, N, K, mg);
 }
 
 template <int BQ>
 static void launch_gemv_bq(const float *x, const float *w, const float *bias, const float *residual, const float *g,
-                           const float *beta, float *y, int N, int K, int act, hipStream_t stream) {
-    if (g) {
-        if (act) launch_gemv_rows<BQ, 1, true>(x, w, bias, residual, g, beta, y, N, K, stream);
-        else launch_gemv_rows<BQ, 0, true>(x, w, bias, residual, g, beta, y, N, K, stream);
+                           const float *beta, float *y, int N, int K, int act, const LmMerge *mg, hipStream_t stream) {
+    const LmMerge none{nullptr, nullptr, 0, 0, 0};
+    if (mg) {
+        launch_gemv_rows<BQ, 0, false, true>(x, w, bias, residual, g, beta, y, N, K, *mg, stream);
+    } else if (g) {
+        if (act) launch_gemv_rows<BQ, 1, true, false>(x, w, bias, residual, g, beta, y, N, K, none, stream);
+        else launch_gemv_rows<BQ, 0, true, false>(x, w, bias, residual, g, beta, y, N, K, none, stream);
     } else {
-        if (act) launch_gemv_rows<BQ, 1, false>(x, w, bias, residual, g, beta, y, N, K, stream);
-        else launch_gemv_rows<BQ, 0, false>(x, w, bias, residual, g, beta, y, N, K, stream);
+        if (act) launch_gemv_rows<BQ, 1, false, false>(x, w, bias, residual, g, beta, y, N, K, none, stream);
+        else launch_gemv_rows<BQ, 0, false, false>(x, w, bias, residual, g, beta, y, N, K, none, stream);
     }
+}
+
+// y = act(LN(x) W^T + b) (+ residual) for B rows, in groups of up to 8 rows per pass over the weights.
+// mg != nullptr: the activations are the merged attention partials (x unused).
+static int lm_gemv_any(const float *x, const float *w, const float *bias, const float *residual, const float *g,
+                       const float *beta, float *y, int B, int N, int K, int act, const LmMerge *mg, hipStream_t stream) {
+    for (int b0 = 0; b0 < B;) {
+        const int left = B - b0;
+        const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
+        const float *xb = x ? x + (int64_t)b0 * K : nullptr, *rb = residual ? residual + (int64_t)b0 * N : nullptr;
+        float *yb = y + (int64_t)b0 * N;
+        LmMerge m2{nullptr, nullptr, 0, 0, 0};
+        if (mg) {
+            m2 = *mg;
+            m2.part += (int64_t)b0 * mg->n_head * mg->nchunk * (2 + mg->hd);
+            m2.cache_len += b0;
+        }
+        const LmMerge *mp = mg ? &m2 : nullptr;
+        switch (bq) {
+            case 8: launch_gemv_bq<8>(xb, w, bias, rb, g, beta, yb, N, K, act, mp, stream); break;
+            case 4: launch_gemv_bq<4>(xb, w, bias, rb, g, beta, yb, N, K, act, mp, stream); break;
+            case 2: launch_gemv_bq<2>(xb, w, bias, rb, g, beta, yb, N, K, act, mp, stream); break;
+            default: launch_gemv_bq<1>(xb, w, bias, rb, g, beta, yb, N, K, act, mp, stream); break;
+        }
+        OT_LAUNCH_CHECK("lm_gemv");
+        b0 += bq;
+    }
+    return OMNITOK_OK;
 }
 
 }  // namespace omnitok
@@ -316,30 +445,13 @@ extern "C" int omnitok_lm_gemv(const float *x, const float *w, const float *bias
     OT_CHECK_ARG((ln_gamma != nullptr) == (ln_beta != nullptr), "lm_gemv: ln_gamma / ln_beta must come together");
     OT_CHECK_ARG(act == 0 || act == 1, "lm_gemv: act %d", act);
     OT_CHECK_ARG(aligned16(x) && aligned16(w), "lm_gemv: unaligned");
-    // batch rows in groups of up to 8 per pass over the weights
-    for (int b0 = 0; b0 < B;) {
-        const int left = B - b0;
-        const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
-        const float *xb = x + (int64_t)b0 * K, *rb = residual ? residual + (int64_t)b0 * N : nullptr;
-        float *yb = y + (int64_t)b0 * N;
-        switch (bq) {
-            case 8: launch_gemv_bq<8>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
-            case 4: launch_gemv_bq<4>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
-            case 2: launch_gemv_bq<2>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
-            default: launch_gemv_bq<1>(xb, w, bias, rb, ln_gamma, ln_beta, yb, N, K, act, stream); break;
-        }
-        OT_LAUNCH_CHECK("lm_gemv");
-        b0 += bq;
-    }
-    return OMNITOK_OK;
+    return lm_gemv_any(x, w, bias, residual, ln_gamma, ln_beta, y, B, N, K, act, nullptr, stream);
 }
 
-extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B,
-                                      int n_head, int head_dim, int max_len, float *scratch, float *out,
-                                      omnitok_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (B == 0) return OMNITOK_OK;
-    OT_CHECK_ARG(qkv && kc && vc && cache_len && scratch && out, "lm_attn_decode: null pointer");
+// chunk partials only (the engine merges them inside the proj GEMV)
+static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B, int n_head,
+                            int head_dim, int max_len, float *scratch, hipStream_t stream) {
+    OT_CHECK_ARG(qkv && kc && vc && cache_len && scratch, "lm_attn_decode: null pointer");
     OT_CHECK_ARG(head_dim == 64 || head_dim == 96 || head_dim == 128, "lm_attn_decode: head_dim %d (64 | 96 | 128)",
                  head_dim);
     OT_CHECK_ARG(max_len > 0 && n_head > 0, "lm_attn_decode: bad sizes");
@@ -360,6 +472,17 @@ extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, co
             break;
     }
     OT_LAUNCH_CHECK("lm_attn_decode");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B,
+                                      int n_head, int head_dim, int max_len, float *scratch, float *out,
+                                      omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (B == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(out, "lm_attn_decode: null pointer");
+    if (int rc = lm_attn_partials(qkv, kc, vc, cache_len, B, n_head, head_dim, max_len, scratch, stream)) return rc;
+    const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
     hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(n_head, B), dim3(128), 0, stream, scratch, cache_len, n_head, head_dim,
                        nchunk, out);
     OT_LAUNCH_CHECK("lm_attn_merge");
@@ -537,6 +660,8 @@ extern "C" int omnitok_lm_finalize(omnitok_lm *lm, omnitok_stream_t stream_) {
 
 extern "C" int omnitok_lm_alloc_cache(omnitok_lm *lm, int max_batch, int max_len) {
     OT_CHECK_ARG(lm && max_batch > 0 && max_batch <= 16 && max_len > 0, "lm_alloc_cache: bad sizes (max_batch <= 16)");
+    OT_CHECK_ARG(max_len <= LM_CHUNK * LM_MAX_CHUNKS && lm->cfg.n_head <= LM_MAX_HEADS,
+                 "lm_alloc_cache: max_len <= %d and n_head <= %d", LM_CHUNK * LM_MAX_CHUNKS, LM_MAX_HEADS);
     lm_free_cache(lm);
     const omnitok_lm_config &c = lm->cfg;
     const int64_t C = c.n_embd;
@@ -584,10 +709,10 @@ extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos,
         // x + proj(attn(ln1(x)))   (reference gpt.py:159-161)
         if (int rc = omnitok_lm_gemv(lm->x, L.wqkv, L.bqkv, nullptr, L.ln1w, L.ln1b, lm->qkv, B, 3 * C, C, 0, stream))
             return rc;
-        if (int rc = omnitok_lm_attn_decode(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, lm->att,
-                                            stream))
+        if (int rc = lm_attn_partials(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, stream))
             return rc;
-        if (int rc = omnitok_lm_gemv(lm->att, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, stream))
+        const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + LM_CHUNK - 1) / LM_CHUNK};
+        if (int rc = lm_gemv_any(nullptr, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, &mg, stream))
             return rc;
         // x + mlp(ln2(x))          (reference gpt.py:162, 150-155)
         if (int rc = omnitok_lm_gemv(lm->x, L.w1, L.b1, nullptr, L.ln2w, L.ln2b, lm->hid, B, 4 * C, C, 1, stream))

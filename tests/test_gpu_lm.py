@@ -161,3 +161,32 @@ def test_gpt_errors(gpts, lib):
     cfg = OmnitokLmConfig(100, 16, 1, 3, 300)
     assert lib.omnitok_lm_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
     assert b"head_dim" in lib.omnitok_last_error()
+
+
+def test_tokens_to_pixels_chain():
+    """The consumer chain of lm_transformer.py:262,430-436: encode() ids condition the LM, sampled ids
+    (clamped into the codebook range, :433) go through decode()."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd import gpt as og
+    from omnitokenizer_amd.config import OmniTokConfig
+    args = make_args(2, resolution=64)
+    cfg = OmniTokConfig.from_args(args)
+    vq = OmniTokenizer_VQGAN(args)
+    vq.load_state_dict(synth.synth_state_dict(cfg, 0), strict=True)
+    vq = vq.cuda().eval()
+    x = synth.synth_video(1, 5, 64).cuda()
+    ids = vq.encode(x, False)                       # [1, 2, 8, 8]
+    n_first = 64                                    # first-frame tokens condition the LM (frame prediction)
+    V, steps = cfg.n_codes, ids.numel() - n_first
+    sd = go.synth_gpt_state(V, ids.numel() + 1, 2, 4, 256, seed=4)
+    lm = og.GPT(argparse.Namespace(), V, ids.numel() + 1, n_layer=2, n_head=4, n_embd=256)
+    lm.load_state_dict(sd, strict=True)
+    lm = lm.cuda().eval()
+    cond = ids.reshape(1, -1)[:, :n_first]
+    new = og.sample_with_past(cond, lm, steps, sample_logits=False, top_k=100, top_p=0.95)
+    ref = go.sample_with_past(sd, cond.cpu(), 4, steps, sample_logits=False, top_k=100, top_p=0.95)
+    assert torch.equal(new.cpu(), ref)
+    index = torch.clamp(torch.cat([cond, new], 1), min=0, max=V - 1)
+    video = vq.decode(index, False)                 # flat video ids, omnitokenizer.py:283-286
+    assert tuple(video.shape) == (1, 3, 5, 64, 64) and torch.isfinite(video).all()
+    assert torch.equal(video, vq.decode(index.reshape(1, 2, 8, 8), False))
