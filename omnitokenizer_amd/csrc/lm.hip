@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     const int kbase = c * LM_CHUNK + wave * 64;
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
+        if (kbase + it * 8 >= total) break;  // wave-uniform: no keys left in this chunk
         const int key = kbase + it * 8 + slot;
         const bool valid = key < total;
         // the new token's row is read from qkv (its cache copy is being written by this kernel)
@@ -370,11 +371,9 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
     out[i] = i < n ? a[i] : (i < 2 * n ? b[i - n] : c[i - 2 * n]);
 }
 
-template <int BQ, int ACT, bool LN, bool XM>
-static void launch_gemv_rows(const float *x, const float *w, const float *bias, const float *residual, const float *g,
-                             const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
-    // 2 rows x 2 chunks (x2 register buffers) per wave: 8 KiB of weights in flight per wave
-    constexpr int ROWS = 2, U = 2;
+template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
+static void launch_gemv_cfg(const float *x, const float *w, const float *bias, const float *residual, const float *g,
+                            const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
     const int kp = K < LM_KP ? K : LM_KP;
     const int lds = (BQ * kp + (XM ? BQ * mg.n_head * mg.nchunk : 0)) * 4;
     const int rows_per_wg = 4 * ROWS;
@@ -386,6 +385,18 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
     }
     hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256),
                        lds, stream, x, w, bias, residual, g, beta, y, N, K, mg);
+}
+
+template <int BQ, int ACT, bool LN, bool XM>
+static void launch_gemv_rows(const float *x, const float *w, const float *bias, const float *residual, const float *g,
+                             const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
+    // ROWS weight rows x U chunks (x2 register buffers) per wave = 8 KiB of weights in flight per wave.
+    // Narrow outputs (N <= 2048: the C x C and C x 4C projections) take one row per wave so that the
+    // launch still covers every CU.  (Measured at C = 1536: 4 rows per wave for 4-8 batch rows, or a
+    // side-stream weight prefetch into the Infinity Cache, did not help: the step is bound by the ~4.5 us
+    // fixed cost of each of its 122 dependent launches, after which the kernels stream at 5-7 TB/s.)
+    if (N <= 2048) launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    else launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
 }
 
 template <int BQ>

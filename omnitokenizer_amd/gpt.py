@@ -271,12 +271,31 @@ class GPT(nn.Module):
 
 
 def _select(logits, sample_logits, top_k, top_p):
-    if top_k is not None:
-        logits = top_k_top_p_filtering(logits, top_k=top_k, top_p=1.0 if top_p is None else top_p)
-    probs = F.softmax(logits, dim=-1)
-    if not sample_logits:
-        return torch.topk(probs, k=1, dim=-1)[1]
-    return torch.multinomial(probs, num_samples=1)
+    """Token selection of the reference's loops (gpt.py:347-357): top-k / top-p filtering, softmax,
+    then top-1 or a multinomial draw.  The stochastic branch draws from the same distribution with
+    ONE descending sort instead of topk + sort: in sorted order the top-k filter is `rank >= k` (ties
+    with the k-th value kept, like `logits < kth`), the nucleus filter is the shifted cumulative mass,
+    and the drawn rank is mapped back through the sort indices."""
+    if not sample_logits or top_k is None:
+        if top_k is not None:
+            logits = top_k_top_p_filtering(logits, top_k=top_k, top_p=1.0 if top_p is None else top_p)
+        probs = F.softmax(logits, dim=-1)
+        if not sample_logits:
+            return torch.topk(probs, k=1, dim=-1)[1]
+        return torch.multinomial(probs, num_samples=1)
+    V = logits.size(-1)
+    top_p = 1.0 if top_p is None else top_p
+    sl, si = torch.sort(logits, descending=True)
+    if top_k > 0:
+        k = min(max(top_k, 1), V)
+        sl = sl.masked_fill(sl < sl[..., k - 1, None], -float("inf"))
+    if top_p < 1.0:
+        cum = torch.cumsum(F.softmax(sl, dim=-1), dim=-1)
+        remove = cum > top_p
+        remove = torch.cat((torch.zeros_like(remove[..., :1]), remove[..., :-1]), dim=-1)
+        sl = sl.masked_fill(remove, -float("inf"))
+    rank = torch.multinomial(F.softmax(sl, dim=-1), num_samples=1)
+    return si.gather(-1, rank)
 
 
 @torch.no_grad()
