@@ -114,6 +114,19 @@ def main():
         prep = ops.vq_prepare(E)
         ms = timeit(lambda: ops.vq_argmin(z, E, prep), a.iters)
         res["vq_argmin"] = (ms, 2.0 * L * 8192 * 8 / ms / 1e9, "TF")
+    # ---- library baselines on the same shapes (only when asked for by name): PyTorch-ROCm fp32 ----
+    # torch.mm dispatches to rocBLAS / hipBLASLt sgemm, F.scaled_dot_product_attention to its fp32 path
+    if "lib_gemm" in a.names:
+        torch.backends.cuda.matmul.allow_tf32 = False
+        for nm, N, K in (("lib_sgemm_ff_in", 2730, D), ("lib_sgemm_kv", 2 * D, D), ("lib_sgemm_q", D, D),
+                         ("lib_sgemm_ff_out", D, 1365)):
+            aa, w = r(L, K), r(N, K) * 0.04
+            ms = timeit(lambda: torch.mm(aa, w.t()), a.iters)
+            res[nm] = (ms, 2.0 * L * N * K / ms / 1e9, "TF")
+    if "lib_sdpa" in a.names:
+        q4 = torch.nn.functional.normalize(r(a.clips * 5, 8, 1024, 64), dim=-1)
+        ms = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q4, q4, q4, scale=8.0), max(2, a.iters // 3))
+        res["lib_sdpa_spatial"] = (ms, 4.0 * a.clips * 5 * 8 * 1024 * 1024 * 64 / ms / 1e9, "TF")
     for k, (ms, rate, unit) in res.items():
         print(f"{k:16s} {ms:9.4f} ms  {rate:9.2f} {unit}")
 
