@@ -55,7 +55,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL on ROCm
+        dist.init_process_group("nccl")  # RCCL on ROCm (lazy communicator init on the device set above)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
@@ -87,7 +87,7 @@ def main():
 
     def sync():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -234,7 +234,7 @@ def main():
                              "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 
