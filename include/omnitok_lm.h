@@ -53,6 +53,15 @@ int64_t omnitok_lm_cache_bytes(omnitok_lm *lm);
 int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
                     float *logits_out, int advance, omnitok_stream_t stream);
 
+/* Batched prefill of a conditioning prefix into EMPTY streams (GPT.forward / the first
+ * forward_with_past call of the reference, gpt.py:207-275, positions 0..T-1): idx[B, T] int64.
+ * Same arithmetic as T decode steps, executed as [B*T]-row fp32-MFMA GEMMs (omnitok_gemm) + causal
+ * flash attention over the cache.  Fills the K/V cache, sets pos[b] = cache_len[b] = T on the
+ * device.  logits_out (optional) [B, T, vocab]: teacher-forced logits of every position.
+ * B * T <= 65535; may hipMalloc its (grow-only) workspace. */
+int omnitok_lm_prefill(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
+                       int T, float *logits_out, omnitok_stream_t stream);
+
 /* building blocks, exported for the parity tests */
 /* y[b, n] = act(sum_k x[b, k] * w[n, k] + bias[n]) (+ residual[b, n]);  act: 0 none, 1 exact-erf
  * GELU (nn.GELU(), gpt.py:152).  B <= 16, K % 256 == 0.  If ln_gamma != NULL, x is layer-normalised

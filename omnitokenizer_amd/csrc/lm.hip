@@ -229,22 +229,26 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
 template <int F4>
 __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
                                                              const int32_t *__restrict__ cache_len, int n_head,
-                                                             int max_len, int max_batch_stride /*unused*/,
+                                                             int max_len, int prefill_T,
                                                              float *__restrict__ part, int nchunk) {
     constexpr int HD = F4 * 32;
-    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int len = cache_len[b];        // entries already in the cache; the new token goes to index len
+    // decode: one query row per stream (row == b), len = cache_len[b].  prefill (prefill_T > 0): row =
+    // b * T + t is query position t of stream b; its keys 0..t-1 are already in the cache (scattered by
+    // lm_kv_scatter_kernel), key t is the row's own K/V
+    const int c = blockIdx.x, h = blockIdx.y, row = blockIdx.z;
+    const int b = prefill_T > 0 ? row / prefill_T : row;
+    const int len = prefill_T > 0 ? row - b * prefill_T : cache_len[row];
     const int total = len + 1;
     if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
     const int C = n_head * HD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = lane >> 3, ds = lane & 7;  // key slot 0..7, dim slot 0..7
-    const float *qn = qkv + (int64_t)b * 3 * C + h * HD;
+    const float *qn = qkv + (int64_t)row * 3 * C + h * HD;
     const float *kn = qn + C, *vn = qn + 2 * C;
     float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
     float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
     // append the new token's K/V (only the workgroup whose chunk holds index len)
-    if (len >= c * LM_CHUNK && len < (c + 1) * LM_CHUNK && len < max_len) {
+    if (prefill_T == 0 && len >= c * LM_CHUNK && len < (c + 1) * LM_CHUNK && len < max_len) {
         for (int d = tid; d < HD; d += 256) {
             krow[(int64_t)len * HD + d] = kn[d];
             vrow[(int64_t)len * HD + d] = vn[d];
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
             L += s_l[wv] * f;
             O += s_o[wv][tid] * f;
         }
-        float *pp = part + (((int64_t)b * n_head + h) * nchunk + c) * (2 + HD);
+        float *pp = part + (((int64_t)row * n_head + h) * nchunk + c) * (2 + HD);
         pp[2 + tid] = O;
         if (tid == 0) {
             pp[0] = M;
@@ -339,10 +343,10 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
 }
 
 __global__ void lm_attn_merge_kernel(const float *__restrict__ part, const int32_t *__restrict__ cache_len, int n_head,
-                                     int HD, int nchunk, float *__restrict__ out) {
-    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+                                     int HD, int nchunk, int prefill_T, float *__restrict__ out) {
+    const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;  // b: query row
     if (d >= HD) return;
-    const int total = cache_len[b] + 1;
+    const int total = (prefill_T > 0 ? b % prefill_T : cache_len[b]) + 1;
     const int used = (total + LM_CHUNK - 1) / LM_CHUNK;
     const float *pp = part + ((int64_t)b * n_head + h) * nchunk * (2 + HD);
     float M = -INFINITY;
@@ -354,6 +358,80 @@ __global__ void lm_attn_merge_kernel(const float *__restrict__ part, const int32
         O += pp[c * (2 + HD) + 2 + d] * f;
     }
     out[((int64_t)b * n_head + h) * HD + d] = O / L;
+}
+
+// ---- batched prefill of a conditioning prefix (the same arithmetic as T decode steps, as GEMMs) ------
+__global__ __launch_bounds__(256) void lm_embed_seq_kernel(const int64_t *__restrict__ idx, const float *__restrict__ tok,
+                                                           const float *__restrict__ pe, float *__restrict__ x, int T,
+                                                           int C, int vocab) {
+    const int64_t row = blockIdx.x;  // b * T + t
+    const int t = (int)(row % T);
+    int64_t id = idx[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    for (int i = threadIdx.x * 4; i < C; i += 256 * 4)
+        *reinterpret_cast<f32x4 *>(x + row * C + i) = *reinterpret_cast<const f32x4 *>(tok + id * C + i) +
+                                                     *reinterpret_cast<const f32x4 *>(pe + (int64_t)t * C + i);
+}
+
+// nn.LayerNorm over rows of any width (two-pass, eps 1e-5): one wave per row
+__global__ __launch_bounds__(256) void lm_layernorm_rows_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                                const float *__restrict__ beta, float *__restrict__ y,
+                                                                int64_t rows, int K) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * K;
+    float s = 0.0f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + k);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_allsum(s) / (float)K;
+    float q = 0.0f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(xr + k);
+        const float a0 = v[0] - mean, a1 = v[1] - mean, a2 = v[2] - mean, a3 = v[3] - mean;
+        q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+    const float rstd = 1.0f / sqrtf(wave_allsum(q) / (float)K + 1e-5f);
+    for (int k = lane * 4; k < K; k += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(xr + k);
+        const f32x4 g4 = *reinterpret_cast<const f32x4 *>(g + k), b4 = *reinterpret_cast<const f32x4 *>(beta + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (v[e] - mean) * rstd * g4[e] + b4[e];
+        *reinterpret_cast<f32x4 *>(y + row * K + k) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void lm_gelu_kernel(float *__restrict__ x, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<f32x4 *>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    reinterpret_cast<f32x4 *>(x)[i] = v;
+}
+
+// qkv[B*T, 3C] (query | key | value) -> K/V cache rows [b][h][t][hd]
+__global__ __launch_bounds__(256) void lm_kv_scatter_kernel(const float *__restrict__ qkv, float *__restrict__ kc,
+                                                            float *__restrict__ vc, int T, int n_head, int hd,
+                                                            int max_len) {
+    const int64_t row = blockIdx.x;  // b * T + t
+    const int b = (int)(row / T), t = (int)(row % T), C = n_head * hd;
+    for (int i = threadIdx.x * 4; i < C; i += 256 * 4) {
+        const int h = i / hd, d = i - h * hd;
+        const int64_t dst = (((int64_t)b * n_head + h) * max_len + t) * hd + d;
+        *reinterpret_cast<f32x4 *>(kc + dst) = *reinterpret_cast<const f32x4 *>(qkv + row * 3 * C + C + i);
+        *reinterpret_cast<f32x4 *>(vc + dst) = *reinterpret_cast<const f32x4 *>(qkv + row * 3 * C + 2 * C + i);
+    }
+}
+
+__global__ void lm_set_len_kernel(int32_t *pos, int32_t *cache_len, int B, int T) {
+    const int b = threadIdx.x;
+    if (b < B) {
+        pos[b] = T;
+        cache_len[b] = T;
+    }
 }
 
 __global__ void lm_advance_kernel(int32_t *pos, int32_t *cache_len, int B) {
@@ -460,26 +538,29 @@ extern "C" int omnitok_lm_gemv(const float *x, const float *w, const float *bias
 }
 
 // chunk partials only (the engine merges them inside the proj GEMV)
+// prefill_T > 0: B * prefill_T query rows (row = b * T + t, keys 0..t), chunks sized for T keys
 static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B, int n_head,
-                            int head_dim, int max_len, float *scratch, hipStream_t stream) {
-    OT_CHECK_ARG(qkv && kc && vc && cache_len && scratch, "lm_attn_decode: null pointer");
+                            int head_dim, int max_len, float *scratch, hipStream_t stream, int prefill_T = 0) {
+    OT_CHECK_ARG(qkv && kc && vc && (cache_len || prefill_T > 0) && scratch, "lm_attn_decode: null pointer");
     OT_CHECK_ARG(head_dim == 64 || head_dim == 96 || head_dim == 128, "lm_attn_decode: head_dim %d (64 | 96 | 128)",
                  head_dim);
     OT_CHECK_ARG(max_len > 0 && n_head > 0, "lm_attn_decode: bad sizes");
-    const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
-    const dim3 grid(nchunk, n_head, B);
+    const int nchunk = ((prefill_T > 0 ? prefill_T : max_len) + LM_CHUNK - 1) / LM_CHUNK;
+    const int rows = prefill_T > 0 ? B * prefill_T : B;
+    OT_CHECK_ARG(rows <= 65535, "lm_attn_decode: %d query rows (max 65535)", rows);
+    const dim3 grid(nchunk, n_head, rows);
     switch (head_dim) {
         case 64:
             hipLaunchKernelGGL(lm_attn_decode_kernel<2>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, 0, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk);
             break;
         case 96:
             hipLaunchKernelGGL(lm_attn_decode_kernel<3>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, 0, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk);
             break;
         default:
             hipLaunchKernelGGL(lm_attn_decode_kernel<4>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, 0, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk);
             break;
     }
     OT_LAUNCH_CHECK("lm_attn_decode");
@@ -495,7 +576,7 @@ extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, co
     if (int rc = lm_attn_partials(qkv, kc, vc, cache_len, B, n_head, head_dim, max_len, scratch, stream)) return rc;
     const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
     hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(n_head, B), dim3(128), 0, stream, scratch, cache_len, n_head, head_dim,
-                       nchunk, out);
+                       nchunk, 0, out);
     OT_LAUNCH_CHECK("lm_attn_merge");
     return OMNITOK_OK;
 }
@@ -521,6 +602,9 @@ struct omnitok_lm {
     int max_batch = 0, max_len = 0;
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *part = nullptr;
     int64_t cache_bytes = 0;
+    // grow-only prefill workspace (rows = B * T)
+    float *pf = nullptr;
+    int64_t pf_floats = 0;
 };
 
 static const float *LW(omnitok_lm *lm, const std::string &k) {
@@ -567,7 +651,8 @@ extern "C" int omnitok_lm_create(const omnitok_lm_config *cfg, omnitok_lm **out)
 }
 
 static void lm_free_cache(omnitok_lm *lm) {
-    for (float **p : {&lm->kv, &lm->x, &lm->qkv, &lm->att, &lm->hid, &lm->part})
+    lm->pf_floats = 0;
+    for (float **p : {&lm->kv, &lm->x, &lm->qkv, &lm->att, &lm->hid, &lm->part, &lm->pf})
         if (*p) {
             (void)hipFree(*p);
             *p = nullptr;
@@ -739,5 +824,80 @@ extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos,
         hipLaunchKernelGGL(lm_advance_kernel, dim3(1), dim3(64), 0, stream, pos, cache_len, B);
         OT_LAUNCH_CHECK("lm_advance");
     }
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_prefill(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B, int T,
+                                  float *logits_out, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(lm, "lm_prefill: null engine");
+    if (B == 0 || T == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(idx && pos && cache_len, "lm_prefill: null pointer");
+    if (!lm->finalized) {
+        set_error("lm_prefill: engine not finalised (load the weights first)");
+        return OMNITOK_ERR_STATE;
+    }
+    if (!lm->kv || B > lm->max_batch || T > lm->max_len) {
+        set_error("lm_prefill: cache not allocated for %d streams x %d tokens (omnitok_lm_alloc_cache)", B, T);
+        return OMNITOK_ERR_STATE;
+    }
+    const omnitok_lm_config &c = lm->cfg;
+    OT_CHECK_ARG(T <= c.block_size, "lm_prefill: %d tokens exceed block_size %d", T, c.block_size);
+    const int C = c.n_embd, hd = C / c.n_head, V = c.vocab_size;
+    const int64_t M = (int64_t)B * T;
+    OT_CHECK_ARG(M <= 65535, "lm_prefill: B * T = %lld rows (max 65535)", (long long)M);
+    const int nchunk = (T + LM_CHUNK - 1) / LM_CHUNK;
+    // workspace: x | xn | att [M, C], qkv [M, 3C], hid [M, 4C], partials
+    const int64_t need = M * C * 3 + M * 3 * C + M * 4 * C + M * c.n_head * nchunk * (2 + hd);
+    if (lm->pf_floats < need) {
+        if (lm->pf) OT_HIP(hipFree(lm->pf));
+        lm->pf = nullptr;
+        lm->pf_floats = 0;
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&lm->pf), (size_t)need * 4));
+        lm->pf_floats = need;
+    }
+    float *x = lm->pf, *xn = x + M * C, *att = xn + M * C, *qkv = att + M * C, *hid = qkv + M * 3 * C,
+          *part = hid + M * 4 * C;
+    const int64_t per_layer = (int64_t)lm->max_batch * c.n_head * lm->max_len * hd;
+    const dim3 ln_grid((unsigned)((M + 3) / 4));
+    hipLaunchKernelGGL(lm_embed_seq_kernel, dim3((unsigned)M), dim3(256), 0, stream, idx, LW(lm, "tok_emb.weight"),
+                       LW(lm, "pos_emb"), x, T, C, V);
+    OT_LAUNCH_CHECK("lm_embed_seq");
+    const int BR = OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL;
+    for (int i = 0; i < c.n_layer; ++i) {
+        const LmLayer &L = lm->layers[i];
+        float *kc = lm->kv + (int64_t)(2 * i) * per_layer, *vc = kc + per_layer;
+        hipLaunchKernelGGL(lm_layernorm_rows_kernel, ln_grid, dim3(256), 0, stream, x, L.ln1w, L.ln1b, xn, M, C);
+        OT_LAUNCH_CHECK("lm_layernorm_rows");
+        if (int rc = omnitok_gemm(xn, C, L.wqkv, C, L.bqkv, nullptr, 0, qkv, 3 * C, M, 3 * C, C, OMNITOK_GEMM_BIAS, 0, 0,
+                                  0, stream))
+            return rc;
+        hipLaunchKernelGGL(lm_kv_scatter_kernel, dim3((unsigned)M), dim3(256), 0, stream, qkv, kc, vc, T, c.n_head, hd,
+                           lm->max_len);
+        OT_LAUNCH_CHECK("lm_kv_scatter");
+        if (int rc = lm_attn_partials(qkv, kc, vc, nullptr, B, c.n_head, hd, lm->max_len, part, stream, T)) return rc;
+        hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(c.n_head, (unsigned)M), dim3(128), 0, stream, part, nullptr,
+                           c.n_head, hd, nchunk, T, att);
+        OT_LAUNCH_CHECK("lm_attn_merge");
+        if (int rc = omnitok_gemm(att, C, L.wproj, C, L.bproj, x, C, x, C, M, C, C, BR, 0, 0, 0, stream)) return rc;
+        hipLaunchKernelGGL(lm_layernorm_rows_kernel, ln_grid, dim3(256), 0, stream, x, L.ln2w, L.ln2b, xn, M, C);
+        OT_LAUNCH_CHECK("lm_layernorm_rows");
+        if (int rc = omnitok_gemm(xn, C, L.w1, C, L.b1, nullptr, 0, hid, 4 * C, M, 4 * C, C, OMNITOK_GEMM_BIAS, 0, 0, 0,
+                                  stream))
+            return rc;
+        hipLaunchKernelGGL(lm_gelu_kernel, dim3((unsigned)((M * C + 255) / 256)), dim3(256), 0, stream, hid, M * C);
+        OT_LAUNCH_CHECK("lm_gelu");
+        if (int rc = omnitok_gemm(hid, 4 * C, L.w2, 4 * C, L.b2, x, C, x, C, M, C, 4 * C, BR, 0, 0, 0, stream)) return rc;
+    }
+    if (logits_out) {
+        hipLaunchKernelGGL(lm_layernorm_rows_kernel, ln_grid, dim3(256), 0, stream, x, LW(lm, "ln_f.weight"),
+                           LW(lm, "ln_f.bias"), xn, M, C);
+        OT_LAUNCH_CHECK("lm_layernorm_rows");
+        if (int rc = omnitok_gemm(xn, C, LW(lm, "head.weight"), C, nullptr, nullptr, 0, logits_out, V, M, V, C, 0, 0, 0, 0,
+                                  stream))
+            return rc;
+    }
+    hipLaunchKernelGGL(lm_set_len_kernel, dim3(1), dim3(64), 0, stream, pos, cache_len, B, T);
+    OT_LAUNCH_CHECK("lm_set_len");
     return OMNITOK_OK;
 }

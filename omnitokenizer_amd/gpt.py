@@ -200,6 +200,31 @@ class GPT(nn.Module):
                                           int(advance), torch.cuda.current_stream().cuda_stream), "lm_step")
         return logits if want_logits else None
 
+    def prefill(self, idx, want_logits=False):
+        """Feeds idx [B, T] into EMPTY streams in one batched pass (GEMMs + causal flash attention,
+        include/omnitok_lm.h omnitok_lm_prefill): same arithmetic as T steps.  Returns the
+        teacher-forced logits [B, T, vocab] if want_logits."""
+        B, T = idx.shape
+        idx = idx.contiguous()
+        logits = torch.empty(B, T, self.vocab_size, device=idx.device, dtype=torch.float32) if want_logits else None
+        check(_lib.load().omnitok_lm_prefill(self._engine, ctypes.c_void_p(idx.data_ptr()),
+                                             ctypes.c_void_p(self._pos.data_ptr()), ctypes.c_void_p(self._len.data_ptr()),
+                                             B, T, None if logits is None else ctypes.c_void_p(logits.data_ptr()),
+                                             torch.cuda.current_stream().cuda_stream), "lm_prefill")
+        return logits
+
+    def _feed(self, idx):
+        """Conditioning tokens idx [B, T] into empty streams: batched prefill, or plain steps when
+        the prefix is short (or too large for one prefill launch)."""
+        B, T = idx.shape
+        if T == 0:
+            return
+        if T >= 8 and B * T <= 65535:
+            self.prefill(idx)
+        else:
+            for t in range(T):
+                self.step(idx[:, t].contiguous(), want_logits=False)
+
     def graph_step(self, B):
         """(idx_buffer, logits_buffer, replay) for a captured decode step of B streams: write the next
         tokens into idx_buffer, call replay(), read logits_buffer.  The step advances pos / cache_len on
@@ -226,16 +251,19 @@ class GPT(nn.Module):
     @torch.no_grad()
     def forward(self, idx, embeddings=None, targets=None, cbox=None, tbox=None):
         """reference gpt.py:207-234: logits [B, T, V] of a whole sequence (teacher-forced), computed by
-        walking the KV-cached step over the T positions (same arithmetic as forward_with_past)."""
+        the batched prefill (same arithmetic as walking the KV-cached step over the T positions)."""
         if embeddings is not None or cbox is not None or tbox is not None:
             raise NotImplementedError("explicit embeddings / vtokens_pos boxes are not built")
         B, T = idx.shape
         assert T <= self.block_size, "Cannot forward, model block size is exhausted."
         self.reset_streams(B, T)
         idx = idx.to(self.device).long()
-        out = torch.empty(B, T, self.vocab_size, device=self.device, dtype=torch.float32)
-        for t in range(T):
-            out[:, t] = self.step(idx[:, t].contiguous())
+        if B * T <= 65535:
+            out = self.prefill(idx, want_logits=True)
+        else:
+            out = torch.empty(B, T, self.vocab_size, device=self.device, dtype=torch.float32)
+            for t in range(T):
+                out[:, t] = self.step(idx[:, t].contiguous())
         loss = None
         if targets is not None:
             loss = F.cross_entropy(out.view(-1, out.size(-1)), targets.view(-1))
@@ -254,8 +282,7 @@ class GPT(nn.Module):
         B, T = idx.shape
         if past is None:
             self.reset_streams(B, self.block_size + 1)
-            for t in range(T - 1):
-                self.step(idx[:, t].contiguous(), want_logits=False)
+            self._feed(idx[:, :T - 1])
             logits = self.step(idx[:, T - 1].contiguous())
             out = torch.zeros(B, T, self.vocab_size, device=self.device) if T > 1 else None
             if out is not None:
@@ -309,8 +336,7 @@ def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, t
     x = x.to(model.device).long()
     B, cond_len = x.shape
     model.reset_streams(B, cond_len + steps)
-    for t in range(cond_len - 1):
-        model.step(x[:, t].contiguous(), want_logits=False)
+    model._feed(x[:, :cond_len - 1])
     if use_graph:
         idx_buf, logits_buf, replay = model.graph_step(B)
     nxt = x[:, -1].contiguous()

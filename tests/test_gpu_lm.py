@@ -136,6 +136,43 @@ def test_gpt_reference_calling_pattern_and_logits(gpts):
     assert torch.equal(sample[:, cond_len:].cpu(), ref_tok)
 
 
+@pytest.mark.parametrize("name", GPT_CASES)
+def test_prefill_equals_steps(gpts, name):
+    """The batched prefill and T single-token steps leave the same cache behind and give the same
+    logits (different summation orders only), including a prefix that spans several 256-key chunks."""
+    m, g, sd, H = gpts(name)
+    V, BS = m.vocab_size, m.block_size
+    T = min(BS - 2, 40)
+    idx = torch.randint(0, V, (3, T), generator=torch.Generator().manual_seed(11)).cuda()
+    m.reset_streams(3, T + 4)
+    stepped = torch.stack([m.step(idx[:, t].contiguous()) for t in range(T)], 1)
+    nxt = torch.randint(0, V, (3,), generator=torch.Generator().manual_seed(12)).cuda()
+    after_steps = m.step(nxt)
+    m.reset_streams(3, T + 4)
+    batched = m.prefill(idx, want_logits=True)
+    after_prefill = m.step(nxt)
+    assert (batched - stepped).abs().max().item() < LOGIT_TOL
+    assert (after_prefill - after_steps).abs().max().item() < LOGIT_TOL
+    ref = go.forward(sd, torch.cat([idx.cpu(), nxt.cpu()[:, None]], 1), H)
+    assert (batched.cpu() - ref[:, :T]).abs().max().item() < LOGIT_TOL
+    assert (after_prefill.cpu() - ref[:, T]).abs().max().item() < LOGIT_TOL
+
+
+def test_prefill_long_prefix_multi_chunk():
+    """600-token prefix (3 attention chunks) on a 1-layer model: prefill + sampling vs the oracle."""
+    from omnitokenizer_amd import gpt as og
+    V, BS, L, H, C = 256, 700, 1, 4, 256
+    sd = go.synth_gpt_state(V, BS, L, H, C, seed=21)
+    m = og.GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = torch.randint(0, V, (2, 600), generator=torch.Generator().manual_seed(22))
+    new, lg = og.sample_with_past(x.cuda(), m, 6, sample_logits=False, return_logits=True)
+    ref, rlg = go.sample_with_past(sd, x, H, 6, sample_logits=False, return_logits=True)
+    assert (lg.cpu() - rlg).abs().max().item() < LOGIT_TOL
+    assert torch.equal(new.cpu(), ref)
+
+
 def test_gpt_stochastic_sampling_statistics(gpts):
     """multinomial sampling: tokens are valid, reproducible under a seed, and respect top-k."""
     from omnitokenizer_amd import gpt as og

@@ -86,6 +86,7 @@ def main():
                      "unit": "GB/s", "step_ms": round(step_ms, 4), "weight_bytes": weight_bytes, "kv_bytes": kv_bytes,
                      "traffic": None},
         "kv_cache_gb": round(m.cache_bytes() / 2**30, 2),
+        "prefill_ms": round(t_prefill * 1e3, 2),  # a.ctx prefix tokens (batched prefill) + 1 sampled token
     }
     out_json["roofline"]["frac"] = round(out_json["roofline"]["achieved"] / PEAK_HBM_GBS, 4)
     if not a.no_cpu_baseline:
