@@ -19,6 +19,7 @@ namespace omnitok {
 
 constexpr int VQ_ROWS_PER_WAVE = 64;
 constexpr int VQ_ROWS_PER_BLOCK = 256;
+int g_vq_split = 0;  // 0 = automatic
 
 __global__ void vq_prepare_kernel(const float *__restrict__ E, int n_codes, float *__restrict__ packed,
                                   float *__restrict__ ee) {
@@ -39,6 +40,18 @@ __global__ void vq_prepare_kernel(const float *__restrict__ E, int n_codes, floa
     }
 }
 
+// SPLIT: the code range is divided over gridDim.y workgroups per row block (load balance: 64 rows x
+// all codes is ~150 us of work per wave, so whole-range units quantise badly over the chip's wave
+// slots -- 2560 units on 2048 slots at C3 -- and leave small batches on a handful of CUs).  Each split
+// merges its (distance, index) into ids[row] with a 64-bit atomicMin on (order-preserving distance
+// key << 32 | index): the lexicographic minimum is exactly "first minimum" (reference codebook.py:86),
+// whatever the arrival order.  ids must be pre-set to all ones; vq_finalize_kernel strips the key.
+__device__ __forceinline__ unsigned order_key(float d) {
+    const unsigned u = __float_as_uint(d);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restrict__ z,
                                                            const float *__restrict__ packed,
                                                            const float *__restrict__ ee_g, int64_t n, int n_codes,
@@ -46,8 +59,14 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     extern __shared__ __attribute__((aligned(16))) float ee_s[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, hi = lane >> 5;
-    for (int i = tid * 4; i < n_codes; i += 256 * 4)
-        *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + i);
+    const int ntiles_all = n_codes >> 5;
+    const int tiles_per = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t0 = SPLIT ? (int)blockIdx.y * tiles_per : 0;
+    const int t1 = SPLIT ? (t0 + tiles_per < ntiles_all ? t0 + tiles_per : ntiles_all) : ntiles_all;
+    if (t0 >= t1) return;
+    const int c0 = t0 * 32;  // first code of this split; ee_s holds ee[c0 .. t1*32)
+    for (int i = tid * 4; i < (t1 - t0) * 32; i += 256 * 4)
+        *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + c0 + i);
     __syncthreads();
 
     const int64_t row_base = (int64_t)blockIdx.x * VQ_ROWS_PER_BLOCK + wave * VQ_ROWS_PER_WAVE;
@@ -75,11 +94,10 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     }
 
     const f32x4 *pk = reinterpret_cast<const f32x4 *>(packed) + lane;
-    const int ntiles = n_codes >> 5;
-    f32x4 a_next = pk[0];
-    for (int t = 0; t < ntiles; ++t) {
+    f32x4 a_next = pk[(int64_t)t0 * 64];
+    for (int t = t0; t < t1; ++t) {
         const f32x4 a = a_next;
-        if (t + 1 < ntiles) a_next = pk[(int64_t)(t + 1) * 64];
+        if (t + 1 < t1) a_next = pk[(int64_t)(t + 1) * 64];
         f32x16 acc[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -92,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         const int cbase = t * 32 + 4 * hi;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ee_s + cbase + 8 * q);
+            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ee_s + cbase - c0 + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int code = cbase + 8 * q + e;
@@ -116,8 +134,19 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
             bidx[g] = oi;
         }
         const int64_t row = row_base + g * 32 + r32;
-        if (hi == 0 && row < n) ids[row] = (int64_t)bidx[g];
+        if (hi == 0 && row < n) {
+            if (SPLIT)
+                atomicMin(reinterpret_cast<unsigned long long *>(ids + row),
+                          ((unsigned long long)order_key(best[g]) << 32) | (unsigned)bidx[g]);
+            else
+                ids[row] = (int64_t)bidx[g];
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void vq_finalize_kernel(int64_t *__restrict__ ids, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids[i] &= 0xFFFFFFFFll;
 }
 
 // z = l2norm(x W^T + b): one 16-lane DPP row per token row
@@ -384,17 +413,36 @@ extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const floa
     OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin: n_codes=%d unsupported", n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin: unaligned");
     if (n == 0) return OMNITOK_OK;
-    const int lds = n_codes * 4;
+    const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
+    // code-range splits: aim at >= 2048 workgroups (whole rounds of the chip's 512 two-per-CU slots at the
+    // BASELINE sizes: C3 640 x 4 = 5 rounds, C2 256 x 8 = 4 rounds), at least 16 tiles (512 codes) each
+    const int ntiles = n_codes >> 5;
+    int nsplit = 1;
+    while (nsplit < 16 && blocks * nsplit < 2048 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
+    if (g_vq_split >= 1) nsplit = g_vq_split;  // "vq_split" option: force (tests / A-B)
+    if (nsplit > ntiles) nsplit = ntiles;
+    const int tiles_per = (ntiles + nsplit - 1) / nsplit;
+    const int lds = tiles_per * 32 * 4;
     static int attr_bytes = 0;
-    if (lds > attr_bytes) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel),
+    if (lds > attr_bytes && lds > 65536) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_bytes = lds;
     }
-    const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
-    hipLaunchKernelGGL(vq_argmin_kernel, dim3((unsigned)blocks), dim3(256), lds, stream, z, packed, ee, n, n_codes,
-                       ids);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL(vq_argmin_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, stream, z, packed, ee, n,
+                           n_codes, ids);
+        OT_LAUNCH_CHECK("vq_argmin");
+        return OMNITOK_OK;
+    }
+    OT_HIP(hipMemsetAsync(ids, 0xFF, (size_t)n * 8, stream));
+    hipLaunchKernelGGL(vq_argmin_kernel<true>, dim3((unsigned)blocks, nsplit), dim3(256), lds, stream, z, packed, ee, n,
+                       n_codes, ids);
     OT_LAUNCH_CHECK("vq_argmin");
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n);
+    OT_LAUNCH_CHECK("vq_finalize");
     return OMNITOK_OK;
 }
 

@@ -449,6 +449,27 @@ def test_vq_argmin_bit_exact_vs_reference_kat(ops, n_codes):
     assert ops.vq_argmin(dev(z[:0]), dev(E)).numel() == 0
 
 
+@pytest.mark.parametrize("split", [1, 2, 4, 16, 3])
+def test_vq_argmin_code_range_splits(ops, split):
+    """The load-balancing code-range split (64-bit atomicMin merge of distance key | index) returns
+    the same first-minimum ids whatever the number of splits, ties included."""
+    from omnitokenizer_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "vq_kat_8192.npz"))
+    z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
+    _lib.set_option("vq_split", split)
+    try:
+        for n in (6144, 1000, 31):
+            ids = ops.vq_argmin(dev(z[:n]), dev(E)).cpu().numpy()
+            assert np.array_equal(ids, ids_ref[:n]), f"split {split}, n {n}: {(ids != ids_ref[:n]).sum()} differ"
+        # exact duplicates far apart in the codebook land in different splits: lowest index wins
+        E2 = E.clone()
+        E2[8000] = E2[100]
+        zz = E2[[100, 8000, 100]].contiguous()
+        assert ops.vq_argmin(dev(zz), dev(E2)).cpu().tolist() == [100, 100, 100]
+    finally:
+        _lib.set_option("vq_split", 0)
+
+
 def test_vq_argmin_large_random_vs_c_oracle(ops):
     rng = np.random.default_rng(5)
     E = rng.standard_normal((8192, 8), dtype=np.float32)
