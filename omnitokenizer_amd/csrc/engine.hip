@@ -652,7 +652,7 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
         set_error("engine_create: need codebook_dim == 8 and n_codes %% 32 == 0 (<= 32768)");
         return OMNITOK_ERR_UNSUPPORTED;
     }
-    if (c.window_size != 8) {
+    if (c.window_size != 8 && (strchr(c.enc_block, 'w') || strchr(c.dec_block, 'w'))) {
         set_error("engine_create: window attention is built for twod_window_size == 8 (got %d)", c.window_size);
         return OMNITOK_ERR_UNSUPPORTED;
     }

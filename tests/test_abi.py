@@ -109,3 +109,29 @@ def test_vae_state_dict_contract(lib):
     assert tuple(m.state_dict()["pre_vq_conv.1.bias"].shape) == (16,)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.encode(torch.zeros(1, 3, 64, 64), True)
+
+
+def test_load_from_pl_checkpoint(tmp_path, lib):
+    """PL-style checkpoints ({state_dict, hyper_parameters: {args}}, reference omnitokenizer.py:208,
+    download.py:49) load through the drop-in class, off-path entries dropped, stale Namespaces
+    back-filled like the reference's hasattr() defaults (omnitokenizer.py:70-98)."""
+    import argparse
+    import torch
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    args = make_args(1, resolution=64)
+    cfg = OmniTokConfig.from_args(args)
+    sd = dict(synth.synth_state_dict(cfg, seed=7))
+    sd["image_discriminator.main.0.weight"] = torch.zeros(3)
+    sd["perceptual_model.net.slice1.0.weight"] = torch.zeros(3)
+    old = argparse.Namespace(**{k: v for k, v in vars(args).items()
+                                if k not in ("enc_block", "dec_block", "twod_window_size", "spatial_pos", "use_vae",
+                                             "defer_temporal_pool", "defer_spatial_pool", "gen_upscale")})
+    path = tmp_path / "tok.ckpt"
+    torch.save({"state_dict": sd, "hyper_parameters": {"args": old}}, path)
+    m = OmniTokenizer_VQGAN.load_from_checkpoint(str(path), attention_mode="legacy")
+    assert m.cfg.enc_block == "tttt" and m.cfg.window_size == 4 and m.cfg.spatial_pos == "rel"  # back-filled
+    assert m.cfg.attention_mode == "legacy" and not m.use_vae
+    got = m.state_dict()
+    assert all(torch.equal(got[k], v) for k, v in sd.items() if k in got)
+    assert not any(k.startswith(("image_discriminator", "perceptual_model")) for k in got)
