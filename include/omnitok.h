@@ -198,6 +198,12 @@ int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, float *pack
 int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
                       int64_t *ids, omnitok_stream_t stream);
 
+/* --use_external_codebook (cosine similarity): ids[n] = first argmax_c sum_k z[n,k] E[c,k]  (reference
+ * quantizer/vector_quantize_pytorch.py:646-650: einsum + argmax; z and E rows unit-norm).  Same kernel
+ * and the same k-ordered FMA chain as omnitok_vq_argmin; packed from omnitok_vq_prepare(E). */
+int omnitok_vq_argmax_cos(const float *z, const float *packed, int64_t n, int n_codes, int64_t *ids,
+                          omnitok_stream_t stream);
+
 /* tok[n, :] = E[ids[n], :] . w[D, cdim]^T + b  (F.embedding + post_vq_conv, reference
  * omnitokenizer.py:270, 156-160). Returns OMNITOK_ERR_INVALID through the status word
  * err_flag[0] != 0 if an id is out of range (checked on device, reported at the next sync). */
@@ -267,6 +273,10 @@ typedef struct omnitok_config {
     int defer_temporal_pool;   /* --defer_temporal_pool (omnitokenizer.py:792-797, 985-990), linear only */
     int defer_spatial_pool;    /* --defer_spatial_pool  (omnitokenizer.py:799-804, 992-1003), linear only */
     int gen_upscale;           /* --gen_upscale: decoder patch_size *= gen_upscale (0 / 1 = off) */
+    int external_codebook;     /* --use_external_codebook with l2_code: VectorQuantize / CosineSimCodebook
+                                * (quantizer/vector_quantize_pytorch.py): weights codebook.project_in / project_out /
+                                * _codebook.embed replace pre_vq_conv / post_vq_conv / codebook.embeddings;
+                                * omnitok_encode's emb_out is then project_out(embed[ids]) as [B,T',h,w,dim] */
 } omnitok_config;
 
 int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine **out);

@@ -22,7 +22,7 @@ class OmnitokConfig(Structure):
         ("causal_temporal", c_int), ("causal_peg", c_int), ("temporal_depth", c_int),
         ("enc_block", c_char * 16), ("dec_block", c_char * 16), ("use_vae", c_int),
         ("patch_embed_cnn", c_int), ("defer_temporal_pool", c_int), ("defer_spatial_pool", c_int),
-        ("gen_upscale", c_int),
+        ("gen_upscale", c_int), ("external_codebook", c_int),
     ]
 
 
@@ -58,6 +58,7 @@ _PROTOS = {
     "omnitok_pre_vq": [P, P, P, P, I64, c_int, c_int, c_int, P],
     "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
+    "omnitok_vq_argmax_cos": [P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
     "omnitok_token_resample": [P, P, c_int, I64, c_int, c_int, c_int, c_int, P],
     "omnitok_vae_sample": [P, P, P, P, P, P, I64, I64, c_int, c_int, P],

@@ -48,6 +48,7 @@ class OmniTokConfig:
     defer_spatial_pool: bool = False   # omnitokenizer.py:799-804 / 992-1003
     gen_upscale: int = 1               # decoder patch_size *= gen_upscale, omnitokenizer.py:957-959
     norm_type: str = "batch"           # Normalize() of the 'cnn' patch-embed, base.py:272-277
+    codebook_type: str = "vq"          # --codebook_type (only 'vq' exists for the external quantiser)
 
     @property
     def ff_inner(self) -> int:
@@ -120,6 +121,7 @@ class OmniTokConfig:
             defer_spatial_pool=bool(_get(args, "defer_spatial_pool", False)),
             gen_upscale=int(_get(args, "gen_upscale", None) or 1),                # omnitokenizer.py:91-92
             norm_type=str(_get(args, "norm_type", "batch")),
+            codebook_type=str(_get(args, "codebook_type", "vq")),
         )
         cfg.validate()
         return cfg
@@ -153,8 +155,16 @@ class OmniTokConfig:
         if len(self.enc_block) != self.spatial_depth:
             raise ValueError("len(enc_block) must equal spatial_depth (reference attention.py:608)")
         if self.use_external_codebook:
-            raise NotImplementedError("use_external_codebook (VectorQuantize) is not built; the released "
-                                      "configs use modules/codebook.py::Codebook")
+            # VectorQuantize (quantizer/vector_quantize_pytorch.py:690), built by omnitokenizer.py:131-138
+            if self.codebook_type != "vq":
+                raise NotImplementedError(f"codebook_type={self.codebook_type!r} (reference omnitokenizer.py:139-140)")
+            if not self.l2_code:
+                raise NotImplementedError("use_external_codebook without l2_code selects EuclideanCodebook (cdist + "
+                                          "sqrt ordering, vector_quantize_pytorch.py:239); only the cosine-similarity "
+                                          "codebook (l2_code, the scripts' default) is built")
+            if self.use_vae:
+                raise NotImplementedError("use_vae with use_external_codebook: pre_vq_conv is Identity there "
+                                          "(omnitokenizer.py:136), the posterior would have 512 channels")
         if self.dim != self.dim_head * self.heads or self.dim_head != 64:
             raise NotImplementedError("kernels are built for dim == heads*dim_head with dim_head == 64")
         if self.dim % 128 != 0:

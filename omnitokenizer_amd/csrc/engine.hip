@@ -203,6 +203,13 @@ static int ensure(Buf &b, int64_t n) {
     return OMNITOK_OK;
 }
 
+// quantiser weight names: Codebook + pre/post_vq_conv, or the external VectorQuantize's own projections
+static const char *k_embed(const omnitok_config &c) { return c.external_codebook ? "codebook._codebook.embed" : "codebook.embeddings"; }
+static const char *k_pre_w(const omnitok_config &c) { return c.external_codebook ? "codebook.project_in.weight" : "pre_vq_conv.1.weight"; }
+static const char *k_pre_b(const omnitok_config &c) { return c.external_codebook ? "codebook.project_in.bias" : "pre_vq_conv.1.bias"; }
+static const char *k_post_w(const omnitok_config &c) { return c.external_codebook ? "codebook.project_out.weight" : "post_vq_conv.1.weight"; }
+static const char *k_post_b(const omnitok_config &c) { return c.external_codebook ? "codebook.project_out.bias" : "post_vq_conv.1.bias"; }
+
 static const float *W(omnitok_engine *e, const std::string &k) {
     auto it = e->w.find(k);
     return it == e->w.end() ? nullptr : static_cast<const float *>(it->second.p);
@@ -722,11 +729,20 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
     }
     // --use_vae: no quantiser on the path, pre_vq emits mean | logvar (reference omnitokenizer.py:143-154)
     const int64_t pre_out = c.use_vae ? 2 * c.codebook_dim : c.codebook_dim;
-    if (!c.use_vae) e->spec["codebook.embeddings"] = {c.n_codes, c.codebook_dim};
-    e->spec["pre_vq_conv.1.weight"] = {pre_out, d};
-    e->spec["pre_vq_conv.1.bias"] = {pre_out};
-    e->spec["post_vq_conv.1.weight"] = {d, c.codebook_dim};
-    e->spec["post_vq_conv.1.bias"] = {d};
+    if (c.external_codebook) {  // VectorQuantize + CosineSimCodebook (vector_quantize_pytorch.py:514, 690)
+        if (c.use_vae || !c.l2_code) {
+            set_error("engine_create: external codebook is built for the cosine-similarity VectorQuantize only");
+            delete e;
+            return OMNITOK_ERR_UNSUPPORTED;
+        }
+        e->spec[k_embed(c)] = {1, c.n_codes, c.codebook_dim};
+    } else if (!c.use_vae) {
+        e->spec[k_embed(c)] = {c.n_codes, c.codebook_dim};
+    }
+    e->spec[k_pre_w(c)] = {pre_out, d};
+    e->spec[k_pre_b(c)] = {pre_out};
+    e->spec[k_post_w(c)] = {d, c.codebook_dim};
+    e->spec[k_post_b(c)] = {d};
     // drop keys the inference path never reads
     for (auto it = e->spec.begin(); it != e->spec.end();)
         it = key_unused(e, it->first) ? e->spec.erase(it) : std::next(it);
@@ -815,7 +831,7 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     if (!c.use_vae) {
         if (int rc = alloc_f(e, &e->cb_packed, (int64_t)c.n_codes * 8)) return rc;
         if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
-        if (int rc = omnitok_vq_prepare(W(e, "codebook.embeddings"), c.n_codes, 8, e->cb_packed, e->cb_ee, stream))
+        if (int rc = omnitok_vq_prepare(W(e, k_embed(c)), c.n_codes, 8, e->cb_packed, e->cb_ee, stream))
             return rc;
     }
     {
@@ -1004,13 +1020,22 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
     const int64_t L = (int64_t)B * T * S;
     // ---- pre_vq + l2norm + nearest code (reference omnitokenizer.py:248-255) ----------------
     OT_RUN("pre_vq", (double)L * D * 4.0,
-           omnitok_pre_vq(e->X.p, W(e, "pre_vq_conv.1.weight"), W(e, "pre_vq_conv.1.bias"), e->Z.p, L, D, 8, c.l2_code,
-                          stream));
-    OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
-           omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
-    if (emb_out)
-        OT_RUN("vq_embed_st", (double)L * 8 * 8.0,
-               omnitok_vq_embed_st(ids_out, e->Z.p, W(e, "codebook.embeddings"), 8, B, (int64_t)T * S, emb_out, stream));
+           omnitok_pre_vq(e->X.p, W(e, k_pre_w(c)), W(e, k_pre_b(c)), e->Z.p, L, D, 8, c.l2_code, stream));
+    if (c.external_codebook) {
+        // cosine similarity: first argmax of the dot (reference vector_quantize_pytorch.py:646-650)
+        OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+               omnitok_vq_argmax_cos(e->Z.p, e->cb_packed, L, c.n_codes, ids_out, stream));
+        if (emb_out)  // eval: quantize = embed[ids] -> project_out, no straight-through term; [B,T',h,w,dim]
+            OT_RUN("dequant_post_vq", (double)L * D * 4.0,
+                   omnitok_dequant_post_vq(ids_out, W(e, k_embed(c)), c.n_codes, 8, W(e, k_post_w(c)), W(e, k_post_b(c)),
+                                           emb_out, L, D, nullptr, stream));
+    } else {
+        OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+               omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
+        if (emb_out)
+            OT_RUN("vq_embed_st", (double)L * 8 * 8.0,
+                   omnitok_vq_embed_st(ids_out, e->Z.p, W(e, k_embed(c)), 8, B, (int64_t)T * S, emb_out, stream));
+    }
     if (z_out) OT_HIP(hipMemcpyAsync(z_out, e->Z.p, (size_t)L * 8 * 4, hipMemcpyDeviceToDevice, stream));
     return OMNITOK_OK;
 }
@@ -1040,8 +1065,8 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
 
     if (kind == LatentKind::Ids)
         OT_RUN("dequant_post_vq", (double)L0 * D * 4.0,
-               omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, "codebook.embeddings"), c.n_codes, 8,
-                                       W(e, "post_vq_conv.1.weight"), W(e, "post_vq_conv.1.bias"), e->X.p, L0, D,
+               omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, k_embed(c)), c.n_codes, 8,
+                                       W(e, k_post_w(c)), W(e, k_post_b(c)), e->X.p, L0, D,
                                        e->err_flag, stream));
     else
         OT_RUN("post_vq", (double)L0 * D * 4.0,

@@ -234,6 +234,17 @@ def vq_argmin(z, codebook, prepared=None):
     return ids
 
 
+def vq_argmax_cos(z, embed, prepared=None):
+    """ids[n] = first argmax_c z[n] . embed[c] (int64): the external cosine-similarity codebook, bit-exact with
+    reference quantizer/vector_quantize_pytorch.py:646-650.  z, embed rows unit-norm."""
+    z = _req(z, "z")
+    packed, _ = prepared if prepared is not None else vq_prepare(embed)
+    n = z.numel() // 8
+    ids = torch.empty(z.shape[:-1], device=z.device, dtype=torch.int64)
+    check(_lib.load().omnitok_vq_argmax_cos(_p(z), _p(packed), n, embed.shape[0], _p(ids), _stream()), "vq_argmax_cos")
+    return ids
+
+
 def dequant_post_vq(ids, codebook, w, b):
     ids = _req(ids, "ids", torch.int64)
     D = w.shape[0]

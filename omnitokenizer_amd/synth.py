@@ -111,6 +111,19 @@ def path_state_spec(cfg: OmniTokConfig) -> "OrderedDict[str, tuple]":
         else:
             spec[f"decoder.{name}.0.weight"] = (c * pd * pd * ptk, d)
             spec[f"decoder.{name}.0.bias"] = (c * pd * pd * ptk,)
+    if cfg.use_external_codebook:
+        # VectorQuantize + CosineSimCodebook state (vector_quantize_pytorch.py:514-560, 690-860); pre_vq_conv /
+        # post_vq_conv are nn.Identity (omnitokenizer.py:136-137): project_in / project_out take their place
+        spec["codebook.codebook_usage"] = (cfg.n_codes,)
+        spec["codebook.project_in.weight"] = (cfg.codebook_dim, d)
+        spec["codebook.project_in.bias"] = (cfg.codebook_dim,)
+        spec["codebook.project_out.weight"] = (d, cfg.codebook_dim)
+        spec["codebook.project_out.bias"] = (d,)
+        spec["codebook._codebook.initted"] = (1,)
+        spec["codebook._codebook.cluster_size"] = (1, cfg.n_codes)
+        spec["codebook._codebook.embed"] = (1, cfg.n_codes, cfg.codebook_dim)
+        spec["codebook._codebook.embed_avg"] = (1, cfg.n_codes, cfg.codebook_dim)
+        return spec
     spec["codebook.embeddings"] = (cfg.n_codes, cfg.codebook_dim)
     spec["codebook.N"] = (cfg.n_codes,)
     spec["codebook.z_avg"] = (cfg.n_codes, cfg.codebook_dim)
@@ -161,7 +174,16 @@ def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, tor
         if leaf == "running_mean":
             sd[name] = torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)))
             continue
-        if name == "codebook.embeddings":
+        if name == "codebook._codebook.embed":
+            v = randn(1.0)  # l2norm(uniform_init(...)), vector_quantize_pytorch.py:539: unit-norm rows
+            v = v / np.linalg.norm(v, axis=-1, keepdims=True)
+        elif name == "codebook._codebook.embed_avg":
+            v = sd["codebook._codebook.embed"].numpy().copy()
+        elif name == "codebook._codebook.initted":
+            v = np.ones(shape, np.float32)
+        elif name == "codebook._codebook.cluster_size":
+            v = np.zeros(shape, np.float32)
+        elif name == "codebook.embeddings":
             v = randn(1.0)  # reference codebook.py:14 torch.randn(n_codes, dim)
         elif name == "codebook.z_avg":
             v = sd["codebook.embeddings"].numpy().copy()

@@ -63,7 +63,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         self.patch_size = cfg.patch_size
         self.use_vae = cfg.use_vae
         self.kl_weight = getattr(args, "kl_weight", 0.0)
-        self.use_external_codebook = False
+        self.use_external_codebook = cfg.use_external_codebook
         self.l2_code = cfg.l2_code
 
         for name, shape in path_state_spec(cfg).items():
@@ -80,6 +80,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         self.encoder.image_size = (cfg.resolution, cfg.resolution)
         self.decoder.image_size = (cfg.resolution, cfg.resolution)
         self.codebook.n_codes = cfg.n_codes
+        self.codebook.codebook_size = cfg.n_codes  # VectorQuantize's name for it
         self.codebook.embedding_dim = cfg.codebook_dim
         self.codebook._need_init = False  # training-time k-means init (codebook.py:40-51) is not on the path
 
@@ -93,7 +94,7 @@ class OmniTokenizer_VQGAN(nn.Module):
     # ---- nn.Module plumbing -------------------------------------------------------------------
     @property
     def device(self):
-        return self.codebook.embeddings.device
+        return self.encoder.enc_spatial_transformer.norm_out.gamma.device
 
     def train(self, mode: bool = True):
         if mode:
@@ -144,6 +145,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         nc.defer_temporal_pool = int(c.defer_temporal_pool)
         nc.defer_spatial_pool = int(c.defer_spatial_pool)
         nc.gen_upscale = int(c.gen_upscale)
+        nc.external_codebook = int(c.use_external_codebook)
         return nc
 
     def _signature(self):
@@ -219,7 +221,12 @@ class OmniTokenizer_VQGAN(nn.Module):
         if self.use_vae:
             return self._encode_vae(x, is_image, (B, F, H, W, T, h, w), noise, sample_posterior, return_moments)
         ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
-        emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device) if include_embeddings else None
+        if not include_embeddings:
+            emb = None
+        elif self.use_external_codebook:  # project_out(embed[ids]), token-major from the engine
+            emb = torch.empty(B, T, h, w, self.cfg.dim, device=x.device)
+        else:
+            emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device)
         z = torch.empty(B, T, h, w, self.cfg.codebook_dim, device=x.device) if return_latents else None
         lib = _lib.load()
         check(lib.omnitok_encode(self._engine, ctypes.c_void_p(x.data_ptr()), B, F, H, W,
@@ -227,6 +234,8 @@ class OmniTokenizer_VQGAN(nn.Module):
                                  None if emb is None else ctypes.c_void_p(emb.data_ptr()),
                                  None if z is None else ctypes.c_void_p(z.data_ptr()),
                                  torch.cuda.current_stream().cuda_stream), "encode")
+        if emb is not None and self.use_external_codebook:
+            emb = emb.permute(0, 4, 1, 2, 3)  # 'b (t h w) c -> b c t h w', vector_quantize_pytorch.py:1077
         if return_latents:
             return (emb, ids, z) if include_embeddings else (ids, z)
         return (emb, ids) if include_embeddings else ids
@@ -305,7 +314,9 @@ class OmniTokenizer_VQGAN(nn.Module):
 
     @torch.no_grad()
     def decode(self, encodings, is_image, check_ids: bool = False):
-        """reference omnitokenizer.py:268-291.  encodings: ids [B,T',h,w], flat video ids
+        """reference omnitokenizer.py:268-291 (with --use_external_codebook the reference's decode() raises
+        -- it reads codebook.embeddings, which VectorQuantize lacks -- so this computes what its forward()
+        computes from the same ids: decoder(project_out(embed[ids]))).  encodings: ids [B,T',h,w], flat video ids
         [B,T'*h*w] (h = w = args.resolution // patch_size, :283-286) or flat image ids [B,h*w]
         (h = int(sqrt(h*w)), :272-275).  Returns [B,3,H,W] (is_image) or [B,3,F,H,W]."""
         self._sync_engine()
@@ -373,8 +384,26 @@ class OmniTokenizer_VQGAN(nn.Module):
         usage, perplexity, avg_usage = ops.vq_stats(ids, self.cfg.n_codes, cb.codebook_usage.data,
                                                     cb.call_cnt == 0, cb.usage_sigma)
         cb.call_cnt += 1
-        return frames, frames_recon, x, x_recon, dict(embeddings=emb, encodings=ids, batch_usage=usage,
-                                                      perplexity=perplexity, avg_usage=avg_usage)
+        vq_output = dict(embeddings=emb, encodings=ids, batch_usage=usage, perplexity=perplexity, avg_usage=avg_usage)
+        if self.use_external_codebook:  # VectorQuantize also reports its (eval: zero) commitment loss
+            vq_output["commitment_loss"] = torch.zeros(1, device=x.device)
+            vq_output["perplexity"] = self._ext_perplexity(ids)
+        return frames, frames_recon, x, x_recon, vq_output
+
+    @staticmethod
+    def _ext_perplexity(ids):
+        """VectorQuantize.get_perplexity (vector_quantize_pytorch.py:849-853) one-hots the UNFLATTENED
+        [b,t,h,w] indices and averages over dim 0 only, so its "perplexity" is exp of the summed per-position
+        entropies of the batch histogram (2^64 for two different 8x8 images), not the codebook perplexity.
+        Reproduced as such (a statistic of forward(), off the encode/decode path): with c[b,p] = how many
+        batch items share item b's code at position p, -sum p log(p + 1e-10) = -(1/B) sum_{b,p} log(c/B + 1e-10)."""
+        B = ids.shape[0]
+        flat = ids.reshape(B, -1)
+        total = torch.zeros((), device=ids.device, dtype=torch.float32)
+        for b in range(B):  # O(B^2 P) compares, no [B, P, n_codes] one-hot
+            cnt = (flat == flat[b:b + 1]).sum(0).to(torch.float32)
+            total = total + torch.log(cnt / B + 1e-10).sum()
+        return torch.exp(-total / B)
 
     # ---- measurement hooks ----------------------------------------------------------------------
     def set_timing(self, enabled: bool):

@@ -21,6 +21,9 @@ def _lib():
     lib.oracle_vq_argmin.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     lib.oracle_vq_argmin.restype = None
+    lib.oracle_vq_argmax_cos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                         ctypes.c_int64, ctypes.c_void_p]
+    lib.oracle_vq_argmax_cos.restype = None
     return lib
 
 
@@ -34,3 +37,13 @@ def vq_argmin(x: np.ndarray, codebook: np.ndarray, return_dist=False):
     _lib().oracle_vq_argmin(x.ctypes.data, e.ctypes.data, n, e.shape[0], dim, ids.ctypes.data,
                             dist.ctypes.data)
     return (ids, dist) if return_dist else ids
+
+
+def vq_argmax_cos(x: np.ndarray, embed: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    e = np.ascontiguousarray(embed, dtype=np.float32)
+    n, dim = x.shape
+    assert e.shape[1] == dim
+    ids = np.empty(n, np.int64)
+    _lib().oracle_vq_argmax_cos(x.ctypes.data, e.ctypes.data, n, e.shape[0], dim, ids.ctypes.data)
+    return ids

@@ -323,9 +323,37 @@ def vq_argmin(z_flat, codebook):
     return torch.argmin(dist, dim=1)
 
 
+def ext_pre_vq(sd, tok):
+    """--use_external_codebook: VectorQuantize.project_in (512 -> codebook_dim, +bias) then the cosine
+    codebook's transform_input = l2norm (vector_quantize_pytorch.py:905, 915, 535).  [b,t,h,w,cdim]."""
+    return F.normalize(F.linear(tok, sd["codebook.project_in.weight"], sd["codebook.project_in.bias"]), p=2, dim=-1)
+
+
+def vq_argmax_cos(z_flat, embed):
+    """CosineSimCodebook.forward in eval (vector_quantize_pytorch.py:646-650): dist = einsum('h n d, h c d
+    -> h n c'), ids = argmax (gumbel_sample at temperature 0 / eval) -> first maximum."""
+    dist = torch.einsum("hnd,hcd->hnc", z_flat[None], embed[None])[0]
+    return dist.argmax(dim=-1)
+
+
+def ext_embeddings(sd, ids):
+    """quantize = embed[ids] -> project_out (vector_quantize_pytorch.py:653, 1070): tokens [..., 512]."""
+    q = F.embedding(ids, sd["codebook._codebook.embed"][0])
+    return F.linear(q, sd["codebook.project_out.weight"], sd["codebook.project_out.bias"])
+
+
 def encode(sd, x, is_image, cfg, include_embeddings=False, taps=None):
     """reference omnitokenizer.py:247-258 VQGAN.encode."""
     tok = encoder(sd, x, is_image, cfg, taps)
+    if cfg.use_external_codebook:
+        z = ext_pre_vq(sd, tok)
+        if taps is not None:
+            taps["z"] = z
+        b, t, h, w, c = z.shape
+        ids = vq_argmax_cos(z.reshape(-1, c), sd["codebook._codebook.embed"][0]).view(b, t, h, w)
+        if include_embeddings:  # eval: no straight-through term (vector_quantize_pytorch.py:935)
+            return ext_embeddings(sd, ids).permute(0, 4, 1, 2, 3), ids
+        return ids
     z = pre_vq(sd, tok, cfg)
     if taps is not None:
         taps["z"] = z
@@ -384,7 +412,15 @@ def decode_vae(sd, z, is_image, cfg):
 
 
 def decode(sd, ids, is_image, cfg, taps=None):
-    """reference omnitokenizer.py:268-291 VQGAN.decode + 1101-1118 / 1059-1098 decoder."""
+    """reference omnitokenizer.py:268-291 VQGAN.decode + 1101-1118 / 1059-1098 decoder.
+    --use_external_codebook: the reference's decode() raises (it reads self.codebook.embeddings, which
+    VectorQuantize does not have); what its forward() computes on the same ids is restated instead:
+    decoder(project_out(embed[ids])) (omnitokenizer.py:362-363 with post_vq_conv = Identity)."""
+    if cfg.use_external_codebook:
+        if ids.ndim == 2:
+            hh = int(math.sqrt(ids.shape[1])) if is_image else cfg.resolution // cfg.patch_size
+            ids = ids.reshape(ids.shape[0], -1, hh, hh) if not is_image else ids.reshape(ids.shape[0], 1, hh, -1)
+        return _decode_tokens(sd, ext_embeddings(sd, ids), is_image, cfg, taps)
     z = F.embedding(ids, sd["codebook.embeddings"])
     if z.ndim == 3:
         if is_image:

@@ -44,3 +44,22 @@ void oracle_vq_argmin(const float *x, const float *E, int64_t n, int64_t n_codes
         if (min_dist) min_dist[i] = best;
     }
 }
+
+/* --use_external_codebook, cosine similarity: reference quantizer/vector_quantize_pytorch.py:646-650
+ *     dist = einsum('h n d, h c d -> h n c', flatten, embed);  ids = dist.argmax(-1)
+ * dot[n,c] = k-ordered fp32 FMA chain from 0 (the same sgemm evaluation order as above), first maximum. */
+void oracle_vq_argmax_cos(const float *x, const float *E, int64_t n, int64_t n_codes, int64_t dim, int64_t *ids)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float *xi = x + i * dim;
+        float best = -INFINITY;
+        int64_t best_c = 0;
+        for (int64_t c = 0; c < n_codes; ++c) {
+            const float *e = E + c * dim;
+            float dot = 0.0f;
+            for (int64_t k = 0; k < dim; ++k) dot = fmaf(xi[k], e[k], dot);
+            if (dot > best || c == 0) { best = dot; best_c = c; }
+        }
+        ids[i] = best_c;
+    }
+}

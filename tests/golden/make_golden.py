@@ -183,6 +183,82 @@ def make_vq_kat():
         print(f"vq_kat_{n_codes}: uniq {np.unique(ids).size}")
 
 
+EXT_CASES = [  # --use_external_codebook (VectorQuantize, cosine similarity): SURVEY.md 8(a) row a16
+    ("ext_s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64, use_external_codebook=True), 2, 1, 1),
+    ("ext_s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64, use_external_codebook=True), 1, 5, 1),
+    ("ext_s1_legacy_r128_vid", 1, "legacy", dict(resolution=128, use_external_codebook=True, n_codes=16384), 1, 5, 2),
+]
+
+
+def run_ext_case(name, stage, mode, overrides, batch, frames, stride):
+    """The reference's decode() raises with the external codebook (it reads codebook.embeddings), so the
+    reconstruction stored here is what its forward() computes (omnitokenizer.py:358-363):
+    decoder(post_vq_conv(codebook(pre_vq_conv(encoder(x)))['embeddings']))."""
+    args = make_args(stage, **overrides)
+    cfg = OmniTokConfig.from_args(args, attention_mode=mode)
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = rh.build_reference_model(args)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    is_image = frames == 1
+    res = cfg.resolution
+    x = synth.synth_image(batch, res, seed=1234) if is_image else synth.synth_video(batch, frames, res, seed=1234)
+    with torch.no_grad(), rh.attention_mode(mode):
+        emb, ids = model.encode(x, is_image, include_embeddings=True)
+        tok = model.encoder(x, is_image)                                  # b d t h w
+        z = model.codebook._codebook.transform_input(
+            model.codebook.project_in(tok.permute(0, 2, 3, 4, 1)))          # b t h w c, unit norm
+        vq = model.codebook(model.pre_vq_conv(tok))
+        assert torch.equal(vq["encodings"], ids)
+        recon = model.decoder(model.post_vq_conv(vq["embeddings"]), is_image)
+        try:
+            model.decode(ids, is_image)
+            raise SystemExit("reference decode() unexpectedly works with the external codebook")
+        except AttributeError:
+            pass
+    sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        stage=stage, mode=mode, overrides=repr(overrides), batch=batch, frames=frames,
+        stride=stride, weight_seed=0, input_seed=1234,
+        state_crc=np.uint32(synth.state_checksum(sd)),
+        input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
+        ids=ids.numpy().astype(np.int16), z=z.contiguous().numpy(),
+        emb=emb.permute(0, 2, 3, 4, 1)[..., ::8].contiguous().numpy(),  # b t h w c, every 8th of 512 channels
+        recon=recon[sl].contiguous().numpy(), recon_absmax=np.float32(recon.abs().max().item()),
+        perplexity=np.float32(vq["perplexity"].item()),
+    )
+    print(f"{name}: ids {tuple(ids.shape)} uniq {ids.unique().numel()} recon {tuple(recon.shape)} "
+          f"absmax {recon.abs().max().item():.3f}")
+
+
+def make_vq_cos_kat():
+    """Known answers of the reference's CosineSimCodebook.forward (eval): unit-norm z, duplicated code rows
+    (ties -> lowest index), exact code rows."""
+    rh.install_stubs()
+    from OmniTokenizer.quantizer.vector_quantize_pytorch import CosineSimCodebook
+    n_codes = 8192
+    rng = np.random.Generator(np.random.PCG64(99))
+    E = rng.standard_normal((n_codes, 8), dtype=np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    E[n_codes // 2] = E[17]
+    E[n_codes - 1] = E[17]
+    E[5] = E[3]
+    z = rng.standard_normal((4096, 8), dtype=np.float32)
+    z /= np.linalg.norm(z, axis=1, keepdims=True)
+    z[3000:3064] = E[17]
+    z[3064:3100] = E[3]
+    z[3100:3200] = E[rng.integers(0, n_codes, 100)]
+    cb = CosineSimCodebook(8, n_codes).eval()
+    cb.embed.data.copy_(torch.from_numpy(E)[None])
+    with torch.no_grad():
+        _, ind, _ = cb(torch.from_numpy(z)[None])
+    ids = ind.reshape(-1).numpy()
+    assert (ids[3000:3064] == 17).all() and (ids[3064:3100] == 3).all()
+    np.savez_compressed(os.path.join(OUT, "vq_cos_kat_8192.npz"), z=z, codebook=E, ids=ids.astype(np.int16))
+    print(f"vq_cos_kat_8192: uniq {np.unique(ids).size}")
+
+
 GPT_CASES = [  # name, vocab, block_size, n_layer, n_head, n_embd (head_dim 64 / 96 / 128)
     ("gpt_hd64", 320, 48, 2, 4, 256),
     ("gpt_hd96", 520, 40, 2, 8, 768),
@@ -235,6 +311,10 @@ if __name__ == "__main__":
     if only in (None, "variants"):
         for c in VARIANT_CASES:
             run_case(*c)
+    if only in (None, "ext"):
+        make_vq_cos_kat()
+        for c in EXT_CASES:
+            run_ext_case(*c)
     if only in (None, "gpt"):
         make_gpt_golden()
     if only in (None, "vae"):

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import omnitok_oracle as orc
-from tests.helpers import E2E_CASES, VAE_CASES, VARIANT_CASES, GoldenCase
+from tests.helpers import E2E_CASES, EXT_CASES, VAE_CASES, VARIANT_CASES, GoldenCase
 
 pytestmark = pytest.mark.gpu
 
@@ -345,3 +345,31 @@ def test_hip_graph_capture_and_side_stream(models):
     torch.cuda.synchronize()
     assert torch.equal(ids_g, ids2) and torch.equal(rec_g, rec2)
     assert torch.equal(ids2.cpu(), torch.roll(c.ids, 1, dims=0))
+
+
+# ---- --use_external_codebook: VectorQuantize / cosine similarity -----------------
+@pytest.mark.parametrize("name", EXT_CASES)
+def test_external_codebook_vs_reference_golden(models, name):
+    c = GoldenCase(name)
+    m = models(c)
+    assert m.use_external_codebook
+    from omnitokenizer_amd import ops
+    E = c.sd["codebook._codebook.embed"][0]
+    x = c.x.cuda()
+    emb, ids, z = m.encode(x, c.is_image, include_embeddings=True, return_latents=True)
+    # the quantiser alone on the reference's unit-norm z: bit-exact first-argmax
+    assert torch.equal(ops.vq_argmax_cos(c.z.cuda(), E.cuda()).cpu(), c.ids)
+    zerr = (z.cpu() - c.z).abs().max().item()
+    assert zerr < Z_TOL
+    flips = assert_ids_match_or_near_tie(ids, c.ids, z, E, name)  # unit norm: nearest == most similar
+    assert tuple(emb.shape) == (c.batch, 512) + tuple(c.ids.shape[1:])
+    if flips == 0:
+        assert (emb.permute(0, 2, 3, 4, 1)[..., ::8].cpu() - c.emb).abs().max().item() < 1e-5
+    recon = m.decode(c.ids.cuda(), c.is_image)  # = the reference forward()'s decoder(project_out(embed[ids]))
+    err = (c.strided(recon.cpu()) - c.recon).abs().max().item()
+    assert err < PIXEL_TOL
+    out = m(x, log_image=True)[4]
+    assert set(out) == {"embeddings", "encodings", "commitment_loss", "perplexity", "avg_usage", "batch_usage"}
+    if flips == 0:
+        assert abs(float(out["perplexity"]) - c.perplexity) < 1e-3 * c.perplexity
+    print(f"{name}: id flips {flips}, z err {zerr:.1e}, pixel err {err:.1e}")

@@ -470,6 +470,22 @@ def test_vq_argmin_code_range_splits(ops, split):
         _lib.set_option("vq_split", 0)
 
 
+@pytest.mark.parametrize("split", [0, 1, 4])
+def test_vq_argmax_cos_bit_exact_vs_reference_kat(ops, split):
+    """External cosine-similarity codebook: ids bit-exact against the reference's CosineSimCodebook.forward."""
+    from omnitokenizer_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "vq_cos_kat_8192.npz"))
+    z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
+    _lib.set_option("vq_split", split)
+    try:
+        for n in (4096, 1000, 31):
+            ids = ops.vq_argmax_cos(dev(z[:n]), dev(E)).cpu().numpy()
+            assert np.array_equal(ids, ids_ref[:n]), f"{(ids != ids_ref[:n]).sum()} of {n} ids differ"
+    finally:
+        _lib.set_option("vq_split", 0)
+    assert np.array_equal(c_oracle.vq_argmax_cos(g["z"][:512], g["codebook"]), ids_ref[:512])
+
+
 def test_vq_argmin_large_random_vs_c_oracle(ops):
     rng = np.random.default_rng(5)
     E = rng.standard_normal((8192, 8), dtype=np.float32)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
+from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -90,3 +90,28 @@ def test_oracle_vae_matches_reference(name):
     assert torch.equal(z, z_seeded)
     assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
     assert torch.equal(recon, recon_flat)
+
+
+def test_vq_cos_c_oracle_matches_reference_kat():
+    g = np.load(os.path.join(GOLDEN, "vq_cos_kat_8192.npz"))
+    ids = c_oracle.vq_argmax_cos(g["z"], g["codebook"])
+    assert np.array_equal(ids, g["ids"].astype(np.int64))
+    assert (ids[3000:3064] == 17).all() and (ids[3064:3100] == 3).all()  # ties -> lowest index
+    t = orc.vq_argmax_cos(torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"])).numpy()
+    assert np.array_equal(t, ids)
+
+
+@pytest.mark.parametrize("name", EXT_CASES[:2])
+def test_oracle_external_codebook_matches_reference(name):
+    """--use_external_codebook (VectorQuantize, cosine similarity)."""
+    c = GoldenCase(name)
+    with torch.no_grad():
+        taps = {}
+        emb, ids = orc.encode(c.sd, c.x, c.is_image, c.cfg, include_embeddings=True, taps=taps)
+        recon = orc.decode(c.sd, c.ids, c.is_image, c.cfg)
+    assert torch.equal(ids, c.ids)
+    assert (taps["z"] - c.z).abs().max().item() < 2e-6
+    assert (emb.permute(0, 2, 3, 4, 1)[..., ::8] - c.emb).abs().max().item() < 1e-6
+    assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
+    cids = c_oracle.vq_argmax_cos(c.z.reshape(-1, 8).numpy(), c.sd["codebook._codebook.embed"][0].numpy())
+    assert np.array_equal(cids, c.ids.reshape(-1).numpy())
