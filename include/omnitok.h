@@ -203,6 +203,11 @@ int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int6
  * and the same k-ordered FMA chain as omnitok_vq_argmin; packed from omnitok_vq_prepare(E). */
 int omnitok_vq_argmax_cos(const float *z, const float *packed, int64_t n, int n_codes, int64_t *ids,
                           omnitok_stream_t stream);
+/* --use_external_codebook without l2_code (EuclideanCodebook, vector_quantize_pytorch.py:29-33, 463):
+ * ids[n] = first argmin_c sqrt(clamp((xx[n] + ee[c]) + (-2 dot[n,c]), 0)), i.e. the first argmax of -cdist
+ * with the correctly rounded sqrt taking part in the ordering.  packed / ee from omnitok_vq_prepare(E). */
+int omnitok_vq_argmin_cdist(const float *z, const float *packed, const float *ee, int64_t n,
+                            int n_codes, int64_t *ids, omnitok_stream_t stream);
 
 /* tok[n, :] = E[ids[n], :] . w[D, cdim]^T + b  (F.embedding + post_vq_conv, reference
  * omnitokenizer.py:270, 156-160). Returns OMNITOK_ERR_INVALID through the status word
@@ -273,7 +278,8 @@ typedef struct omnitok_config {
     int defer_temporal_pool;   /* --defer_temporal_pool (omnitokenizer.py:792-797, 985-990), linear only */
     int defer_spatial_pool;    /* --defer_spatial_pool  (omnitokenizer.py:799-804, 992-1003), linear only */
     int gen_upscale;           /* --gen_upscale: decoder patch_size *= gen_upscale (0 / 1 = off) */
-    int external_codebook;     /* --use_external_codebook with l2_code: VectorQuantize / CosineSimCodebook
+    int external_codebook;     /* --use_external_codebook: VectorQuantize with its CosineSimCodebook (l2_code) or
+                                * EuclideanCodebook (no l2_code)
                                 * (quantizer/vector_quantize_pytorch.py): weights codebook.project_in / project_out /
                                 * _codebook.embed replace pre_vq_conv / post_vq_conv / codebook.embeddings;
                                 * omnitok_encode's emb_out is then project_out(embed[ids]) as [B,T',h,w,dim] */

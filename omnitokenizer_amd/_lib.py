@@ -59,6 +59,7 @@ _PROTOS = {
     "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
     "omnitok_vq_argmax_cos": [P, P, I64, c_int, P, P],
+    "omnitok_vq_argmin_cdist": [P, P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],
     "omnitok_token_resample": [P, P, c_int, I64, c_int, c_int, c_int, c_int, P],
     "omnitok_vae_sample": [P, P, P, P, P, P, I64, I64, c_int, c_int, P],

@@ -158,10 +158,6 @@ class OmniTokConfig:
             # VectorQuantize (quantizer/vector_quantize_pytorch.py:690), built by omnitokenizer.py:131-138
             if self.codebook_type != "vq":
                 raise NotImplementedError(f"codebook_type={self.codebook_type!r} (reference omnitokenizer.py:139-140)")
-            if not self.l2_code:
-                raise NotImplementedError("use_external_codebook without l2_code selects EuclideanCodebook (cdist + "
-                                          "sqrt ordering, vector_quantize_pytorch.py:239); only the cosine-similarity "
-                                          "codebook (l2_code, the scripts' default) is built")
             if self.use_vae:
                 raise NotImplementedError("use_vae with use_external_codebook: pre_vq_conv is Identity there "
                                           "(omnitokenizer.py:136), the posterior would have 512 channels")

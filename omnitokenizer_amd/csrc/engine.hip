@@ -730,8 +730,8 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
     // --use_vae: no quantiser on the path, pre_vq emits mean | logvar (reference omnitokenizer.py:143-154)
     const int64_t pre_out = c.use_vae ? 2 * c.codebook_dim : c.codebook_dim;
     if (c.external_codebook) {  // VectorQuantize + CosineSimCodebook (vector_quantize_pytorch.py:514, 690)
-        if (c.use_vae || !c.l2_code) {
-            set_error("engine_create: external codebook is built for the cosine-similarity VectorQuantize only");
+        if (c.use_vae) {
+            set_error("engine_create: use_vae with the external codebook is not a valid reference configuration");
             delete e;
             return OMNITOK_ERR_UNSUPPORTED;
         }
@@ -1022,9 +1022,14 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
     OT_RUN("pre_vq", (double)L * D * 4.0,
            omnitok_pre_vq(e->X.p, W(e, k_pre_w(c)), W(e, k_pre_b(c)), e->Z.p, L, D, 8, c.l2_code, stream));
     if (c.external_codebook) {
-        // cosine similarity: first argmax of the dot (reference vector_quantize_pytorch.py:646-650)
-        OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
-               omnitok_vq_argmax_cos(e->Z.p, e->cb_packed, L, c.n_codes, ids_out, stream));
+        // cosine similarity (l2_code): first argmax of the dot (vector_quantize_pytorch.py:646-650);
+        // otherwise EuclideanCodebook: first argmax of -cdist (:463)
+        if (c.l2_code)
+            OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+                   omnitok_vq_argmax_cos(e->Z.p, e->cb_packed, L, c.n_codes, ids_out, stream));
+        else
+            OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+                   omnitok_vq_argmin_cdist(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
         if (emb_out)  // eval: quantize = embed[ids] -> project_out, no straight-through term; [B,T',h,w,dim]
             OT_RUN("dequant_post_vq", (double)L * D * 4.0,
                    omnitok_dequant_post_vq(ids_out, W(e, k_embed(c)), c.n_codes, 8, W(e, k_post_w(c)), W(e, k_post_b(c)),

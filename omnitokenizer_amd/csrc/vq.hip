@@ -51,10 +51,16 @@ __device__ __forceinline__ unsigned order_key(float d) {
     return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
-// COS: the external cosine-similarity codebook (reference quantizer/vector_quantize_pytorch.py:646-650):
-// ids = first argmax_c of dot[n,c].  Same sweep with xx = ee = 0: d = (0 - 2 dot) + 0 = -2 dot exactly, so the
-// first minimum of d is the first maximum of the dot (doubling is exact and order preserving).
-template <bool SPLIT, bool COS = false>
+// MODE: which distance the sweep minimises (all: first minimum, k-ordered FMA dot from 0):
+//   VQ_CODEBOOK  modules/codebook.py:82-86                 d = (xx - 2 dot) + ee
+//   VQ_COS       external CosineSimCodebook (vector_quantize_pytorch.py:646-650): first argmax of the dot.
+//                xx = ee = 0: d = (0 - 2 dot) + 0 = -2 dot exactly (doubling is exact, order preserving)
+//   VQ_EUCLID    external EuclideanCodebook (:29-33, :463): first argmax of -cdist = first argmin of
+//                sqrt(clamp((xx + ee) + (-2 dot), 0)); the correctly rounded sqrt is part of the ordering
+//                (distinct squared distances can round to the same root -> tie -> lowest index)
+enum { VQ_CODEBOOK = 0, VQ_COS = 1, VQ_EUCLID = 2 };
+
+template <bool SPLIT, int MODE = VQ_CODEBOOK>
 __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restrict__ z,
                                                            const float *__restrict__ packed,
                                                            const float *__restrict__ ee_g, int64_t n, int n_codes,
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     const int t1 = SPLIT ? (t0 + tiles_per < ntiles_all ? t0 + tiles_per : ntiles_all) : ntiles_all;
     if (t0 >= t1) return;
     const int c0 = t0 * 32;  // first code of this split; ee_s holds ee[c0 .. t1*32)
-    if (!COS) {
+    if (MODE != VQ_COS) {
         for (int i = tid * 4; i < (t1 - t0) * 32; i += 256 * 4)
             *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + c0 + i);
         __syncthreads();
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(lo[k], lo[k]));
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(hi4[k], hi4[k]));
-        xx[g] = COS ? 0.0f : acc;
+        xx[g] = MODE == VQ_COS ? 0.0f : acc;
         // k = 2s + hi for MFMA step s
         xb[g][0] = 2.0f * (hi ? lo[1] : lo[0]);
         xb[g][1] = 2.0f * (hi ? lo[3] : lo[2]);
@@ -115,14 +121,18 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         const int cbase = t * 32 + 4 * hi;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 e4 = COS ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+            const f32x4 e4 = MODE == VQ_COS ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
                                  : *reinterpret_cast<const f32x4 *>(ee_s + cbase - c0 + 8 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int code = cbase + 8 * q + e;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const float d = __fadd_rn(__fsub_rn(xx[g], acc[g][q * 4 + e]), e4[e]);
+                    float d;
+                    if (MODE == VQ_EUCLID)  // + 0.0f: sqrt(-0.0) = -0.0 must not order below +0.0 in the split key
+                        d = __fadd_rn(__fsqrt_rn(fmaxf(__fsub_rn(__fadd_rn(xx[g], e4[e]), acc[g][q * 4 + e]), 0.0f)), 0.0f);
+                    else
+                        d = __fadd_rn(__fsub_rn(xx[g], acc[g][q * 4 + e]), e4[e]);
                     if (d < best[g]) {
                         best[g] = d;
                         bidx[g] = code;
@@ -411,8 +421,10 @@ extern "C" int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, 
     return OMNITOK_OK;
 }
 
+template <int MODE>
 static int launch_vq(const float *z, const float *packed, const float *ee, int64_t n, int n_codes, int64_t *ids,
-                     bool cosine, hipStream_t stream) {
+                     hipStream_t stream) {
+    constexpr bool cosine = MODE == VQ_COS;
     const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
     // code-range splits: aim at >= 2048 workgroups (whole rounds of the chip's 512 two-per-CU slots at the
     // BASELINE sizes: C3 640 x 4 = 5 rounds, C2 256 x 8 = 4 rounds), at least 16 tiles (512 codes) each
@@ -423,29 +435,22 @@ static int launch_vq(const float *z, const float *packed, const float *ee, int64
     if (nsplit > ntiles) nsplit = ntiles;
     const int tiles_per = (ntiles + nsplit - 1) / nsplit;
     const int lds = cosine ? 0 : tiles_per * 32 * 4;
-    static int attr_bytes = 0;
+    static int attr_bytes = 0;  // per MODE instantiation
     if (lds > attr_bytes && lds > 65536) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<false, false>),
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<false, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<true, false>),
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<true, MODE>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_bytes = lds;
     }
     const dim3 grid((unsigned)blocks, nsplit);
     if (nsplit == 1) {
-        if (cosine)
-            hipLaunchKernelGGL((vq_argmin_kernel<false, true>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
-        else
-            hipLaunchKernelGGL((vq_argmin_kernel<false, false>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes,
-                               ids);
+        hipLaunchKernelGGL((vq_argmin_kernel<false, MODE>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
         OT_LAUNCH_CHECK("vq_argmin");
         return OMNITOK_OK;
     }
     OT_HIP(hipMemsetAsync(ids, 0xFF, (size_t)n * 8, stream));
-    if (cosine)
-        hipLaunchKernelGGL((vq_argmin_kernel<true, true>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
-    else
-        hipLaunchKernelGGL((vq_argmin_kernel<true, false>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
+    hipLaunchKernelGGL((vq_argmin_kernel<true, MODE>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
     OT_LAUNCH_CHECK("vq_argmin");
     hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n);
     OT_LAUNCH_CHECK("vq_finalize");
@@ -459,7 +464,7 @@ extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const floa
     OT_CHECK_ARG(z && packed && ee && ids, "vq_argmin: null pointer");
     OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin: n_codes=%d unsupported", n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin: unaligned");
-    return launch_vq(z, packed, ee, n, n_codes, ids, false, stream);
+    return launch_vq<VQ_CODEBOOK>(z, packed, ee, n, n_codes, ids, stream);
 }
 
 extern "C" int omnitok_vq_argmax_cos(const float *z, const float *packed, int64_t n, int n_codes, int64_t *ids,
@@ -469,7 +474,18 @@ extern "C" int omnitok_vq_argmax_cos(const float *z, const float *packed, int64_
     OT_CHECK_ARG(z && packed && ids, "vq_argmax_cos: null pointer");
     OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmax_cos: n_codes=%d unsupported", n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed), "vq_argmax_cos: unaligned");
-    return launch_vq(z, packed, nullptr, n, n_codes, ids, true, stream);
+    return launch_vq<VQ_COS>(z, packed, nullptr, n, n_codes, ids, stream);
+}
+
+extern "C" int omnitok_vq_argmin_cdist(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
+                                       int64_t *ids, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(z && packed && ee && ids, "vq_argmin_cdist: null pointer");
+    OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin_cdist: n_codes=%d unsupported",
+                 n_codes);
+    OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin_cdist: unaligned");
+    return launch_vq<VQ_EUCLID>(z, packed, ee, n, n_codes, ids, stream);
 }
 
 extern "C" int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_codes, int cdim,

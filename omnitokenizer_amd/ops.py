@@ -245,6 +245,18 @@ def vq_argmax_cos(z, embed, prepared=None):
     return ids
 
 
+def vq_argmin_cdist(z, embed, prepared=None):
+    """ids[n] = first argmax_c of -cdist(z[n], embed[c]) (int64): the external EuclideanCodebook, bit-exact with
+    reference quantizer/vector_quantize_pytorch.py:29-33, 463."""
+    z = _req(z, "z")
+    packed, ee = prepared if prepared is not None else vq_prepare(embed)
+    n = z.numel() // 8
+    ids = torch.empty(z.shape[:-1], device=z.device, dtype=torch.int64)
+    check(_lib.load().omnitok_vq_argmin_cdist(_p(z), _p(packed), _p(ee), n, embed.shape[0], _p(ids), _stream()),
+          "vq_argmin_cdist")
+    return ids
+
+
 def dequant_post_vq(ids, codebook, w, b):
     ids = _req(ids, "ids", torch.int64)
     D = w.shape[0]

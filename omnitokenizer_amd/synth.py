@@ -175,8 +175,9 @@ def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, tor
             sd[name] = torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1)))
             continue
         if name == "codebook._codebook.embed":
-            v = randn(1.0)  # l2norm(uniform_init(...)), vector_quantize_pytorch.py:539: unit-norm rows
-            v = v / np.linalg.norm(v, axis=-1, keepdims=True)
+            v = randn(1.0)
+            if cfg.l2_code:  # CosineSimCodebook: l2norm(uniform_init(...)), vector_quantize_pytorch.py:539
+                v = v / np.linalg.norm(v, axis=-1, keepdims=True)
         elif name == "codebook._codebook.embed_avg":
             v = sd["codebook._codebook.embed"].numpy().copy()
         elif name == "codebook._codebook.initted":

@@ -24,6 +24,8 @@ def _lib():
     lib.oracle_vq_argmax_cos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                          ctypes.c_int64, ctypes.c_void_p]
     lib.oracle_vq_argmax_cos.restype = None
+    lib.oracle_vq_argmin_cdist.argtypes = lib.oracle_vq_argmax_cos.argtypes
+    lib.oracle_vq_argmin_cdist.restype = None
     return lib
 
 
@@ -46,4 +48,13 @@ def vq_argmax_cos(x: np.ndarray, embed: np.ndarray):
     assert e.shape[1] == dim
     ids = np.empty(n, np.int64)
     _lib().oracle_vq_argmax_cos(x.ctypes.data, e.ctypes.data, n, e.shape[0], dim, ids.ctypes.data)
+    return ids
+
+
+def vq_argmin_cdist(x: np.ndarray, embed: np.ndarray):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    e = np.ascontiguousarray(embed, dtype=np.float32)
+    n, dim = x.shape
+    ids = np.empty(n, np.int64)
+    _lib().oracle_vq_argmin_cdist(x.ctypes.data, e.ctypes.data, n, e.shape[0], dim, ids.ctypes.data)
     return ids

@@ -323,10 +323,22 @@ def vq_argmin(z_flat, codebook):
     return torch.argmin(dist, dim=1)
 
 
-def ext_pre_vq(sd, tok):
-    """--use_external_codebook: VectorQuantize.project_in (512 -> codebook_dim, +bias) then the cosine
-    codebook's transform_input = l2norm (vector_quantize_pytorch.py:905, 915, 535).  [b,t,h,w,cdim]."""
-    return F.normalize(F.linear(tok, sd["codebook.project_in.weight"], sd["codebook.project_in.bias"]), p=2, dim=-1)
+def ext_pre_vq(sd, tok, cosine=True):
+    """--use_external_codebook: VectorQuantize.project_in (512 -> codebook_dim, +bias) then the codebook's
+    transform_input: l2norm for the cosine codebook, identity for the Euclidean one
+    (vector_quantize_pytorch.py:905, 915, 535, 259).  [b,t,h,w,cdim]."""
+    z = F.linear(tok, sd["codebook.project_in.weight"], sd["codebook.project_in.bias"])
+    return F.normalize(z, p=2, dim=-1) if cosine else z
+
+
+def vq_argmin_cdist(z_flat, embed):
+    """EuclideanCodebook.forward in eval (vector_quantize_pytorch.py:29-33, 463-465): dist = -cdist,
+    cdist = sqrt(clamp(x2 + y2 + (-2) * x.y, 0)); ids = argmax -> first maximum."""
+    x2 = (z_flat ** 2).sum(-1)
+    y2 = (embed ** 2).sum(-1)
+    xy = torch.einsum("bid,bjd->bij", z_flat[None], embed[None])[0] * -2
+    dist = -(x2[:, None] + y2[None, :] + xy).clamp(min=0).sqrt()
+    return dist.argmax(dim=-1)
 
 
 def vq_argmax_cos(z_flat, embed):
@@ -346,11 +358,12 @@ def encode(sd, x, is_image, cfg, include_embeddings=False, taps=None):
     """reference omnitokenizer.py:247-258 VQGAN.encode."""
     tok = encoder(sd, x, is_image, cfg, taps)
     if cfg.use_external_codebook:
-        z = ext_pre_vq(sd, tok)
+        z = ext_pre_vq(sd, tok, cfg.l2_code)
         if taps is not None:
             taps["z"] = z
         b, t, h, w, c = z.shape
-        ids = vq_argmax_cos(z.reshape(-1, c), sd["codebook._codebook.embed"][0]).view(b, t, h, w)
+        quant = vq_argmax_cos if cfg.l2_code else vq_argmin_cdist  # use_cosine_sim = args.l2_code, :134
+        ids = quant(z.reshape(-1, c), sd["codebook._codebook.embed"][0]).view(b, t, h, w)
         if include_embeddings:  # eval: no straight-through term (vector_quantize_pytorch.py:935)
             return ext_embeddings(sd, ids).permute(0, 4, 1, 2, 3), ids
         return ids

@@ -63,3 +63,31 @@ void oracle_vq_argmax_cos(const float *x, const float *E, int64_t n, int64_t n_c
         ids[i] = best_c;
     }
 }
+
+/* --use_external_codebook without l2_code, Euclidean: reference quantizer/vector_quantize_pytorch.py:29-33, 463
+ *     cdist = sqrt(clamp((x2 + y2) + (-2 * dot), 0));  ids = (-cdist).argmax(-1)
+ * x2, y2 sequential sums of rounded squares, dot the k-ordered FMA chain, sqrtf correctly rounded; the
+ * first maximum of -cdist is the first minimum of cdist. */
+void oracle_vq_argmin_cdist(const float *x, const float *E, int64_t n, int64_t n_codes, int64_t dim, int64_t *ids)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float *xi = x + i * dim;
+        float xx = 0.0f;
+        for (int64_t k = 0; k < dim; ++k) { float sq = xi[k] * xi[k]; xx = xx + sq; }
+        float best = INFINITY;
+        int64_t best_c = 0;
+        for (int64_t c = 0; c < n_codes; ++c) {
+            const float *e = E + c * dim;
+            float ee = 0.0f, dot = 0.0f;
+            for (int64_t k = 0; k < dim; ++k) {
+                float sq = e[k] * e[k];
+                ee = ee + sq;
+                dot = fmaf(xi[k], e[k], dot);
+            }
+            float d2 = (xx + ee) + (dot * -2.0f);
+            float d = sqrtf(d2 > 0.0f ? d2 : 0.0f);
+            if (d < best || c == 0) { best = d; best_c = c; }
+        }
+        ids[i] = best_c;
+    }
+}

@@ -187,6 +187,9 @@ EXT_CASES = [  # --use_external_codebook (VectorQuantize, cosine similarity): SU
     ("ext_s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64, use_external_codebook=True), 2, 1, 1),
     ("ext_s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64, use_external_codebook=True), 1, 5, 1),
     ("ext_s1_legacy_r128_vid", 1, "legacy", dict(resolution=128, use_external_codebook=True, n_codes=16384), 1, 5, 2),
+    # without --l2_code VectorQuantize uses its EuclideanCodebook (use_cosine_sim = args.l2_code, omnitokenizer.py:134)
+    ("ext_euclid_s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64, use_external_codebook=True, l2_code=False), 2, 1, 1),
+    ("ext_euclid_s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64, use_external_codebook=True, l2_code=False), 1, 5, 1),
 ]
 
 
@@ -207,7 +210,7 @@ def run_ext_case(name, stage, mode, overrides, batch, frames, stride):
         emb, ids = model.encode(x, is_image, include_embeddings=True)
         tok = model.encoder(x, is_image)                                  # b d t h w
         z = model.codebook._codebook.transform_input(
-            model.codebook.project_in(tok.permute(0, 2, 3, 4, 1)))          # b t h w c, unit norm
+            model.codebook.project_in(tok.permute(0, 2, 3, 4, 1)))          # b t h w c (unit norm if cosine)
         vq = model.codebook(model.pre_vq_conv(tok))
         assert torch.equal(vq["encodings"], ids)
         recon = model.decoder(model.post_vq_conv(vq["embeddings"]), is_image)
@@ -230,6 +233,32 @@ def run_ext_case(name, stage, mode, overrides, batch, frames, stride):
     )
     print(f"{name}: ids {tuple(ids.shape)} uniq {ids.unique().numel()} recon {tuple(recon.shape)} "
           f"absmax {recon.abs().max().item():.3f}")
+
+
+def make_vq_cdist_kat():
+    """Known answers of the reference's EuclideanCodebook.forward (eval), incl. duplicated and exact codes."""
+    rh.install_stubs()
+    from OmniTokenizer.quantizer.vector_quantize_pytorch import EuclideanCodebook
+    n_codes = 8192
+    rng = np.random.Generator(np.random.PCG64(101))
+    E = rng.standard_normal((n_codes, 8), dtype=np.float32)
+    E[n_codes // 2] = E[17]
+    E[n_codes - 1] = E[17]
+    E[5] = E[3]
+    z = rng.standard_normal((4096, 8), dtype=np.float32)
+    z[3000:3064] = E[17]
+    z[3064:3100] = E[3]
+    z[3100:3200] = E[rng.integers(0, n_codes, 100)]
+    z[3200:3300] *= 1e-3
+    z[3300:3400] *= 30.0
+    cb = EuclideanCodebook(8, n_codes).eval()
+    cb.embed.data.copy_(torch.from_numpy(E)[None])
+    with torch.no_grad():
+        _, ind, _ = cb(torch.from_numpy(z)[None])
+    ids = ind.reshape(-1).numpy()
+    assert (ids[3000:3064] == 17).all() and (ids[3064:3100] == 3).all()
+    np.savez_compressed(os.path.join(OUT, "vq_cdist_kat_8192.npz"), z=z, codebook=E, ids=ids.astype(np.int16))
+    print(f"vq_cdist_kat_8192: uniq {np.unique(ids).size}")
 
 
 def make_vq_cos_kat():
@@ -313,6 +342,7 @@ if __name__ == "__main__":
             run_case(*c)
     if only in (None, "ext"):
         make_vq_cos_kat()
+        make_vq_cdist_kat()
         for c in EXT_CASES:
             run_ext_case(*c)
     if only in (None, "gpt"):

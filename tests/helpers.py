@@ -21,7 +21,9 @@ SMALL_CASES = [c for c in E2E_CASES if "r64" in c]
 VARIANT_CASES = ["var_pool_a_r128_vid", "var_pool_m_r128_img", "var_pool_l_r128_vid", "var_cnn_r128_img",
                  "var_cnn_r128_vid", "var_defer_t_r128_vid", "var_defer_s_r128_vid", "var_defer_ts_r128_img",
                  "var_genup2_r64_vid"]
-EXT_CASES = ["ext_s2_sdpa_r64_img", "ext_s2_sdpa_r64_vid", "ext_s1_legacy_r128_vid"]  # external cosine codebook
+# external VectorQuantize: cosine-similarity codebook (l2_code) and Euclidean codebook (no l2_code)
+EXT_CASES = ["ext_s2_sdpa_r64_img", "ext_s2_sdpa_r64_vid", "ext_s1_legacy_r128_vid", "ext_euclid_s2_sdpa_r64_img",
+             "ext_euclid_s2_sdpa_r64_vid"]
 VAE_CASES = ["vae_s2_sdpa_r64_img", "vae_s2_sdpa_r64_vid", "vae_s1_legacy_r64_vid", "vae_s2_sdpa_r256_vid"]
 
 

@@ -85,11 +85,11 @@ def test_config_rejects_unbuilt_variants():
     from omnitokenizer_amd import make_args
     from omnitokenizer_amd.config import OmniTokConfig
     # 'n'/'r' Up blocks make the reference decoder itself raise (omnitokenizer.py:1078); GroupNorm(32)
-    # over the cnn decoder's 3 channels cannot be constructed (base.py:274); the external VectorQuantize is
-    # built for its cosine-similarity codebook only (l2_code)
+    # over the cnn decoder's 3 channels cannot be constructed (base.py:274); the external VectorQuantize
+    # exists for codebook_type 'vq' only (omnitokenizer.py:139-140)
     for bad in (dict(dec_block="tntt"), dict(dec_block="trtt"), dict(dec_block="tatt"), dict(enc_block="ttnw"),
                 dict(patch_embed="cnn", norm_type="group"), dict(patch_embed="conv"),
-                dict(use_external_codebook=True, l2_code=False), dict(use_external_codebook=True, codebook_type="lfq"),
+                dict(use_external_codebook=True, codebook_type="lfq"),
                 dict(use_external_codebook=True, use_vae=True), dict(dim_head=32)):
         with pytest.raises((NotImplementedError, ValueError)):
             OmniTokConfig.from_args(make_args(2, **bad))

@@ -357,11 +357,12 @@ def test_external_codebook_vs_reference_golden(models, name):
     E = c.sd["codebook._codebook.embed"][0]
     x = c.x.cuda()
     emb, ids, z = m.encode(x, c.is_image, include_embeddings=True, return_latents=True)
-    # the quantiser alone on the reference's unit-norm z: bit-exact first-argmax
-    assert torch.equal(ops.vq_argmax_cos(c.z.cuda(), E.cuda()).cpu(), c.ids)
+    # the quantiser alone on the reference's z: bit-exact first-argmax (cosine) / first-argmin of cdist
+    quant = ops.vq_argmax_cos if c.cfg.l2_code else ops.vq_argmin_cdist
+    assert torch.equal(quant(c.z.cuda(), E.cuda()).cpu(), c.ids)
     zerr = (z.cpu() - c.z).abs().max().item()
     assert zerr < Z_TOL
-    flips = assert_ids_match_or_near_tie(ids, c.ids, z, E, name)  # unit norm: nearest == most similar
+    flips = assert_ids_match_or_near_tie(ids, c.ids, z, E, name)  # cosine, unit norm: nearest == most similar
     assert tuple(emb.shape) == (c.batch, 512) + tuple(c.ids.shape[1:])
     if flips == 0:
         assert (emb.permute(0, 2, 3, 4, 1)[..., ::8].cpu() - c.emb).abs().max().item() < 1e-5

@@ -486,6 +486,27 @@ def test_vq_argmax_cos_bit_exact_vs_reference_kat(ops, split):
     assert np.array_equal(c_oracle.vq_argmax_cos(g["z"][:512], g["codebook"]), ids_ref[:512])
 
 
+@pytest.mark.parametrize("split", [0, 1, 4])
+def test_vq_argmin_cdist_bit_exact_vs_reference_kat(ops, split):
+    """External Euclidean codebook: ids bit-exact against the reference's EuclideanCodebook.forward (the
+    correctly rounded sqrt of the clamped squared distance takes part in the ordering)."""
+    from omnitokenizer_amd import _lib
+    g = np.load(os.path.join(GOLDEN, "vq_cdist_kat_8192.npz"))
+    z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
+    _lib.set_option("vq_split", split)
+    try:
+        for n in (4096, 1000, 31):
+            ids = ops.vq_argmin_cdist(dev(z[:n]), dev(E)).cpu().numpy()
+            assert np.array_equal(ids, ids_ref[:n]), f"{(ids != ids_ref[:n]).sum()} of {n} ids differ"
+    finally:
+        _lib.set_option("vq_split", 0)
+    rng = np.random.default_rng(7)
+    zz = rng.standard_normal((20000, 8), dtype=np.float32)
+    EE = rng.standard_normal((1024, 8), dtype=np.float32)
+    ids = ops.vq_argmin_cdist(dev(torch.from_numpy(zz)), dev(torch.from_numpy(EE))).cpu().numpy()
+    assert np.array_equal(ids[:4096], c_oracle.vq_argmin_cdist(zz[:4096], EE))
+
+
 def test_vq_argmin_large_random_vs_c_oracle(ops):
     rng = np.random.default_rng(5)
     E = rng.standard_normal((8192, 8), dtype=np.float32)

@@ -101,7 +101,16 @@ def test_vq_cos_c_oracle_matches_reference_kat():
     assert np.array_equal(t, ids)
 
 
-@pytest.mark.parametrize("name", EXT_CASES[:2])
+def test_vq_cdist_c_oracle_matches_reference_kat():
+    g = np.load(os.path.join(GOLDEN, "vq_cdist_kat_8192.npz"))
+    ids = c_oracle.vq_argmin_cdist(g["z"], g["codebook"])
+    assert np.array_equal(ids, g["ids"].astype(np.int64))
+    assert (ids[3000:3064] == 17).all() and (ids[3064:3100] == 3).all()
+    t = orc.vq_argmin_cdist(torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"])).numpy()
+    assert np.array_equal(t, ids)
+
+
+@pytest.mark.parametrize("name", [c for c in EXT_CASES if "r128" not in c])
 def test_oracle_external_codebook_matches_reference(name):
     """--use_external_codebook (VectorQuantize, cosine similarity)."""
     c = GoldenCase(name)
@@ -113,5 +122,6 @@ def test_oracle_external_codebook_matches_reference(name):
     assert (taps["z"] - c.z).abs().max().item() < 2e-6
     assert (emb.permute(0, 2, 3, 4, 1)[..., ::8] - c.emb).abs().max().item() < 1e-6
     assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
-    cids = c_oracle.vq_argmax_cos(c.z.reshape(-1, 8).numpy(), c.sd["codebook._codebook.embed"][0].numpy())
+    cq = c_oracle.vq_argmax_cos if c.cfg.l2_code else c_oracle.vq_argmin_cdist
+    cids = cq(c.z.reshape(-1, 8).numpy(), c.sd["codebook._codebook.embed"][0].numpy())
     assert np.array_equal(cids, c.ids.reshape(-1).numpy())
