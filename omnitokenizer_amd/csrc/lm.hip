@@ -28,7 +28,6 @@
 namespace omnitok {
 
 constexpr int LM_CHUNK = 256;   // keys per attention workgroup
-constexpr int LM_MAX_BQ = 8;    // batch rows sharing one pass over a weight matrix
 
 __global__ __launch_bounds__(256) void lm_embed_kernel(const int64_t *__restrict__ idx, const int32_t *__restrict__ pos,
                                                        const float *__restrict__ tok, const float *__restrict__ pe,
