@@ -161,6 +161,39 @@ def test_oracle_parity_other_shapes(models):
     assert (m.decode(ids_ref.cuda(), False).cpu() - rec_ref).abs().max().item() < PIXEL_TOL
 
 
+@pytest.mark.parametrize("overrides,mode", [
+    (dict(embedding_dim=256, heads=4, spatial_depth=2, enc_block="tw", dec_block="wt", temporal_depth=1, ff_mult=2.0,
+          n_codes=1024, causal_in_temporal_transformer=False, causal_in_peg=False, temporal_patch_size=2), "sdpa"),
+    (dict(embedding_dim=768, heads=12, spatial_depth=1, enc_block="t", dec_block="t", temporal_depth=2, ff_mult=3.0,
+          n_codes=2048, spatial_pos="rel"), "legacy"),
+    (dict(embedding_dim=384, heads=6, spatial_depth=3, enc_block="wtw", dec_block="ttw", temporal_depth=1,
+          n_codes=4096, l2_code=False, causal_in_peg=False), "sdpa"),
+])
+def test_other_architectures_vs_oracle(overrides, mode):
+    """Hyper-parameters no released checkpoint uses (width, heads, depth, ff_mult, block strings,
+    non-causal temporal attention / PEG, no l2 normalisation before the quantiser), straight against
+    the CPU oracle -- which tests/test_oracle_vs_reference.py pins to the live reference."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    args = make_args(2, resolution=64, **overrides)
+    cfg = OmniTokConfig.from_args(args, attention_mode=mode)
+    sd = synth.synth_state_dict(cfg, seed=13)
+    m = OmniTokenizer_VQGAN(args, attention_mode=mode)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda().eval()
+    for is_image, x in ((True, synth.synth_image(2, 64, seed=5)), (False, synth.synth_video(2, 5, 64, seed=6))):
+        with torch.no_grad():
+            taps = {}
+            ids_ref = orc.encode(sd, x, is_image, cfg, taps=taps)
+            rec_ref = orc.decode(sd, ids_ref, is_image, cfg)
+        ids, z = m.encode(x.cuda(), is_image, return_latents=True)
+        scale = max(1.0, taps["z"].abs().max().item())
+        assert (z.cpu() - taps["z"]).abs().max().item() < Z_TOL * scale
+        assert_ids_match_or_near_tie(ids, ids_ref, z, sd["codebook.embeddings"], str(overrides))
+        assert (m.decode(ids_ref.cuda(), is_image).cpu() - rec_ref).abs().max().item() < PIXEL_TOL
+
+
 # ---- size-independent properties at BASELINE.json sizes (C2: B=64 images, C3: B=32 clips) -------
 @pytest.mark.parametrize("is_image,batch", [(True, 64), (False, 32)])
 def test_full_size_properties(models, is_image, batch):
