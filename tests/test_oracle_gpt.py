@@ -77,3 +77,27 @@ def test_product_gpt_state_dict_and_cpu_refusal():
         m(torch.zeros(1, 4, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True)
+
+
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.9), (2048, 0.9), (64, 1.0), (300, 0.5), (1, 0.3)])
+def test_product_token_selection_matches_reference_semantics(top_k, top_p):
+    """omnitokenizer_amd.gpt's filtering (pure torch, CPU-runnable) == the oracle's restatement of
+    reference gpt.py:19-51, and its single-sort sampling branch draws from exactly that distribution."""
+    import torch.nn.functional as F
+    from omnitokenizer_amd import gpt as og
+    g = torch.Generator().manual_seed(top_k)
+    lg = torch.randn(4, 300, generator=g) * 3
+    lg[0, 10] = lg[0, 11]
+    ref = go.top_k_top_p_filtering(lg, top_k, top_p)
+    assert torch.equal(og.top_k_top_p_filtering(lg.clone(), top_k=top_k, top_p=top_p), ref)
+    # greedy branch: same token as the reference's topk(softmax(filtered))
+    assert torch.equal(og._select(lg.clone(), False, top_k, top_p), torch.topk(F.softmax(ref, -1), 1)[1])
+    # stochastic branch: empirical support is inside the reference's support, frequencies follow its probs
+    probs = F.softmax(ref, -1)
+    torch.manual_seed(0)
+    draws = torch.cat([og._select(lg.clone(), True, top_k, top_p) for _ in range(400)], 1)  # [4, 400]
+    assert (probs.gather(1, draws) > 0).all()
+    if top_k > 1:
+        top = probs.argmax(-1)
+        freq = (draws == top[:, None]).float().mean(1)
+        assert (freq - probs.gather(1, top[:, None])[:, 0]).abs().max().item() < 0.12
