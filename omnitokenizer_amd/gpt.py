@@ -335,6 +335,8 @@ def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, t
         raise NotImplementedError("vtokens_pos boxes are not built")
     x = x.to(model.device).long()
     B, cond_len = x.shape
+    if cond_len + steps - 1 > model.block_size:  # the reference fails at pos_emb[:, past_length] (gpt.py:248)
+        raise ValueError(f"{cond_len} conditioning + {steps} sampled tokens exceed block_size {model.block_size}")
     model.reset_streams(B, cond_len + steps)
     model._feed(x[:, :cond_len - 1])
     if use_graph:
@@ -374,6 +376,8 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
     sos = torch.zeros_like(x)
     cond = torch.cat((x, sos), 1) if class_first else torch.cat((sos, x), 1)
     cond_len = cond.shape[1]  # 2
+    if cond_len + steps - 1 > model.block_size:
+        raise ValueError(f"{cond_len} conditioning + {steps} sampled tokens exceed block_size {model.block_size}")
     model.reset_streams(2 * B, cond_len + steps)
     # conditioning prefix of the conditional rows only (rows [B, 2B) stay empty): advance them by hand
     for t in range(cond_len - 1):

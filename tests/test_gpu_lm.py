@@ -193,6 +193,9 @@ def test_gpt_errors(gpts, lib):
         m(torch.zeros(1, m.block_size + 1, dtype=torch.long, device="cuda"))
     with pytest.raises(ValueError):
         m.reset_streams(17, 8)
+    from omnitokenizer_amd import gpt as og
+    with pytest.raises(ValueError, match="block_size"):
+        og.sample_with_past(torch.zeros(1, 3, dtype=torch.long, device="cuda"), m, m.block_size)
     from omnitokenizer_amd._lib import OmnitokLmConfig
     h = ctypes.c_void_p()
     cfg = OmnitokLmConfig(100, 16, 1, 3, 300)
