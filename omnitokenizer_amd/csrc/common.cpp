@@ -17,6 +17,7 @@ namespace omnitok {
 extern int g_gemm_variant;
 extern int g_gemm_lds_pad_kb;
 extern int g_gemm_small;
+extern int g_gemm_gn;
 extern int g_vq_split;
 extern long long *g_gemm_trace;
 extern int g_peg_variant;
@@ -26,6 +27,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     if (!name) return OMNITOK_ERR_INVALID;
     if (!strcmp(name, "gemm_variant")) omnitok::g_gemm_variant = value;
     else if (!strcmp(name, "gemm_lds_pad_kb")) omnitok::g_gemm_lds_pad_kb = value;
+    else if (!strcmp(name, "gemm_gn")) omnitok::g_gemm_gn = value;
     else if (!strcmp(name, "gemm_small")) omnitok::g_gemm_small = value;
     else if (!strcmp(name, "vq_split")) omnitok::g_vq_split = value;
     else if (!strcmp(name, "peg_variant")) omnitok::g_peg_variant = value;

@@ -25,6 +25,7 @@ namespace omnitok {
 // 256x128 x 8 waves), +4 = force; "gemm_lds_pad_kb" extra dynamic LDS per workgroup (variants 0, 1).
 int g_gemm_variant = 1;
 int g_gemm_lds_pad_kb = 0;
+int g_gemm_gn = 8;     // "gemm_gn": tile columns per column group
 int g_gemm_small = 1;  // "gemm_small": 64x128 tiles when the 128x128 tiling cannot fill the chip
 long long *g_gemm_trace = nullptr;
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
     const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     int64_t bm;
     int bn;
-    tile_coords(lid, p.nbm, p.nbn, bm, bn);
+    tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
 
     // ---- loader mapping: thread -> 4 rows x one float4 column of the 128x32 tile ----------
     const int lrow = tid >> 3, lc4 = tid & 7;
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_f32_mfma_persistent(GemmPara
         const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
         int64_t tbm;
         int tbn;
-        tile_coords(lid, p.nbm, p.nbn, tbm, tbn);
+        tile_coords(lid, p.nbm, p.nbn, p.gn, tbm, tbn);
 #pragma unroll
         for (int r = 0; r < NA; ++r) {
             int64_t gr = tbm * TM + lrow + RPP * r;
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_f32_mfma_persistent(GemmPara
         const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
         int64_t ebm;
         int ebn;
-        tile_coords(lid, p.nbm, p.nbn, ebm, ebn);
+        tile_coords(lid, p.nbm, p.nbn, p.gn, ebm, ebn);
         // the shared epilogue addresses 64x64 wave tiles in 128-row units
         gemm_epilogue<FLAGS, false>(p, acc, ebm * (WM / 2) + (wm >> 1), ebn, wm & 1, wn, r32, hi);
         zero_acc();
@@ -561,6 +562,7 @@ extern "C" int omnitok_gemm(const float *a, int64_t lda, const float *w, int64_t
     p.M = M; p.N = N; p.K = K;
     p.nbn = (N + BN - 1) / BN;
     p.a_rpg = a_rows_per_group; p.a_stride = a_group_stride; p.a_off = a_group_offset;
+    p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
     switch (flags) {
         case 0: return launch_gemm<0>(p, stream);
         case OMNITOK_GEMM_BIAS: return launch_gemm<OMNITOK_GEMM_BIAS>(p, stream);

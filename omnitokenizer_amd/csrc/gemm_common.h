@@ -23,6 +23,7 @@ struct GemmParams {
     int ntiles;
     long long *trace;  // debug: per-wave s_memtime stamps of workgroup 0 (null = off)
     int64_t a_rpg, a_stride, a_off;
+    int gn;  // tile columns per column group of the tile order ("gemm_gn" option, default 8)
 };
 
 // exact-erf GELU (reference attention.py:155-156, F.gelu default).  erf by Abramowitz-Stegun 7.1.26
@@ -147,8 +148,7 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // in flight then touch 8 A panels + 8 W tiles (4 MiB at K = 512 = the XCD's L2) instead of 3 A
 // panels + ALL W tiles (5.8 MiB for the FF-in weight, which thrashed: 4.5 GB of memory-side reads
 // per launch against 0.34 GB of operands).
-constexpr int GN = 8;
-__device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int64_t &bm, int &bn) {
+__device__ __forceinline__ void tile_coords(int lid, int nbm, int nbn, int GN, int64_t &bm, int &bn) {
     const int full = nbn / GN;            // number of full column groups
     const int gsz = GN * nbm;             // tiles per full group
     int cg = lid / gsz, rem = lid - cg * gsz, width = GN;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_persistent(SplitGemmParams
         const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
         int64_t tbm;
         int tbn;
-        tile_coords(lid, p.nbm, p.nbn, tbm, tbn);
+        tile_coords(lid, p.nbm, p.nbn, p.gn, tbm, tbn);
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             int64_t gr = tbm * BM + lrow + 64 * r;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_persistent(SplitGemmParams
         const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
         int64_t ebm;
         int ebn;
-        tile_coords(lid, p.nbm, p.nbn, ebm, ebn);
+        tile_coords(lid, p.nbm, p.nbn, p.gn, ebm, ebn);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -289,6 +289,7 @@ extern "C" int omnitok_gemm_bf16x3(const void *a_planes, const void *w_planes, c
     OT_CHECK_ARG(nt < (1ll << 31), "gemm_bf16x3: grid too large");
     p.ntiles = (int)nt;
     p.a_rpg = 0; p.a_stride = 0; p.a_off = 0;
+    p.gn = 8;
     p.trace = nullptr;
     sp.a3 = static_cast<const char *>(a_planes);
     sp.w3 = static_cast<const char *>(w_planes);
