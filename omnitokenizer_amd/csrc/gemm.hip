@@ -127,24 +127,26 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma(GemmParams p) {
 
 // Small-problem variant (launch-latency regime, e.g. one 256x256 image = 1024 tokens): when the
 // 128x128 tiling gives fewer workgroups than CUs, the time of a GEMM is the serial MFMA chain of one
-// wave.  64x128 tiles with 32x64 wave tiles halve that chain and double the workgroup count; the
-// GEGLU value/gate pairing (two adjacent 32-column blocks) still lives inside one wave.
+// wave.  64 x (64*NB) tiles with 32 x (32*NB) wave tiles shorten that chain 2x (NB = 2) or 4x (NB = 1) and
+// multiply the workgroup count; with NB = 2 the GEGLU value/gate pairing (two adjacent 32-column
+// blocks) still lives inside one wave.
 constexpr int SM_BM = 64;
-constexpr int SMALL_LDS_BYTES = 2 * (SM_BM + BN) * LDT * 4;
 
-template <int FLAGS>
+template <int FLAGS, int NB>
 __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int STAGE = (SM_BM + BN) * LDT;
+    constexpr int SBN = 64 * NB;                  // tile columns
+    constexpr int STAGE = (SM_BM + SBN) * LDT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r32 = lane & 31, hi = lane >> 5;
-    const int64_t bm = blockIdx.x / p.nbn;
-    const int bn = blockIdx.x % p.nbn;
+    const int nbn = (p.N + SBN - 1) / SBN;
+    const int64_t bm = blockIdx.x / nbn;
+    const int bn = blockIdx.x % nbn;
 
     const int lrow = tid >> 3, lc4 = tid & 7;
     const float *ap[2];
-    const float *wp[4];
+    const float *wp[2 * NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int64_t gr = bm * SM_BM + lrow + 32 * i;
@@ -154,18 +156,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
         ap[i] = p.a + ar * p.lda + lc4 * 4;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int wr = bn * BN + lrow + 32 * i;
+    for (int i = 0; i < 2 * NB; ++i) {
+        int wr = bn * SBN + lrow + 32 * i;
         if (wr > p.N - 1) wr = p.N - 1;
         wp[i] = p.w + (int64_t)wr * p.ldw + lc4 * 4;
     }
     const int st_off = lrow * LDT + lc4 * 4;
-    f32x4 ra[2], rb[4];
+    f32x4 ra[2], rb[2 * NB];
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) ra[i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
+        for (int i = 0; i < 2 * NB; ++i) rb[i] = *reinterpret_cast<const f32x4 *>(wp[i] + k0);
     };
     auto lstore = [&](int buf) {
         float *As = smem + buf * STAGE;
@@ -173,11 +175,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4 *>(As + st_off + i * 32 * LDT) = ra[i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
+        for (int i = 0; i < 2 * NB; ++i) *reinterpret_cast<f32x4 *>(Bs + st_off + i * 32 * LDT) = rb[i];
     };
-    f32x16 acc[2];
+    f32x16 acc[NB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
@@ -186,18 +188,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
     lstore(0);
     __syncthreads();
     const int a_frag_off = (wm * 32 + r32) * LDT + hi * 16;
-    const int b_frag_off = (wn * 64 + r32) * LDT + hi * 16;
+    const int b_frag_off = (wn * 32 * NB + r32) * LDT + hi * 16;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * BK);
         const float *As = smem + buf * STAGE;
         const float *Bs = As + SM_BM * LDT;
-        f32x4 af[4], bf[2][4];
+        f32x4 af[4], bf[NB][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             af[j] = *reinterpret_cast<const f32x4 *>(As + a_frag_off + 4 * j);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 bf[nb][j] = *reinterpret_cast<const f32x4 *>(Bs + b_frag_off + nb * 32 * LDT + 4 * j);
         }
 #pragma unroll
@@ -205,24 +207,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc[nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j][e], bf[nb][j][e], acc[nb], 0, 0, 0);
         if (kt + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
 
     const int64_t row0 = bm * SM_BM + wm * 32;
-    if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
+    if constexpr ((FLAGS & OMNITOK_GEMM_GEGLU) != 0) {
+        static_assert(NB == 2 || !(FLAGS & OMNITOK_GEMM_GEGLU), "GEGLU pairs two 32-column blocks per wave");
         const int ocol = (bn * 2 + wn) * 32 + r32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int64_t row = row0 + mfma32_row(r, hi);
-            if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[1][r]) * acc[0][r];
+            if (row < p.M) p.c[row * p.ldc + ocol] = gelu_erf(acc[NB - 1][r]) * acc[0][r];
         }
     } else {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            const int col = bn * BN + wn * 64 + nb * 32 + r32;
+        for (int nb = 0; nb < NB; ++nb) {
+            const int col = bn * SBN + wn * 32 * NB + nb * 32 + r32;
             const bool colok = col < p.N;
             float bv = 0.0f;
             if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = colok ? p.bias[col] : 0.0f;
@@ -239,6 +242,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_mfma_small(GemmParams p) {
             }
         }
     }
+}
+
+template <int FLAGS, int NB>
+static int launch_small(const GemmParams &p, hipStream_t stream) {
+    constexpr int SBN = 64 * NB;
+    constexpr int lds = 2 * (SM_BM + SBN) * LDT * 4;
+    static int attr = 0;
+    if (!attr) {
+        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_small<FLAGS, NB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = 1;
+    }
+    const int64_t nwg = ((p.M + SM_BM - 1) / SM_BM) * ((p.N + SBN - 1) / SBN);
+    hipLaunchKernelGGL((gemm_f32_mfma_small<FLAGS, NB>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    OT_LAUNCH_CHECK("gemm_f32_mfma_small");
+    return OMNITOK_OK;
 }
 
 // Persistent variant: workgroups walk the tile list (tile = blockIdx.x + i * gridDim.x, then
@@ -491,17 +510,13 @@ static int launch_gemm(GemmParams p, hipStream_t stream) {
     if (variant == 2) return launch_persistent<FLAGS, 4>(p, n_cu, stream);
     if (variant == 1) return launch_persistent<FLAGS, 2>(p, n_cu, stream);
     if (nwg < n_cu && g_gemm_small && !force) {
-        // fewer 128x128 tiles than CUs: 64x128 tiles, 32x64 per wave (half the serial MFMA chain)
-        static int small_attr = 0;
-        if (!small_attr) {
-            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_small<FLAGS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMALL_LDS_BYTES));
-            small_attr = 1;
+        // fewer 128x128 tiles than CUs: 64x128 tiles (32x64 per wave, half the serial MFMA chain); if even
+        // those leave most of the chip idle, 64x64 tiles (32x32 per wave, a quarter of the chain)
+        if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU)) {
+            const int64_t nwg128 = ((p.M + SM_BM - 1) / SM_BM) * p.nbn;
+            if (nwg128 < n_cu / 2 || g_gemm_small == 2) return launch_small<FLAGS, 1>(p, stream);
         }
-        const int64_t nwg_s = ((p.M + SM_BM - 1) / SM_BM) * p.nbn;
-        hipLaunchKernelGGL((gemm_f32_mfma_small<FLAGS>), dim3((unsigned)nwg_s), dim3(256), SMALL_LDS_BYTES, stream, p);
-        OT_LAUNCH_CHECK("gemm_f32_mfma_small");
-        return OMNITOK_OK;
+        return launch_small<FLAGS, 2>(p, stream);
     }
     const int lds = GEMM_LDS_BYTES + g_gemm_lds_pad_kb * 1024;
     const bool nedge = (p.N % 64) != 0;
