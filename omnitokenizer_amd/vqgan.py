@@ -118,6 +118,13 @@ class OmniTokenizer_VQGAN(nn.Module):
         model.load_state_dict(ckpt["state_dict"], strict=strict)
         return model
 
+    @property
+    def latent_shape(self):
+        """reference omnitokenizer.py:239-245: (frames, H, W) // args.downsample."""
+        a = self.args
+        inp = (a.sequence_length // a.sample_every_n_frames, a.resolution, a.resolution)
+        return tuple(s // d for s, d in zip(inp, a.downsample))
+
     def __del__(self):
         try:
             if self._engine is not None:
@@ -426,3 +433,11 @@ class OmniTokenizer_VQGAN(nn.Module):
 
     def workspace_bytes(self) -> int:
         return 0 if self._engine is None else int(_lib.load().omnitok_engine_workspace_bytes(self._engine))
+
+
+def load_vqgan(tokenizer, vqgan_ckpt, device=torch.device("cpu"), **kw):
+    """reference download.py:48-53: checkpoint -> eval-mode model on `device` (`tokenizer` is the
+    reference's unused selector argument)."""
+    vqgan = OmniTokenizer_VQGAN.load_from_checkpoint(vqgan_ckpt, strict=False, **kw).to(device)
+    vqgan.eval()
+    return vqgan

@@ -135,4 +135,7 @@ def test_load_from_pl_checkpoint(tmp_path, lib):
     assert m.cfg.attention_mode == "legacy" and not m.use_vae
     got = m.state_dict()
     assert all(torch.equal(got[k], v) for k, v in sd.items() if k in got)
+    from omnitokenizer_amd.vqgan import load_vqgan
+    m2 = load_vqgan("omnitokenizer", str(path))
+    assert not m2.training and m2.latent_shape == (4, 16, 16)  # (17 // 1, 64, 64) // (4, 4, 4)
     assert not any(k.startswith(("image_discriminator", "perceptual_model")) for k in got)
