@@ -139,3 +139,23 @@ def test_load_from_pl_checkpoint(tmp_path, lib):
     m2 = load_vqgan("omnitokenizer", str(path))
     assert not m2.training and m2.latent_shape == (4, 16, 16)  # (17 // 1, 64, 64) // (4, 4, 4)
     assert not any(k.startswith(("image_discriminator", "perceptual_model")) for k in got)
+
+
+def test_torch_custom_ops_registered_with_schemas(lib):
+    """SURVEY.md 8(b): the operators are schema-registered PyTorch custom ops (omnitok::*), with fake
+    (shape-inference) kernels so that they trace without a GPU."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from omnitokenizer_amd import ops
+    assert ops.CUSTOM_OPS_REGISTERED
+    assert str(torch.ops.omnitok.vq_argmin.default._schema) == "omnitok::vq_argmin(Tensor z, Tensor codebook) -> Tensor"
+    for name in ("linear", "layernorm", "attn_spatial", "attn_window", "attn_temporal", "peg3d"):
+        assert hasattr(torch.ops.omnitok, name)
+    with FakeTensorMode():
+        z, E = torch.empty(10, 3, 8, device="cuda"), torch.empty(8192, 8, device="cuda")
+        ids = torch.ops.omnitok.vq_argmin(z, E)
+        assert tuple(ids.shape) == (10, 3) and ids.dtype == torch.int64
+        y = torch.ops.omnitok.linear(torch.empty(7, 512, device="cuda"), torch.empty(192, 512, device="cuda"), None)
+        assert tuple(y.shape) == (7, 192)
+        q = torch.empty(2048, 512, device="cuda")
+        assert tuple(torch.ops.omnitok.attn_spatial(q, q, q, 1024, 8).shape) == (2048, 512)

@@ -365,6 +365,17 @@ def test_pre_vq_and_dequant(ops):
         ops.dequant_post_vq(dev(bad), dev(E), dev(pw), dev(pb))
 
 
+def test_torch_custom_ops_dispatch(ops):
+    """torch.ops.omnitok.* run the same kernels as the wrappers."""
+    g = np.load(os.path.join(GOLDEN, "vq_kat_8192.npz"))
+    z, E = dev(torch.from_numpy(g["z"][:512])), dev(torch.from_numpy(g["codebook"]))
+    assert torch.equal(torch.ops.omnitok.vq_argmin(z, E), ops.vq_argmin(z, E))
+    x, w, b = dev(rnd(300, 512, seed=1)), dev(rnd(192, 512, seed=2) * 0.05), dev(rnd(192, seed=3))
+    assert torch.equal(torch.ops.omnitok.linear(x, w, b), ops.linear(x, w, b))
+    gm = dev(rnd(512, seed=4) + 1.0)
+    assert torch.equal(torch.ops.omnitok.layernorm(x, gm, None), ops.layernorm(x, gm, None))
+
+
 def test_token_resample(ops):
     """pooling blocks / deferred pools vs the torch ops the reference calls (bit-exact: adds and
     power-of-two scalings in the same order)."""
