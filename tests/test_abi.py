@@ -159,3 +159,27 @@ def test_torch_custom_ops_registered_with_schemas(lib):
         assert tuple(y.shape) == (7, 192)
         q = torch.empty(2048, 512, device="cuda")
         assert tuple(torch.ops.omnitok.attn_spatial(q, q, q, 1024, 8).shape) == (2048, 512)
+
+
+def test_lm_argument_errors_without_gpu(lib):
+    """include/omnitok_lm.h: configuration / argument validation happens before any HIP call."""
+    from omnitokenizer_amd._lib import OmnitokLmConfig
+    h = ctypes.c_void_p()
+    bad = OmnitokLmConfig(100, 16, 1, 3, 300)           # head_dim 100
+    assert lib.omnitok_lm_create(ctypes.byref(bad), ctypes.byref(h)) != 0
+    assert b"head_dim" in lib.omnitok_last_error()
+    assert lib.omnitok_lm_create(None, ctypes.byref(h)) == -1
+    ok = OmnitokLmConfig(8192, 5120, 24, 16, 1536)
+    assert lib.omnitok_lm_create(ctypes.byref(ok), ctypes.byref(h)) == 0
+    try:
+        assert lib.omnitok_lm_step(h, None, None, None, 1, None, 1, None) == -1       # null pointers
+        assert lib.omnitok_lm_alloc_cache(h, 17, 64) == -1                             # more than 16 streams
+        assert lib.omnitok_lm_alloc_cache(h, 1, 9000) == -1                            # beyond 8192 positions
+        assert lib.omnitok_lm_gemv(None, None, None, None, None, None, None, 1, 8, 256, 0, None) == -1
+        shape = (ctypes.c_int64 * 2)(7, 7)
+        x = ctypes.c_float(0)
+        assert lib.omnitok_lm_set_weight(h, b"tok_emb.weight", ctypes.byref(x), shape, 2, None) == -1  # shape mismatch
+        assert b"tok_emb.weight" in lib.omnitok_last_error()
+        assert lib.omnitok_lm_set_weight(h, b"blocks.0.attn.mask", ctypes.byref(x), shape, 2, None) == 1  # ignored
+    finally:
+        lib.omnitok_lm_destroy(h)
