@@ -89,6 +89,13 @@ def main():
         "prefill_ms": round(t_prefill * 1e3, 2),  # a.ctx prefix tokens (batched prefill) + 1 sampled token
     }
     out_json["roofline"]["frac"] = round(out_json["roofline"]["achieved"] / PEAK_HBM_GBS, 4)
+    try:  # memory-side traffic of one step from the committed PMC pass (default model shape, B = 1 only)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["lm_step_b1"]
+        if (V, BS, L, H, C, B) == (8192, 5120, 24, 16, 1536, 1):
+            out_json["roofline"]["traffic"] = pmc["read_bytes"] + pmc["write_bytes"]
+            out_json["roofline"]["traffic_source"] = pmc["source"]
+    except Exception:
+        pass
     if not a.no_cpu_baseline:
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         x = cond.cpu()[:1, -1:]
