@@ -153,36 +153,6 @@ def sample_with_past_cfg(sd, x, n_head, steps, temperature=1.0, sample_logits=Tr
     return (out, torch.stack(all_logits, 1)) if return_logits else out
 
 
-def synth_gpt_state(vocab_size, block_size, n_layer, n_head, n_embd, seed=0):
-    """Seeded numpy weights with the reference GPT's key names / shapes (gpt.py:172-193)."""
-    import numpy as np
-    import zlib
-    from collections import OrderedDict
-    sd = OrderedDict()
-
-    def put(name, shape, kind):
-        rng = np.random.Generator(np.random.PCG64((seed * 1000003 + zlib.crc32(name.encode())) & 0xFFFFFFFF))
-        if kind == "w":
-            v = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
-        elif kind == "b":
-            v = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.02)
-        elif kind == "g":
-            v = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.1) + np.float32(1.0)
-        else:
-            v = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.5)
-        sd[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)))
-
-    C = n_embd
-    put("pos_emb", (1, block_size, C), "e")
-    put("tok_emb.weight", (vocab_size, C), "e")
-    for i in range(n_layer):
-        p = f"blocks.{i}"
-        put(f"{p}.ln1.weight", (C,), "g"); put(f"{p}.ln1.bias", (C,), "b")
-        put(f"{p}.ln2.weight", (C,), "g"); put(f"{p}.ln2.bias", (C,), "b")
-        for n in ("key", "query", "value", "proj"):
-            put(f"{p}.attn.{n}.weight", (C, C), "w"); put(f"{p}.attn.{n}.bias", (C,), "b")
-        put(f"{p}.mlp.0.weight", (4 * C, C), "w"); put(f"{p}.mlp.0.bias", (4 * C,), "b")
-        put(f"{p}.mlp.2.weight", (C, 4 * C), "w"); put(f"{p}.mlp.2.bias", (C,), "b")
-    put("ln_f.weight", (C,), "g"); put("ln_f.bias", (C,), "b")
-    put("head.weight", (vocab_size, C), "w")
-    return sd
+# seeded synthetic GPT weights live with the other generators in the product package (pure numpy; the
+# golden fixtures pin their crc); re-exported here for the tests
+from omnitokenizer_amd.synth import synth_gpt_state  # noqa: E402,F401

@@ -183,3 +183,12 @@ def test_lm_argument_errors_without_gpu(lib):
         assert lib.omnitok_lm_set_weight(h, b"blocks.0.attn.mask", ctypes.byref(x), shape, 2, None) == 1  # ignored
     finally:
         lib.omnitok_lm_destroy(h)
+
+
+def test_missing_library_fails_loudly(lib, monkeypatch):
+    """No CPU / PyTorch fallback: without libomnitok.so the product raises instead of computing."""
+    from omnitokenizer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libomnitok.so")
+    with pytest.raises(_lib.OmnitokError, match="no CPU fallback"):
+        _lib.load()

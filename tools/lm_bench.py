@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 from omnitokenizer_amd import gpt as og  # noqa: E402
-from oracle import gpt_oracle as go  # noqa: E402  (cpu_baseline leg only)
+from omnitokenizer_amd.synth import synth_gpt_state  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0
 
@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     V, BS, L, H, C = a.vocab, a.block, a.layers, a.heads, a.embd
-    sd = go.synth_gpt_state(V, BS, L, H, C, seed=0)
+    sd = synth_gpt_state(V, BS, L, H, C, seed=0)
     m = og.GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C)
     m.load_state_dict(sd, strict=True)
     m = m.cuda().eval()
@@ -97,6 +97,7 @@ def main():
     except Exception:
         pass
     if not a.no_cpu_baseline:
+        from oracle import gpt_oracle as go  # the CPU oracle is only the baseline / checker here
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         x = cond.cpu()[:1, -1:]
         with torch.no_grad():
