@@ -30,7 +30,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
 PEAK_HBM_GBS = 8000.0
@@ -44,25 +43,30 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (C3: 32)")
     ap.add_argument("--frames", type=int, default=17)
     ap.add_argument("--resolution", type=int, default=256)
+    ap.add_argument("--n-codes", type=int, default=0, help="codebook size (default: the stage-2 8192; C5: 16384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from omnitokenizer_amd import launch
+
+    # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves
+    rc = launch.maybe_respawn(os.path.abspath(__file__), sys.argv[1:], a.gpus)
+    if rc is not None:
+        sys.exit(rc)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL on ROCm (lazy communicator init on the device set above)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    info = launch.init_ranks(a.gpus, backend="nccl")   # RCCL on ROCm
+    world, rank, local_rank = info.world, info.rank, info.local_rank
 
     from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
-    from omnitokenizer_amd import dist as od
     from omnitokenizer_amd.config import OmniTokConfig
 
-    args = make_args(2, resolution=a.resolution)
+    over = dict(resolution=a.resolution)
+    if a.n_codes:
+        over["n_codes"] = a.n_codes
+    if a.frames > 17:
+        over["sequence_length"] = a.frames
+    args = make_args(2, **over)
     cfg = OmniTokConfig.from_args(args)
     sd = synth.synth_state_dict(cfg, seed=0)
     model = OmniTokenizer_VQGAN(args)
@@ -71,37 +75,15 @@ def main():
 
     B = a.batch
     is_image = a.frames == 1
-    # every rank generates its own shard (distinct seed): the batch is sharded by clip
-    base = (synth.synth_image(min(B, 4), a.resolution, seed=1234 + rank) if is_image
-            else synth.synth_video(min(B, 4), a.frames, a.resolution, seed=1234 + rank))
-    x = torch.cat([base] * (-(-B // base.shape[0])))[:B].cuda().contiguous()
+    # every rank generates its own shard (distinct seed per rank, B DISTINCT clips): the batch is
+    # sharded by clip
+    x = (synth.synth_image(B, a.resolution, seed=1234 + rank) if is_image
+         else synth.synth_video(B, a.frames, a.resolution, seed=1234 + rank)).cuda().contiguous()
     n_total = B * world
 
-    def step():
-        ids_local = model.encode(x, is_image)
-        if world > 1:
-            ids_all = od.all_gather_ids(ids_local, n_total)     # the one collective of the path
-            lo, hi = od.shard_range(n_total, rank, world)
-            ids_local = ids_all[lo:hi].contiguous()
-        return ids_local, model.decode(ids_local, is_image)
-
-    def sync():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        ids, rec = step()
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    res = launch.timed_sharded_steps(info, lambda xs: model.encode(xs, is_image),
+                                     lambda i: model.decode(i, is_image), x, a.steps, a.warmup)
+    dt, ids = res.seconds, res.ids_local
     tokens_per_clip = ids.numel() // B
     value = n_total * tokens_per_clip * a.steps / dt
 
@@ -169,18 +151,26 @@ def main():
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3)
                                                            / 1e9, 2)
 
+        if is_image:
+            wl_name = "C2" if (B, a.resolution) == (64, 256) else "images"
+        elif (a.frames, a.resolution) == (17, 256):
+            wl_name = "C3" if world == 1 else f"C4-shape ({n_total} clips over {world} GPUs)"
+        elif (a.frames, a.resolution, cfg.n_codes) == (65, 512, 16384):
+            wl_name = "C5"
+        else:
+            wl_name = "clips"
         out = {
             "metric": "patches/sec encode+decode", "value": round(value, 1), "unit": "patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"C2: B={B}/GPU {a.resolution}x{a.resolution} images, stage-2 " if is_image else
-                                    f"C3: B={B}/GPU {a.frames}x{a.resolution}x{a.resolution} clips, stage-2 ")
-                                   +
-                                   "(imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes=8192), encode + "
-                                   f"{'RCCL id all-gather + ' if world > 1 else ''}decode",
+            "config": {"workload": wl_name + f": B={B}/GPU " + (f"{a.resolution}x{a.resolution} images" if is_image
+                                    else f"{a.frames}x{a.resolution}x{a.resolution} clips")
+                                   + f", stage-2 (imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes={cfg.n_codes}), encode + "
+                                   f"{'RCCL id all-gather + ' if world > 1 else ''}decode; {B} distinct clips per rank",
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
                        "parallelism": f"clip-sharded x{world}"},
+            "rccl_world_size": res.world_seen, "ids_crc32": res.ids_crc, "allgather_ms": res.allgather_ms,
             "roofline": roofline, "kernels": kernels,
             "workspace_gb": round(model.workspace_bytes() / 2**30, 2),
         }
@@ -233,9 +223,7 @@ def main():
                              "psnr_vs_ref_db": round(orc.psnr(g_rec, rec_ref), 2),
                              "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2)}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    launch.finish(info)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,182 @@
+"""One-process-per-GPU launch protocol of the clip-sharded path (bench.py --gpus N, and any caller
+that wants the same contract).
+
+The reference's launch contract is environment based (ddp_utils.py:333-364: RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_ADDR / MASTER_PORT set by the launcher, `init_process_group('nccl')`).  This
+module keeps that contract and adds the piece a plain `python bench.py --gpus N` needs: when the
+process was NOT started by a launcher (WORLD_SIZE unset) and N > 1 it re-executes itself through
+`torch.distributed.run` on 127.0.0.1 with one rank per GPU.
+
+The timed protocol (`timed_sharded_steps`) is the one the driver's contract asks for: W untimed
+warm-up steps, barrier + device synchronise, exactly K steps, barrier + synchronise, MAX over ranks.
+A step = encode(local shard) -> all-gather of the ids (the path's only collective; RCCL on the
+GPU, gloo in the CPU tests) -> decode(local shard of the gathered ids).  After the timed region every
+rank computes the CRC-32 of the gathered id tensor and the ranks compare them, so a collective
+that silently returned garbage (or a world that is smaller than asked) fails the run.
+"""
+from __future__ import annotations
+
+import os
+import socket
+import subprocess
+import sys
+import time
+import zlib
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import dist as od
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launched_by_torchrun() -> bool:
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def respawn_command(script: str, argv: List[str], nproc: int, port: Optional[int] = None) -> List[str]:
+    """The command `python script argv...` turns into when it has to start its own ranks."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), script, *argv]
+
+
+def maybe_respawn(script: str, argv: List[str], nproc: int) -> Optional[int]:
+    """If `nproc` > 1 and no launcher started this process: run the ranks, return their exit code.
+    Returns None when the caller should simply continue (single rank, or already a rank)."""
+    if nproc <= 1 or launched_by_torchrun():
+        return None
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    r = subprocess.run(respawn_command(script, argv, nproc), env=env)
+    return r.returncode
+
+
+@dataclass
+class RankInfo:
+    rank: int = 0
+    world: int = 1
+    local_rank: int = 0
+    backend: str = "none"
+
+
+def init_ranks(expected_world: int, backend: str = "nccl", set_cuda_device: bool = True) -> RankInfo:
+    """Reads the launcher's environment, binds this rank to its GPU and creates the process group.
+    Raises if the world the launcher created is not the one the command line asked for."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != expected_world:
+        raise RuntimeError(f"asked for {expected_world} ranks but the launcher created WORLD_SIZE={world}")
+    if set_cuda_device:
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)   # "nccl" is RCCL on ROCm
+        if dist.get_world_size() != world:
+            raise RuntimeError(f"process group has {dist.get_world_size()} ranks, expected {world}")
+    return RankInfo(rank, world, local_rank, backend if world > 1 else "none")
+
+
+@dataclass
+class ShardedResult:
+    seconds: float                  # max over ranks of the timed region
+    steps: int
+    ids_local: torch.Tensor = None
+    rec_local: torch.Tensor = None
+    n_total: int = 0
+    ids_crc: int = 0                # CRC-32 of the gathered ids (equal on every rank, checked)
+    allgather_ms: Optional[float] = None
+    world_seen: int = 1
+    extra: dict = field(default_factory=dict)
+
+
+def _barrier(info: RankInfo, on_gpu: bool):
+    if info.world > 1:
+        if on_gpu:
+            dist.barrier(device_ids=[info.local_rank])
+        else:
+            dist.barrier()
+    if on_gpu:
+        torch.cuda.synchronize()
+
+
+def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.Tensor],
+                        decode: Callable[[torch.Tensor], torch.Tensor], x_local: torch.Tensor,
+                        steps: int, warmup: int) -> ShardedResult:
+    """Weak-scaling protocol: every rank owns `x_local` (its clips), n_total = world * local."""
+    on_gpu = x_local.is_cuda
+    b_local = x_local.shape[0]
+    n_total = b_local * info.world
+    lo, hi = od.shard_range(n_total, info.rank, info.world)
+    state = {}
+
+    def step():
+        ids_local = encode(x_local)
+        if info.world > 1:
+            ids_all = od.all_gather_ids(ids_local, n_total)     # the one collective of the path
+            state["ids_all"] = ids_all
+            ids_dec = ids_all[lo:hi].contiguous()
+        else:
+            state["ids_all"] = ids_local
+            ids_dec = ids_local
+        return ids_local, decode(ids_dec)
+
+    for _ in range(warmup):
+        step()
+    _barrier(info, on_gpu)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids, rec = step()
+    _barrier(info, on_gpu)
+    dt = time.perf_counter() - t0
+    res = ShardedResult(seconds=dt, steps=steps, ids_local=ids, rec_local=rec, n_total=n_total,
+                        world_seen=info.world)
+    ids_all = state["ids_all"]
+    res.ids_crc = zlib.crc32(ids_all.cpu().numpy().tobytes())
+    if info.world > 1:
+        dev = x_local.device
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res.seconds = float(tt.item())
+        # (1) the gathered tensor holds this rank's own ids in its shard
+        if not torch.equal(ids_all[lo:hi], ids):
+            raise RuntimeError(f"rank {info.rank}: gathered ids differ from the locally encoded ids")
+        # (2) every rank holds the same gathered tensor; (3) the group really has `world` members
+        crcs = torch.zeros(info.world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([res.ids_crc], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(crcs, mine)
+        crcs = crcs.cpu().tolist()
+        if len(set(crcs)) != 1:
+            raise RuntimeError(f"gathered-id CRCs differ across ranks: {crcs}")
+        ones = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(ones)
+        res.world_seen = int(ones.item())
+        if res.world_seen != info.world:
+            raise RuntimeError(f"collective saw {res.world_seen} ranks, expected {info.world}")
+        # cost of the collective alone (untimed region), averaged
+        reps = 5
+        _barrier(info, on_gpu)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            od.all_gather_ids(ids, n_total)
+        _barrier(info, on_gpu)
+        ag = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(ag, op=dist.ReduceOp.MAX)
+        res.allgather_ms = float(ag.item())
+    return res
+
+
+def finish(info: RankInfo, on_gpu: bool = True):
+    if info.world > 1:
+        _barrier(info, on_gpu)
+        dist.destroy_process_group()

@@ -73,3 +73,37 @@ def test_shard_range_partitions():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_self_spawning_launcher_gloo():
+    """`python <script> --gpus 2` with no launcher around it starts its own two ranks (the command form
+    the driver uses for bench.py), runs the timed sharded-step protocol and cross-checks the gathered ids."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_driver.py"), "--gpus", "2"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["n_total"] == 4
+    assert out["allgather_ms"] is not None and out["ids_local_shape"][0] == 2
+    # single-rank run of the same driver: no respawn, no collective
+    r1 = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_driver.py"), "--gpus", "1"],
+                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    out1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    assert out1["n_gpus"] == 1 and out1["allgather_ms"] is None
+
+
+def test_launcher_rejects_wrong_world(monkeypatch):
+    from omnitokenizer_amd import launch
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError, match="asked for 2 ranks"):
+        launch.init_ranks(2, backend="gloo", set_cuda_device=False)
+    cmd = launch.respawn_command("bench.py", ["--gpus", "4"], 4, port=29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-3:] == ["bench.py", "--gpus", "4"]
