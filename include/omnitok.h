@@ -102,6 +102,27 @@ int omnitok_gemm_bf16x3(const void *a_planes, const void *w_planes, const float 
                         const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N,
                         int K, int flags, omnitok_stream_t stream);
 
+/* --- fp32 GEMM on the bf16 matrix cores, operands split in-kernel (csrc/gemm_x3.hip) ----------------
+ * Same contract as omnitok_gemm (c = a . w^T + epilogue, fp32 operands in HBM, fp32 result) but each
+ * fp32 operand element is split exactly into three bf16 numbers while it is staged to LDS and six
+ * v_mfma_f32_32x32x16_bf16 products per element pair are accumulated in fp32 (the three dropped
+ * products are < 2^-24 |a b|).  K % 32 == 0, N % 32 == 0.  The per-element arithmetic does not depend
+ * on M, N or the tile shape, so results are independent of the batch size.
+ * Optional fused LayerNorm of the A operand (reference attention.py:73-80,163: the norm that precedes
+ * to_q / qkv / the FeedForward's first Linear): ln_stats[rows][2] = (mean, rstd) per PHYSICAL a row
+ * (omnitok_row_stats), ln_gamma[K], ln_beta[K] (NULL = 0), K <= 512; output columns [0, ln_cols) are
+ * computed from LN(a), columns [ln_cols, N) from a itself (Q from LN(x), K/V from x in one launch,
+ * attention.py:404-412).  ln_stats == NULL: no LayerNorm. */
+int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                    const float *residual, int64_t ldr, float *c, int64_t ldc,
+                    int64_t M, int N, int K, int flags,
+                    int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
+                    const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
+                    omnitok_stream_t stream);
+/* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm). */
+int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats,
+                      omnitok_stream_t stream);
+
 /* Packs FeedForward's first Linear weight w1[2*inner, K] (value rows [0,inner), gate rows
  * [inner, 2*inner), reference attention.py:153-156,164) into out[2*inner_pad, K]: 32-row blocks
  * alternate value / gate, zero rows beyond inner.  inner_pad % 64 == 0. */

@@ -43,6 +43,7 @@ struct LayerT {  // 't' block (+ FF)
     const float *peg_w27, *peg_b;
     const float *ng, *nb;
     const float *wq, *wkv, *wo;
+    const float *wqkv;  // [3D, D] = to_q | to_kv rows (one launch: Q from LN(x), K/V from x)
     const float *q_scale, *k_scale;
     std::string bias_prefix;  // spatial_rel_pos_bias prefix ("" if none)
 };
@@ -98,7 +99,7 @@ struct omnitok_engine {
     std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
     std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
     // workspace
-    Buf X, X2, Y, QKV, AO, HD, Z;
+    Buf X, X2, Y, QKV, AO, HD, Z, ST;
     int *err_flag = nullptr;
     // timing
     bool timing = false;
@@ -286,6 +287,14 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
             L.t.wq = W(e, p + ".1.to_q.weight");
             L.t.wkv = W(e, p + ".1.to_kv.weight");
             L.t.wo = W(e, p + ".1.to_out.weight");
+            {
+                float *m;
+                if (int rc = alloc_f(e, &m, 3 * (int64_t)c.dim * c.dim)) return rc;
+                OT_HIP(hipMemcpyAsync(m, L.t.wq, (size_t)c.dim * c.dim * 4, hipMemcpyDeviceToDevice, stream));
+                OT_HIP(hipMemcpyAsync(m + (int64_t)c.dim * c.dim, L.t.wkv, (size_t)2 * c.dim * c.dim * 4,
+                                      hipMemcpyDeviceToDevice, stream));
+                L.t.wqkv = m;
+            }
             L.t.q_scale = W(e, p + ".1.q_scale");
             L.t.k_scale = W(e, p + ".1.k_scale");
             L.t.bias_prefix = (spatial && c.legacy_attention && !c.spatial_rope) ? p + ".1.spatial_rel_pos_bias" : "";
@@ -489,6 +498,31 @@ static int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, 
     return OMNITOK_OK;
 }
 
+// GEMM dispatch of the engine.  "gemm_mode" 1 (default): fp32 operands split in-kernel into three bf16
+// planes, six bf16-MFMA products (gemm_x3.hip; fp32-class error, 1.6x the fp32-MFMA rate); 0: the
+// fp32-input MFMA kernels of gemm.hip (bitwise an fmaf chain).  The mode is process-wide so that every
+// GEMM of a run -- whatever its size -- uses the same arithmetic (batch-size independence).
+int g_gemm_mode = 1;
+
+static bool x3_ok(int N, int K, int flags) {
+    return g_gemm_mode == 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
+           (!(flags & OMNITOK_GEMM_GEGLU) || N % 64 == 0);
+}
+
+static int eg_gemm(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, const float *residual,
+                   int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags, int64_t rpg, int64_t gstride,
+                   int64_t goff, hipStream_t stream, const float *ln_stats = nullptr, const float *ln_g = nullptr,
+                   const float *ln_b = nullptr, int ln_cols = 0) {
+    if (x3_ok(N, K, flags))
+        return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
+                               ln_stats, ln_g, ln_b, ln_cols, stream);
+    if (ln_stats) {
+        set_error("eg_gemm: fused LayerNorm needs the x3 kernel");
+        return OMNITOK_ERR_STATE;
+    }
+    return omnitok_gemm(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff, stream);
+}
+
 // One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
 // Pooling blocks shrink the token grid (attention.py:683-684): *ghp / *gwp are updated.
 static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
@@ -509,7 +543,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             }
             if (ly.kind == 'l')  // Linear(4D -> D) on four consecutive tokens: x.view(B, N/4, 4C)
                 OT_RUN("pool", 2.0 * (double)L * D * D,
-                       omnitok_gemm(e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
+                       eg_gemm(e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
                                     OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
             else
                 OT_RUN("pool", 1.25 * L * D * 4.0,
@@ -533,65 +567,100 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
                 // half and the attention kernel drop out.  Identical results to the general path.
                 OT_RUN("gemm_qkv", gemm_f * D,
-                       omnitok_gemm(e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D,
+                       eg_gemm(e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D,
                                     0, 0, 0, 0, stream));
                 OT_RUN("gemm_out", gemm_f * D,
-                       omnitok_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D,
+                       eg_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D,
                                     OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
                 goto feed_forward;
             }
-            OT_RUN("layernorm", 2.0 * L * D * 4.0,
-                   omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
             float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
+            int64_t ldq = D, ldkv = 2 * D;
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
-            OT_RUN("gemm_qkv", gemm_f * D,
-                   omnitok_gemm(e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
-            OT_RUN("gemm_qkv", gemm_f * 2 * D,
-                   omnitok_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
-                                stream));
+            if (x3_ok(3 * D, D, 0) && D <= 512 && D % 256 == 0) {
+                // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
+                // for the Q columns only; QKV rows are [q | k | v]
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream, e->ST.p, ly.t.ng, ly.t.nb, D));
+                KV = e->QKV.p + D;
+                ldq = 3 * D;
+                ldkv = 3 * D;
+            } else if (x3_ok(D, D, 0) && D <= 512) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       eg_gemm(e->X.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream, e->ST.p,
+                               ly.t.ng, ly.t.nb, D));
+                OT_RUN("gemm_qkv", gemm_f * 2 * D,
+                       eg_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
+                               stream));
+            } else {
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       eg_gemm(e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * 2 * D,
+                       eg_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
+                               stream));
+            }
             if (spatial) {
                 const float *cosp = nullptr, *sinp = nullptr;
                 if (c.spatial_rope)
                     if (int rc = get_rope(e, S, &cosp, &sinp, stream)) return rc;
                 OT_RUN("qk_prep", 4.0 * L * D * 4.0,
-                       omnitok_qk_prep(Q, D, KV, 2 * D, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
+                       omnitok_qk_prep(Q, ldq, KV, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
                                        stream));
                 const float *bias = nullptr;
                 if (!ly.t.bias_prefix.empty())
                     if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
                 OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
-                       omnitok_attn_spatial(Q, D, KV, KV + D, 2 * D, e->AO.p, D, B * T, S, heads, bias, gh, gw,
+                       omnitok_attn_spatial(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, B * T, S, heads, bias, gh, gw,
                                             stream));
             } else {
                 const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
                 OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
-                       omnitok_attn_temporal(Q, D, KV, KV + D, 2 * D, e->AO.p, D, (int64_t)B * S, T, heads,
+                       omnitok_attn_temporal(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, (int64_t)B * S, T, heads,
                                              ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi, stream));
             }
             OT_RUN("gemm_out", gemm_f * D,
-                   omnitok_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
+                   eg_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
                                 0, 0, 0, stream));
         } else {
-            OT_RUN("layernorm", 2.0 * L * D * 4.0,
-                   omnitok_layernorm(e->X.p, ly.w.ng, ly.w.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
-            OT_RUN("gemm_qkv", gemm_f * 3 * D,
-                   omnitok_gemm(e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
-                                stream));
+            if (x3_ok(3 * D, D, 0) && D <= 512) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e->X.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream, e->ST.p, ly.w.ng, ly.w.nb, 3 * D));
+            } else {
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.w.ng, ly.w.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream));
+            }
             OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
                    omnitok_attn_window(e->QKV.p, 3 * D, ly.w.bias_dense, e->AO.p, D, B * T, gh, gw, heads, stream));
             OT_RUN("gemm_out", gemm_f * D,
-                   omnitok_gemm(e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
+                   eg_gemm(e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
                                 OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
         }
     feed_forward:
         // FeedForward (reference attention.py:153-168)
-        OT_RUN("layernorm", 2.0 * L * D * 4.0,
-               omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
-        OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
-               omnitok_gemm(e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
-                            D, OMNITOK_GEMM_GEGLU, 0, 0, 0, stream));
+        if (x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU) && D <= 512) {
+            OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
+                   eg_gemm(e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
+                           OMNITOK_GEMM_GEGLU, 0, 0, 0, stream, e->ST.p, ly.ff.lw, ly.ff.lb, 2 * e->inner_pad));
+        } else {
+            OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                   omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
+                   eg_gemm(e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
+                           D, OMNITOK_GEMM_GEGLU, 0, 0, 0, stream));
+        }
         OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
-               omnitok_gemm(e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+               eg_gemm(e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
                             e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
     }
     OT_RUN("layernorm", 2.0 * L * D * 4.0,
@@ -618,6 +687,7 @@ static int ensure_workspace(omnitok_engine *e, int64_t L) {
     if (int rc = ensure(e->AO, L * D)) return rc;
     if (int rc = ensure(e->HD, L * hdw)) return rc;
     if (int rc = ensure(e->Z, L * 8)) return rc;
+    if (int rc = ensure(e->ST, L * 2)) return rc;
     return OMNITOK_OK;
 }
 
@@ -755,7 +825,7 @@ extern "C" void omnitok_engine_destroy(omnitok_engine *e) {
     for (auto &kv : e->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (void *p : e->owned) (void)hipFree(p);
-    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z})
+    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST})
         if (b->p) (void)hipFree(b->p);
     if (e->err_flag) (void)hipFree(e->err_flag);
     for (auto &r : e->recs) {
@@ -949,7 +1019,7 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
             OT_RUN("patchify_ln", ((double)M * K) * 8.0,
                    omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, nullptr, nullptr, 0.0f, e->HD.p, ld, stream));
             OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
-                   omnitok_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
+                   eg_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
                                 OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
             // scatter the frame group into the token tensor (a strided row copy)
             for (int b = 0; b < B; ++b)
@@ -961,7 +1031,7 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
                omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, W(e, n + ".1.weight"), W(e, n + ".1.bias"), 1e-5f,
                                    e->HD.p, ld, stream));
         OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
-               omnitok_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
+               eg_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
                             OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
         OT_RUN("layernorm", 2.0 * M * D * 4.0,
                omnitok_layernorm(e->AO.p, W(e, n + ".3.weight"), W(e, n + ".3.bias"), e->X.p, M, D, 1e-5f, rpg, gstride,
@@ -1103,14 +1173,14 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream)) return rc;
     // ---- to_pixels (reference omnitokenizer.py:1006-1033, 1089-1096) -------------------------
     OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,
-           omnitok_gemm(e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
+           eg_gemm(e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
                         OMNITOK_GEMM_BIAS, S, (int64_t)T2 * S, 0, stream));
     OT_RUN("unpatchify", (double)B * S * K0 * 8.0,
            omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 0, 1, 1, p, pixels_out, stream));
     if (T2 > 1) {
         const int64_t M1 = (int64_t)B * (T2 - 1) * S;
         OT_RUN("gemm_pixels", 2.0 * M1 * (double)K1 * D,
-               omnitok_gemm(e->X.p, D, e->px_w[1], D, e->px_b[1], nullptr, 0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS,
+               eg_gemm(e->X.p, D, e->px_w[1], D, e->px_b[1], nullptr, 0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS,
                             (int64_t)(T2 - 1) * S, (int64_t)T2 * S, S, stream));
         OT_RUN("unpatchify", (double)M1 * K1 * 8.0,
                omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T2 - 1, pt, p, pixels_out, stream));
@@ -1176,7 +1246,7 @@ extern "C" int omnitok_decode_vae(omnitok_engine *e, const float *z, int channel
 
 extern "C" int64_t omnitok_engine_workspace_bytes(omnitok_engine *e) {
     int64_t n = 0;
-    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z}) n += b->cap * 4;
+    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST}) n += b->cap * 4;
     return n;
 }
 

@@ -62,6 +62,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         }
 }
 
+// statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
+// A operand (gemm_x3.hip), so LN(x) is never written to HBM
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim, float eps,
+                                                        float *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = (dim / 4 + 63) / 64;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = __builtin_nontemporal_load(xr + lane + 64 * i);
+    float mean, rstd;
+    row_stats(v, nv, lane, dim, eps, mean, rstd);
+    if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
+}
+
 // one wave per patch: gathers the (c, pt, p1, p2) features (p2 contiguous in memory) and
 // layer-normalises them.  feature f = ((c*pt + j)*p + p1)*p + p2.
 __global__ __launch_bounds__(256) void patchify_ln_kernel(const float *__restrict__ video, int B, int C, int F, int H,
@@ -175,6 +193,19 @@ extern "C" int omnitok_layernorm(const float *x, const float *gamma, const float
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y,
                        rows, dim, eps, rows_per_group, group_stride, group_offset);
     OT_LAUNCH_CHECK("layernorm");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats,
+                                 omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && stats, "row_stats: null pointer");
+    OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4, "row_stats: dim=%d unsupported", dim);
+    OT_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "row_stats: alignment");
+    if (rows == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, dim, eps,
+                       stats);
+    OT_LAUNCH_CHECK("row_stats");
     return OMNITOK_OK;
 }
 

@@ -94,6 +94,47 @@ def linear_bf16x3(x, weight, bias=None, residual=None, geglu=False, w_planes=Non
     return out
 
 
+def row_stats(x, eps=1e-5):
+    """[rows, 2] = (mean, rstd) per row of x[..., dim] (the statistics a fused-LN GEMM consumes)."""
+    x = _req(x, "x")
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    st = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_row_stats(_p(x), rows, dim, eps, _p(st), _stream()), "row_stats")
+    return st
+
+
+def linear_x3(x, weight, bias=None, residual=None, geglu=False, ln=None, ln_cols=None):
+    """y = x @ weight.T (+epilogue) with fp32 operands split in-kernel into 3 bf16 planes each (six bf16
+    MFMA products, fp32 accumulate; csrc/gemm_x3.hip).  geglu: weight packed by pack_geglu_weight.
+    ln = (stats, gamma, beta|None): LayerNorm fused into the A operand for output columns [0, ln_cols)."""
+    x = _req(x, "x")
+    weight = _req(weight, "weight")
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = weight.shape[0]
+    ncol = N // 2 if geglu else N
+    out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
+    if bias is not None:
+        _req(bias, "bias")
+    if residual is not None:
+        _req(residual, "residual")
+        if residual.numel() != M * ncol:
+            raise ValueError("residual must have the shape of the output")
+    flags = GEMM_GEGLU if geglu else ((GEMM_BIAS if bias is not None else 0) |
+                                      (GEMM_RESIDUAL if residual is not None else 0))
+    st = g = b = None
+    if ln is not None:
+        st, g, b = ln
+        _req(st, "ln stats")
+        _req(g, "ln gamma")
+        if b is not None:
+            _req(b, "ln beta")
+    check(_lib.load().omnitok_gemm_x3(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), ncol, _p(out),
+                                      ncol, M, N, K, flags, 0, 0, 0, _p(st), _p(g), _p(b),
+                                      int(ln_cols if ln_cols is not None else N), _stream()), "gemm_x3")
+    return out
+
+
 def pack_geglu_weight(w1, inner_pad):
     w1 = _req(w1, "w1")
     inner, K = w1.shape[0] // 2, w1.shape[1]
