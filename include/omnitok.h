@@ -119,9 +119,36 @@ int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int64_t ldw, co
                     int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
                     const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
                     omnitok_stream_t stream);
-/* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm). */
-int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats,
-                      omnitok_stream_t stream);
+/* --- fp32 GEMM on the fp16 matrix cores, 2-way split operands (csrc/gemm_h2.hip) ---------------------
+ * c = a . w^T (+epilogue as omnitok_gemm) with each operand element a' = hi + lo (two fp16 numbers, 22
+ * significand bits) and three v_mfma_f32_32x32x16_f16 products per element pair, fp32 accumulation.
+ * The weight is packed once by omnitok_h2_pack_weight (row-scaled by a power of two, split, interleaved:
+ * planes[N][K/8][2][8] fp16 = 4 bytes per element, scale[N]).  fp16 has 5 exponent bits, so the caller
+ * states an UPPER BOUND of |a|: a_bound (> 0), multiplied by a_bound_dev[a_bound_stride * (m /
+ * a_rows_per_clip)] for row m when that device pointer is given (bounds produced by an earlier kernel, e.g.
+ * omnitok_row_stats; a_rows_per_clip <= 0: one value for all rows); the kernel scales the rows of a clip by
+ * one power of two so that |a'| <= 2^15 (tiles never straddle clips: a_rows_per_clip % 64 == 0).  A wrong (too small) bound overflows to inf; elements more than
+ * 2^18 below the bound lose relative precision (absolute error <= 2^-40 of the bound).
+ * Fused LayerNorm as omnitok_gemm_x3, with ln_bound >= max |LN(a)| (sqrt(K) max|gamma| + max|beta|).
+ * K % 32 == 0, N % 32 == 0.  Results are independent of M and of the tile shape. */
+int omnitok_h2_pack_weight(const float *w, int64_t ldw, int N, int K, void *planes, float *scale,
+                           omnitok_stream_t stream);
+int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes, const float *w_scale,
+                    const float *bias, const float *residual, int64_t ldr, float *c, int64_t ldc,
+                    int64_t M, int N, int K, int flags,
+                    int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
+                    float a_bound, const float *a_bound_dev, int a_bound_stride, int64_t a_rows_per_clip,
+                    const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
+                    float ln_bound, omnitok_stream_t stream);
+/* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
+ * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
+ * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of
+ * max|x| (|mean| + sqrt(dim)/rstd) and of the row norm ||x||_2: the range information omnitok_gemm_h2
+ * needs for operands derived from x, kept per clip so that results never depend on the rest of the batch. */
+int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats, float *bounds,
+                      int64_t rows_per_clip, omnitok_stream_t stream);
+/* out2[0] = max_rows ||w_row||_2, out2[1] = max|w| (atomic max into floats zeroed by the caller). */
+int omnitok_weight_range(const float *w, int64_t ldw, int rows, int K, float *out2, omnitok_stream_t stream);
 
 /* Packs FeedForward's first Linear weight w1[2*inner, K] (value rows [0,inner), gate rows
  * [inner, 2*inner), reference attention.py:153-156,164) into out[2*inner_pad, K]: 32-row blocks

@@ -45,13 +45,26 @@ struct LayerT {  // 't' block (+ FF)
     const float *wq, *wkv, *wo;
     const float *wqkv;  // [3D, D] = to_q | to_kv rows (one launch: Q from LN(x), K/V from x)
     const float *q_scale, *k_scale;
+    float ln_bound = 0.0f;  // >= max |LN(x)|            (ranges for the fp16-split GEMM, gemm_h2.hip)
+    float vnorm = 0.0f;     // max_j ||Wv_j||_2: |attention output| <= max_rows ||x||_2 * vnorm
     std::string bias_prefix;  // spatial_rel_pos_bias prefix ("" if none)
 };
 struct LayerW {  // 'w' block
     const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;
+    float ln_bound = 0.0f, ao_bound = 0.0f;  // >= max |LN(x)|, >= max |window attention output|
 };
 struct LayerFF {
     const float *lw, *lb, *w1p, *w2p;
+    float ln_bound = 0.0f, h_bound = 0.0f;   // >= max |LN(x)|, >= max |GEGLU hidden|
+};
+struct H2W {  // a weight packed for gemm_h2 (fp16 hi|lo planes + row scales)
+    const void *pl = nullptr;
+    const float *sc = nullptr;
+};
+struct ABound {  // upper bound of |A| of a row of clip c = stat * (dev ? dev[2 c] : 1); stat <= 0: unknown
+    float stat = 0.0f;
+    const float *dev = nullptr;  // per-clip range slots written by omnitok_row_stats
+    int64_t rpc = 0;             // rows per clip
 };
 struct Layer {
     char kind;  // 't', 'w', or a pooling block 'a' / 'm' / 'l'
@@ -69,6 +82,7 @@ struct Geo {
 struct TransformerW {
     std::vector<Layer> layers;
     const float *og, *ob;
+    float out_bound = 0.0f;  // >= max |LN_out(x)|
 };
 
 struct TimingRec {
@@ -100,6 +114,12 @@ struct omnitok_engine {
     std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
     // workspace
     Buf X, X2, Y, QKV, AO, HD, Z, ST;
+    // fp16-split GEMM (gemm_mode 2): packed weights by fp32 weight pointer, device-side range slots
+    std::map<const float *, H2W> h2w;
+    float pe_bound[2] = {0.0f, 0.0f};
+    float *bounds = nullptr;  // [launch][clip][2] range slots, zeroed at the start of every encode / decode
+    int bound_next = 0, bound_clips = 0, bound_cap = 0;
+    float *range_scratch = nullptr;
     int *err_flag = nullptr;
     // timing
     bool timing = false;
@@ -268,6 +288,49 @@ __global__ void pad_cols_kernel(const float *__restrict__ src, int rows, int col
     dst[idx] = c < cols ? src[(int64_t)r * cols + c] : 0.0f;
 }
 
+constexpr int N_BOUND_LAUNCHES = 64;  // row-statistics launches with ranges per encode / decode
+
+// (max_rows ||w_row||_2, max |w|) of a device matrix; synchronous (finalize only)
+static int weight_range(omnitok_engine *e, const float *w, int64_t ld, int rows, int K, float *norm, float *amax,
+                        hipStream_t stream) {
+    if (!e->range_scratch) OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->range_scratch), 2 * sizeof(float)));
+    OT_HIP(hipMemsetAsync(e->range_scratch, 0, 2 * sizeof(float), stream));
+    if (int rc = omnitok_weight_range(w, ld, rows, K, e->range_scratch, stream)) return rc;
+    float h[2];
+    OT_HIP(hipMemcpyAsync(h, e->range_scratch, sizeof(h), hipMemcpyDeviceToHost, stream));
+    OT_HIP(hipStreamSynchronize(stream));
+    if (norm) *norm = h[0];
+    if (amax) *amax = h[1];
+    return OMNITOK_OK;
+}
+
+// >= max |LayerNorm(x)_k| = |xhat_k gamma_k + beta_k| with |xhat_k| <= sqrt(dim); *l2 (optional) >= ||LN(x)||_2
+static int ln_range(omnitok_engine *e, const float *gamma, const float *beta, int dim, float *amax, float *l2,
+                    hipStream_t stream) {
+    float gn = 0, gm = 0, bn = 0, bm = 0;
+    if (int rc = weight_range(e, gamma, dim, 1, dim, &gn, &gm, stream)) return rc;
+    if (beta)
+        if (int rc = weight_range(e, beta, dim, 1, dim, &bn, &bm, stream)) return rc;
+    const float sq = sqrtf((float)dim);
+    if (amax) *amax = 1.01f * (sq * gm + bm);
+    if (l2) *l2 = 1.01f * (sq * gm + bn);  // ||xhat o gamma|| <= max|gamma| ||xhat|| = max|gamma| sqrt(dim)
+    return OMNITOK_OK;
+}
+
+// pack a GEMM weight for gemm_h2 and register it under its fp32 pointer
+static int pack_h2(omnitok_engine *e, const float *w, int64_t ld, int N, int K, hipStream_t stream) {
+    if (!w || N % 32 || K % 32 || ld != K) return OMNITOK_OK;  // shapes the h2 kernel does not take: x3 / fp32 path
+    float *pl, *sc;
+    if (int rc = alloc_f(e, &pl, (int64_t)N * K)) return rc;  // 2 planes x 2 B = 4 B per element
+    if (int rc = alloc_f(e, &sc, N)) return rc;
+    if (int rc = omnitok_h2_pack_weight(w, ld, N, K, pl, sc, stream)) return rc;
+    H2W h;
+    h.pl = pl;
+    h.sc = sc;
+    e->h2w[w] = h;
+    return OMNITOK_OK;
+}
+
 static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &prefix, const std::string &block,
                              bool spatial, hipStream_t stream) {
     const omnitok_config &c = e->cfg;
@@ -294,7 +357,19 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
                 OT_HIP(hipMemcpyAsync(m + (int64_t)c.dim * c.dim, L.t.wkv, (size_t)2 * c.dim * c.dim * 4,
                                       hipMemcpyDeviceToDevice, stream));
                 L.t.wqkv = m;
+                if (int rc = pack_h2(e, m, c.dim, 3 * c.dim, c.dim, stream)) return rc;
+                auto it = e->h2w.find(m);
+                if (it != e->h2w.end()) {  // the V rows alone (images: temporal attention over one token)
+                    H2W v;
+                    v.pl = static_cast<const char *>(it->second.pl) + (int64_t)2 * c.dim * c.dim * 4;
+                    v.sc = it->second.sc + 2 * c.dim;
+                    e->h2w[L.t.wkv + (int64_t)c.dim * c.dim] = v;
+                }
             }
+            if (int rc = pack_h2(e, L.t.wo, c.dim, c.dim, c.dim, stream)) return rc;
+            if (int rc = ln_range(e, L.t.ng, L.t.nb, c.dim, &L.t.ln_bound, nullptr, stream)) return rc;
+            if (int rc = weight_range(e, L.t.wkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &L.t.vnorm, nullptr, stream))
+                return rc;
             L.t.q_scale = W(e, p + ".1.q_scale");
             L.t.k_scale = W(e, p + ".1.k_scale");
             L.t.bias_prefix = (spatial && c.legacy_attention && !c.spatial_rope) ? p + ".1.spatial_rel_pos_bias" : "";
@@ -318,6 +393,16 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
             L.w.wproj = W(e, p + ".1.proj.weight");
             L.w.bproj = W(e, p + ".1.proj.bias");
             L.w.bias_dense = dense;
+            if (int rc = pack_h2(e, L.w.wqkv, c.dim, 3 * c.dim, c.dim, stream)) return rc;
+            if (int rc = pack_h2(e, L.w.wproj, c.dim, c.dim, c.dim, stream)) return rc;
+            {
+                float l2 = 0, vn = 0;
+                if (int rc = ln_range(e, L.w.ng, L.w.nb, c.dim, &L.w.ln_bound, &l2, stream)) return rc;
+                if (int rc = weight_range(e, L.w.wqkv + (int64_t)2 * c.dim * c.dim, c.dim, c.dim, c.dim, &vn, nullptr,
+                                          stream))
+                    return rc;
+                L.w.ao_bound = 1.01f * l2 * vn;  // |softmax-weighted V| <= max |V_j| <= ||LN(x)|| ||Wv_j||
+            }
         }
         float *w1p, *w2p;
         if (int rc = alloc_f(e, &w1p, 2 * (int64_t)e->inner_pad * c.dim)) return rc;
@@ -334,10 +419,20 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
         L.ff.lb = W(e, p + ".3.0.bias");
         L.ff.w1p = w1p;
         L.ff.w2p = w2p;
+        if (int rc = pack_h2(e, w1p, c.dim, 2 * e->inner_pad, c.dim, stream)) return rc;
+        if (int rc = pack_h2(e, w2p, e->inner_pad, c.dim, e->inner_pad, stream)) return rc;
+        {
+            float l2 = 0, wn = 0;
+            if (int rc = ln_range(e, L.ff.lw, L.ff.lb, c.dim, &L.ff.ln_bound, &l2, stream)) return rc;
+            if (int rc = weight_range(e, w1p, c.dim, 2 * e->inner_pad, c.dim, &wn, nullptr, stream)) return rc;
+            // |gelu(g) v| <= |g| |v| <= (||LN(x)|| max_j ||W1_j||)^2
+            L.ff.h_bound = 1.01f * (l2 * wn) * (l2 * wn);
+        }
         tw.layers.push_back(L);
     }
     tw.og = W(e, prefix + ".norm_out.gamma");
     tw.ob = W(e, prefix + ".norm_out.beta");
+    if (int rc = ln_range(e, tw.og, tw.ob, c.dim, &tw.out_bound, nullptr, stream)) return rc;
     return OMNITOK_OK;
 }
 
@@ -423,6 +518,14 @@ static int build_patch_operands(omnitok_engine *e, hipStream_t stream) {
             e->px_w[i] = W(e, q + ".0.weight");
             e->px_b[i] = W(e, q + ".0.bias");
         }
+        e->pe_bound[i] = 0.0f;
+        if (!c.patch_embed_cnn) {  // the patch rows are LayerNorm outputs: a static range exists
+            if (int rc = ln_range(e, W(e, p + ".1.weight"), W(e, p + ".1.bias"), K, &e->pe_bound[i], nullptr, stream))
+                return rc;
+            if (int rc = pack_h2(e, e->pe_w[i], ld, D, ld, stream)) return rc;
+            const int Kp = C * g.p_dec * g.p_dec * (i ? g.pt_dec : 1);
+            if (int rc = pack_h2(e, e->px_w[i], D, Kp, D, stream)) return rc;
+        }
     }
     return OMNITOK_OK;
 }
@@ -498,26 +601,44 @@ static int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, 
     return OMNITOK_OK;
 }
 
-// GEMM dispatch of the engine.  "gemm_mode" 1 (default): fp32 operands split in-kernel into three bf16
-// planes, six bf16-MFMA products (gemm_x3.hip; fp32-class error, 1.6x the fp32-MFMA rate); 0: the
-// fp32-input MFMA kernels of gemm.hip (bitwise an fmaf chain).  The mode is process-wide so that every
-// GEMM of a run -- whatever its size -- uses the same arithmetic (batch-size independence).
-int g_gemm_mode = 1;
+// GEMM dispatch of the engine.  "gemm_mode"
+//   2 (default): 2-way fp16 split, three fp16-MFMA products (gemm_h2.hip) wherever a rigorous range of the A
+//      operand is known (LayerNorm outputs: static; raw activations / attention outputs: from the row
+//      statistics pass; GEGLU hidden: from the weights), bf16x3 elsewhere;
+//   1: fp32 operands split in-kernel into three bf16 planes, six bf16-MFMA products (gemm_x3.hip);
+//   0: the fp32-input MFMA kernels of gemm.hip (bitwise an fmaf chain).
+// All three have fp32-class error (tests/test_gpu_ops.py).  The mode is process-wide and the per-element
+// arithmetic of each kernel is independent of the problem / tile size (batch-size independence).
+int g_gemm_mode = 2;
 
 static bool x3_ok(int N, int K, int flags) {
-    return g_gemm_mode == 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
+    return g_gemm_mode >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
            (!(flags & OMNITOK_GEMM_GEGLU) || N % 64 == 0);
 }
 
-static int eg_gemm(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias, const float *residual,
-                   int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags, int64_t rpg, int64_t gstride,
-                   int64_t goff, hipStream_t stream, const float *ln_stats = nullptr, const float *ln_g = nullptr,
-                   const float *ln_b = nullptr, int ln_cols = 0) {
+static float *next_bounds(omnitok_engine *e) {  // [n_clips][2] slots of one row-statistics launch
+    if (e->bound_next >= N_BOUND_LAUNCHES) return nullptr;
+    return e->bounds + (int64_t)2 * e->bound_clips * (e->bound_next++);
+}
+
+static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                   const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags,
+                   int64_t rpg, int64_t gstride, int64_t goff, hipStream_t stream, ABound ab = ABound(),
+                   const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
+                   int ln_cols = 0, float ln_bound = 0.0f) {
+    if (g_gemm_mode == 2 && ab.stat > 0.0f && x3_ok(N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
+        (!ab.dev || (ab.rpc > 0 && ab.rpc % 64 == 0 && rpg == 0))) {
+        auto it = e->h2w.find(w);
+        if (it != e->h2w.end() && ldw == K)
+            return omnitok_gemm_h2(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K, flags,
+                                   rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b, ln_cols,
+                                   ln_bound, stream);
+    }
     if (x3_ok(N, K, flags))
         return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
                                ln_stats, ln_g, ln_b, ln_cols, stream);
     if (ln_stats) {
-        set_error("eg_gemm: fused LayerNorm needs the x3 kernel");
+        set_error("eg_gemm: fused LayerNorm needs the x3 / h2 kernel");
         return OMNITOK_ERR_STATE;
     }
     return omnitok_gemm(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff, stream);
@@ -533,6 +654,8 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
     int64_t L = (int64_t)B * T * gh * gw;
     int S = gh * gw;
     double gemm_f = 2.0 * (double)L * D;
+    // split-operand GEMMs apply the LayerNorm while staging their A operand (no LN pass over HBM)
+    const bool fused = x3_ok(3 * D, D, 0) && D <= 512;
     for (const Layer &ly : tw.layers) {
         if (ly.kind == 'a' || ly.kind == 'm' || ly.kind == 'l') {
             // Pooling (reference attention.py:83-113), no residual (:674); then FF (+residual) on the
@@ -543,8 +666,8 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             }
             if (ly.kind == 'l')  // Linear(4D -> D) on four consecutive tokens: x.view(B, N/4, 4C)
                 OT_RUN("pool", 2.0 * (double)L * D * D,
-                       eg_gemm(e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
-                                    OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+                       eg_gemm(e, e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
+                               OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
             else
                 OT_RUN("pool", 1.25 * L * D * 4.0,
                        omnitok_token_resample(e->X.p, e->X2.p, ly.kind == 'a' ? 0 : 1, (int64_t)B * T, 1, gh, gw, D,
@@ -561,47 +684,60 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             OT_RUN("peg3d", 2.0 * L * D * 4.0,
                    omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
             std::swap(e->X, e->X2);
+            // device-side ranges of this layer's x (filled by the row-statistics pass): bs[0] >= max |x|,
+            // bs[1] >= max ||x_row||; |V_j| <= ||x|| ||Wv_j|| bounds the attention output (a convex
+            // combination of V rows) -- what the fp16-split GEMMs need (gemm_h2.hip)
+            float *bs = fused ? next_bounds(e) : nullptr;
+            if (fused && !bs) {
+                set_error("run_transformer: out of range slots");
+                return OMNITOK_ERR_STATE;
+            }
+            const int64_t rpc = L / B;  // both token orders keep a clip's rows contiguous (b is the outermost index)
+            const ABound ab_x = bs ? ABound{1.01f, bs, rpc} : ABound();
+            const ABound ab_ao = bs ? ABound{1.01f * ly.t.vnorm, bs + 1, rpc} : ABound();
             if (!spatial && T == 1) {
                 // Images: a temporal sequence of one token.  softmax over a single key is exactly 1
                 // (causal or not, with or without ALiBi), so the attention output is V bit for bit:
                 // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
                 // half and the attention kernel drop out.  Identical results to the general path.
+                if (bs && g_gemm_mode == 2)  // only the ranges are needed here
+                    OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
-                       eg_gemm(e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D,
-                                    0, 0, 0, 0, stream));
+                       eg_gemm(e, e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D, 0, 0,
+                               0, 0, stream, ab_x));
                 OT_RUN("gemm_out", gemm_f * D,
-                       eg_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D,
-                                    OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+                       eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
+                               0, 0, 0, stream, ab_ao));
                 goto feed_forward;
             }
             float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
             int64_t ldq = D, ldkv = 2 * D;
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
-            if (x3_ok(3 * D, D, 0) && D <= 512 && D % 256 == 0) {
+            if (fused && D % 256 == 0) {
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
                 // for the Q columns only; QKV rows are [q | k | v]
-                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
-                       eg_gemm(e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
-                               stream, e->ST.p, ly.t.ng, ly.t.nb, D));
+                       eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream, ab_x, e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound));
                 KV = e->QKV.p + D;
                 ldq = 3 * D;
                 ldkv = 3 * D;
-            } else if (x3_ok(D, D, 0) && D <= 512) {
-                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+            } else if (fused) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
-                       eg_gemm(e->X.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream, e->ST.p,
-                               ly.t.ng, ly.t.nb, D));
+                       eg_gemm(e, e->X.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream, ab_x,
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound));
                 OT_RUN("gemm_qkv", gemm_f * 2 * D,
-                       eg_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
-                               stream));
+                       eg_gemm(e, e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0, stream,
+                               ab_x));
             } else {
                 OT_RUN("layernorm", 2.0 * L * D * 4.0,
                        omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
-                       eg_gemm(e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
+                       eg_gemm(e, e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
                 OT_RUN("gemm_qkv", gemm_f * 2 * D,
-                       eg_gemm(e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
+                       eg_gemm(e, e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
                                stream));
             }
             if (spatial) {
@@ -624,50 +760,69 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                                              ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi, stream));
             }
             OT_RUN("gemm_out", gemm_f * D,
-                   eg_gemm(e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
-                                0, 0, 0, stream));
+                   eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL, 0, 0,
+                           0, stream, ab_ao));
         } else {
-            if (x3_ok(3 * D, D, 0) && D <= 512) {
-                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+            if (fused) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
-                       eg_gemm(e->X.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
-                               stream, e->ST.p, ly.w.ng, ly.w.nb, 3 * D));
+                       eg_gemm(e, e->X.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream, ABound{1.0f, nullptr, 0}, e->ST.p, ly.w.ng, ly.w.nb, 3 * D, ly.w.ln_bound));
             } else {
                 OT_RUN("layernorm", 2.0 * L * D * 4.0,
                        omnitok_layernorm(e->X.p, ly.w.ng, ly.w.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
-                       eg_gemm(e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                       eg_gemm(e, e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
                                stream));
             }
             OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
                    omnitok_attn_window(e->QKV.p, 3 * D, ly.w.bias_dense, e->AO.p, D, B * T, gh, gw, heads, stream));
             OT_RUN("gemm_out", gemm_f * D,
-                   eg_gemm(e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
-                                OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+                   eg_gemm(e, e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
+                           OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream,
+                           fused ? ABound{ly.w.ao_bound, nullptr, 0} : ABound()));
         }
     feed_forward:
         // FeedForward (reference attention.py:153-168)
-        if (x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU) && D <= 512) {
-            OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, stream));
+        if (fused && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
+            OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
             OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
-                   eg_gemm(e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
-                           OMNITOK_GEMM_GEGLU, 0, 0, 0, stream, e->ST.p, ly.ff.lw, ly.ff.lb, 2 * e->inner_pad));
+                   eg_gemm(e, e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
+                           OMNITOK_GEMM_GEGLU, 0, 0, 0, stream, ABound{1.0f, nullptr, 0}, e->ST.p, ly.ff.lw, ly.ff.lb,
+                           2 * e->inner_pad, ly.ff.ln_bound));
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
+                   eg_gemm(e, e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+                           e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream, ABound{ly.ff.h_bound, nullptr, 0}));
         } else {
             OT_RUN("layernorm", 2.0 * L * D * 4.0,
                    omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
             OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
-                   eg_gemm(e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
+                   eg_gemm(e, e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
                            D, OMNITOK_GEMM_GEGLU, 0, 0, 0, stream));
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
+                   eg_gemm(e, e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+                           e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
         }
-        OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
-               eg_gemm(e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
-                            e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
     }
     OT_RUN("layernorm", 2.0 * L * D * 4.0,
            omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
     std::swap(e->X, e->X2);
     *ghp = gh;
     *gwp = gw;
+    return OMNITOK_OK;
+}
+
+// range slots of the fp16-split GEMMs: per clip, zeroed once per encode / decode (atomic max targets)
+static int reset_bounds(omnitok_engine *e, int B, hipStream_t stream) {
+    if (B > e->bound_cap) {
+        if (e->bounds) OT_HIP(hipFree(e->bounds));
+        e->bounds = nullptr;
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->bounds), (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float)));
+        e->bound_cap = B;
+    }
+    e->bound_clips = B;
+    e->bound_next = 0;
+    OT_HIP(hipMemsetAsync(e->bounds, 0, (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float), stream));
     return OMNITOK_OK;
 }
 
@@ -688,6 +843,7 @@ static int ensure_workspace(omnitok_engine *e, int64_t L) {
     if (int rc = ensure(e->HD, L * hdw)) return rc;
     if (int rc = ensure(e->Z, L * 8)) return rc;
     if (int rc = ensure(e->ST, L * 2)) return rc;
+
     return OMNITOK_OK;
 }
 
@@ -828,6 +984,8 @@ extern "C" void omnitok_engine_destroy(omnitok_engine *e) {
     for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST})
         if (b->p) (void)hipFree(b->p);
     if (e->err_flag) (void)hipFree(e->err_flag);
+    if (e->bounds) (void)hipFree(e->bounds);
+    if (e->range_scratch) (void)hipFree(e->range_scratch);
     for (auto &r : e->recs) {
         (void)hipEventDestroy(r.a);
         (void)hipEventDestroy(r.b);
@@ -889,6 +1047,7 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     OT_HIP(hipStreamSynchronize(stream));
     for (void *p : e->owned) (void)hipFree(p);
     e->owned.clear();
+    e->h2w.clear();
     e->rope.clear();
     e->bias_tables.clear();
     const omnitok_config &c = e->cfg;
@@ -1003,6 +1162,7 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
     if (int rc = check_attention_grid("encode", c.enc_block, gh, gw)) return rc;
     const int64_t L = (int64_t)B * T * S;
     if (int rc = ensure_workspace(e, L)) return rc;
+    if (int rc = reset_bounds(e, B, stream)) return rc;
     const char *names[2] = {"encoder.to_patch_emb_first_frame", "encoder.to_patch_emb"};
 
     // ---- patch embedding (reference omnitokenizer.py:806-838, 934-945) ----------------------
@@ -1019,8 +1179,8 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
             OT_RUN("patchify_ln", ((double)M * K) * 8.0,
                    omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, nullptr, nullptr, 0.0f, e->HD.p, ld, stream));
             OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
-                   eg_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
-                                OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+                   eg_gemm(e, e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
+                           OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
             // scatter the frame group into the token tensor (a strided row copy)
             for (int b = 0; b < B; ++b)
                 OT_HIP(hipMemcpyAsync(e->X.p + ((int64_t)b * gstride + goff) * D, e->AO.p + (int64_t)b * rpg * D,
@@ -1031,8 +1191,8 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
                omnitok_patchify_ln(x, B, C, F, H, W_, f0, tt, pti, p, W(e, n + ".1.weight"), W(e, n + ".1.bias"), 1e-5f,
                                    e->HD.p, ld, stream));
         OT_RUN("gemm_patch", 2.0 * M * (double)K * D,
-               eg_gemm(e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld,
-                            OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+               eg_gemm(e, e->HD.p, ld, e->pe_w[i], ld, e->pe_b[i], nullptr, 0, e->AO.p, D, M, D, ld, OMNITOK_GEMM_BIAS,
+                       0, 0, 0, stream, ABound{e->pe_bound[i], nullptr, 0}));
         OT_RUN("layernorm", 2.0 * M * D * 4.0,
                omnitok_layernorm(e->AO.p, W(e, n + ".3.weight"), W(e, n + ".3.bias"), e->X.p, M, D, 1e-5f, rpg, gstride,
                                  goff, stream));
@@ -1136,6 +1296,7 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     const int S = gh2 * gw2;
     const int64_t L = (int64_t)B * T2 * S;
     if (int rc = ensure_workspace(e, L)) return rc;
+    if (int rc = reset_bounds(e, B, stream)) return rc;
     const int K0 = C * p * p, K1 = K0 * pt;
 
     if (kind == LatentKind::Ids)
@@ -1173,15 +1334,15 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream)) return rc;
     // ---- to_pixels (reference omnitokenizer.py:1006-1033, 1089-1096) -------------------------
     OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,
-           eg_gemm(e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
-                        OMNITOK_GEMM_BIAS, S, (int64_t)T2 * S, 0, stream));
+           eg_gemm(e, e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,
+                   OMNITOK_GEMM_BIAS, S, (int64_t)T2 * S, 0, stream, ABound{e->dec_s.out_bound, nullptr, 0}));
     OT_RUN("unpatchify", (double)B * S * K0 * 8.0,
            omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 0, 1, 1, p, pixels_out, stream));
     if (T2 > 1) {
         const int64_t M1 = (int64_t)B * (T2 - 1) * S;
         OT_RUN("gemm_pixels", 2.0 * M1 * (double)K1 * D,
-               eg_gemm(e->X.p, D, e->px_w[1], D, e->px_b[1], nullptr, 0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS,
-                            (int64_t)(T2 - 1) * S, (int64_t)T2 * S, S, stream));
+               eg_gemm(e, e->X.p, D, e->px_w[1], D, e->px_b[1], nullptr, 0, e->HD.p, K1, M1, K1, D, OMNITOK_GEMM_BIAS,
+                       (int64_t)(T2 - 1) * S, (int64_t)T2 * S, S, stream, ABound{e->dec_s.out_bound, nullptr, 0}));
         OT_RUN("unpatchify", (double)M1 * K1 * 8.0,
                omnitok_unpatchify(e->HD.p, B, C, F, H, W_, 1, T2 - 1, pt, p, pixels_out, stream));
     }

@@ -31,7 +31,7 @@
 //  * optional LayerNorm fused into the A staging (mean / rstd per row from a stats pass, gamma/beta
 //    from an LDS table): the LN output never exists in HBM, and a column range [0, ln_cols) of one
 //    launch can take LN(x) while the rest takes x (Q from LN(x), K/V from x: attention.py:404-412).
-#include "gemm_common.h"
+#include "gemm_x_common.h"
 
 #include <type_traits>
 
@@ -90,77 +90,6 @@ __device__ __forceinline__ void split3x4(const f32x4 v, u32x2 &p0, u32x2 &p1, u3
     p2[1] = __builtin_amdgcn_perm(b2[3], b2[2], 0x07060302u);
 }
 
-__device__ __forceinline__ auto x3_rsrc(const float *ptr, int bytes) {
-    const unsigned long long u = reinterpret_cast<unsigned long long>(ptr);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u);
-    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((unsigned long long)hi32 << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
-// Fused epilogue of one wave tile (MI*32 rows x NI*32 columns at (row0, col0)); N % 32 == 0.
-// Same technique as gemm_epilogue: wave-uniform buffer descriptors bound the rows (loads of rows
-// >= M return 0, stores are dropped), so there are no per-element guards.
-template <int FLAGS, int MI, int NI>
-__device__ __forceinline__ void x3_epilogue(const GemmParams &p, f32x16 (&acc)[MI][NI], int64_t row0, int col0,
-                                            int r32, int hi) {
-    int64_t vr64 = p.M - row0;
-    const int vr = vr64 > MI * 32 ? MI * 32 : (vr64 < 0 ? 0 : (int)vr64);
-    const int ldc = (int)p.ldc;
-    if constexpr (FLAGS & OMNITOK_GEMM_GEGLU) {
-        static_assert(NI % 2 == 0 || !(FLAGS & OMNITOK_GEMM_GEGLU), "GEGLU pairs two 32-column blocks per wave");
-        const int ocol0 = col0 / 2;
-        const int ow = NI * 16;
-        const auto c_rs = x3_rsrc(p.c + row0 * p.ldc + ocol0, vr > 0 ? ((vr - 1) * ldc + ow) * 4 : 0);
-        const int c_voff = (4 * hi * ldc + r32) * 4;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int np = 0; np < NI / 2; ++np)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    __builtin_amdgcn_raw_buffer_store_b32(
-                        __builtin_bit_cast(unsigned, gelu_erf(acc[mi][2 * np + 1][r]) * acc[mi][2 * np][r]), c_rs,
-                        c_voff, ((mi * 32 + mfma32_row(r, 0)) * ldc + np * 32) * 4, 0);
-    } else {
-        if (col0 >= p.N) return;
-        int vc = p.N - col0;  // valid columns of this wave tile (multiple of 32)
-        if (vc > NI * 32) vc = NI * 32;
-        const int ldr = (int)p.ldr;
-        const auto c_rs = x3_rsrc(p.c + row0 * p.ldc + col0, vr > 0 ? ((vr - 1) * ldc + vc) * 4 : 0);
-        const int c_voff = (4 * hi * ldc + r32) * 4;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            if (ni * 32 >= vc) break;
-            float bv = 0.0f;
-            if constexpr (FLAGS & OMNITOK_GEMM_BIAS) bv = p.bias[col0 + ni * 32 + r32];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                float res[16];  // 16 residual loads in flight
-                if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) {
-                    const auto r_rs =
-                        x3_rsrc(p.residual + row0 * p.ldr + col0, vr > 0 ? ((vr - 1) * ldr + vc) * 4 : 0);
-                    const int r_voff = (4 * hi * ldr + r32) * 4;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        res[r] = __builtin_bit_cast(
-                            float, __builtin_amdgcn_raw_buffer_load_b32(
-                                       r_rs, r_voff, ((mi * 32 + mfma32_row(r, 0)) * ldr + ni * 32) * 4, 0));
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[mi][ni][r];
-                    if constexpr (FLAGS & OMNITOK_GEMM_BIAS) v += bv;
-                    if constexpr (FLAGS & OMNITOK_GEMM_LEAKY) v = v > 0.0f ? v : 0.1f * v;
-                    if constexpr (FLAGS & OMNITOK_GEMM_RESIDUAL) v += res[r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), c_rs, c_voff,
-                                                          ((mi * 32 + mfma32_row(r, 0)) * ldc + ni * 32) * 4, 0);
-                }
-            }
-        }
-    }
-}
-
 // DBG (measurement builds only, wrong results): 1 skip the split arithmetic, 2 skip the LDS stores of the
 // K loop, 4 skip the global loads of the K loop, 8 skip the per-step barrier
 template <int FLAGS, typename C, bool LN, int DBG = 0>
@@ -197,7 +126,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(X3Params xp) {
     const int lrow = tid >> 2, lq = tid & 3;
     const float *ap[NA];
     const float *wp[NB];
-    float cur_mean[NA], cur_rstd[NA];  // LN statistics of the rows the load pointers address
+    const float *sp[NA];               // (mean, rstd) of the rows the load pointers address
     bool cur_ln = false;               // does the tile the load pointers address take LN(a)?
     auto set_ptrs = [&](int i) {
         const int lid = xcd_remap((int)blockIdx.x + i * (int)gridDim.x, p.ntiles);
@@ -213,10 +142,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(X3Params xp) {
             int64_t ar = gr;
             if (p.a_rpg > 0) ar = (gr / p.a_rpg) * p.a_stride + p.a_off + (gr % p.a_rpg);
             ap[r] = p.a + ar * p.lda + lq * 4;
-            if constexpr (LN) {
-                cur_mean[r] = ln_on ? xp.ln_stats[2 * ar] : 0.0f;
-                cur_rstd[r] = ln_on ? xp.ln_stats[2 * ar + 1] : 1.0f;
-            }
+            if constexpr (LN) sp[r] = xp.ln_stats + 2 * ar;
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
@@ -238,8 +164,11 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(X3Params xp) {
         if constexpr (LN) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
-                st_mean[set][r] = cur_mean[r];
-                st_rstd[set][r] = cur_rstd[r];
+                // loaded with the K-step's A data (8 bytes per row, L1-resident): the statistics travel
+                // with the staged set across tile switches
+                const float2 ms = *reinterpret_cast<const float2 *>(sp[r]);
+                st_mean[set][r] = ms.x;
+                st_rstd[set][r] = ms.y;
             }
             st_tab[set] = 2 * (k0 + lq * 4);
             st_ln[set] = cur_ln;
@@ -259,7 +188,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(X3Params xp) {
                     gb0 = f32x4{1.0f, 0.0f, 1.0f, 0.0f};
                     gb1 = gb0;
                 }
-                const float m = st_mean[set][piece], rs = st_rstd[set][piece];
+                const float m = st_ln[set] ? st_mean[set][piece] : 0.0f, rs = st_ln[set] ? st_rstd[set][piece] : 1.0f;
                 v[0] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v[0], m), rs), gb0[0]), gb0[1]);
                 v[1] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v[1], m), rs), gb0[2]), gb0[3]);
                 v[2] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(v[2], m), rs), gb1[0]), gb1[1]);

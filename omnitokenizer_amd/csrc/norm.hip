@@ -63,21 +63,81 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
-// A operand (gemm_x3.hip), so LN(x) is never written to HBM
+// A operand (gemm_x3.hip / gemm_h2.hip), so LN(x) is never written to HBM.
+// bounds (optional, [n_clips][2] floats that the caller zeroed; clip of row m = m / rows_per_clip, one clip
+// if rows_per_clip <= 0): atomic max over the rows of each clip of
+//   [0] |mean| + sqrt(dim) / rstd   >= max_k |x_k|      (|x_k - mean| <= sqrt(dim * var))
+//   [1] sqrt(dim * (mean^2 + 1 / rstd^2)) >= ||x||_2
+// -- the range information the fp16-split GEMM needs for operands derived from x (gemm_h2.hip).  Per
+// clip, so that a clip's results never depend on what else is in the batch.
+// 16 rows per workgroup (4 per wave): one atomic pair per workgroup when its rows share a clip.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim, float eps,
-                                                        float *__restrict__ stats) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+                                                        float *__restrict__ stats, float *__restrict__ bounds,
+                                                        int64_t rows_per_clip) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
     const int nv = (dim / 4 + 63) / 64;
-    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
-    f32x4 v[LN_MAX_V4];
+    float b0 = 0.0f, b1 = 0.0f;
+    const bool one_clip = rows_per_clip <= 0 || (row0 / rows_per_clip == (row0 + 15) / rows_per_clip);
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = __builtin_nontemporal_load(xr + lane + 64 * i);
-    float mean, rstd;
-    row_stats(v, nv, lane, dim, eps, mean, rstd);
-    if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
+    for (int j = 0; j < 4; ++j) {
+        const int64_t row = row0 + wave * 4 + j;
+        if (row >= rows) break;
+        const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
+        f32x4 v[LN_MAX_V4];
+#pragma unroll
+        for (int i = 0; i < LN_MAX_V4; ++i)
+            if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = __builtin_nontemporal_load(xr + lane + 64 * i);
+        float mean, rstd;
+        row_stats(v, nv, lane, dim, eps, mean, rstd);
+        if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
+        const float sd = 1.0f / rstd;
+        const float r0 = fabsf(mean) + sqrtf((float)dim) * sd;
+        const float r1 = sqrtf((float)dim * (mean * mean + sd * sd));
+        if (bounds && !one_clip && lane == 0 && r0 == r0 && r1 == r1) {
+            unsigned *bc = reinterpret_cast<unsigned *>(bounds) + 2 * (row / rows_per_clip);
+            atomicMax(bc, __float_as_uint(r0));  // non-negative floats order like their bit patterns
+            atomicMax(bc + 1, __float_as_uint(r1));
+        }
+        b0 = fmaxf(b0, r0 == r0 ? r0 : 0.0f);
+        b1 = fmaxf(b1, r1 == r1 ? r1 : 0.0f);
+    }
+    if (bounds && one_clip) {
+        __shared__ float sh[2][4];
+        if (lane == 0) {
+            sh[0][wave] = b0;
+            sh[1][wave] = b1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 && row0 < rows) {
+            const float m = fmaxf(fmaxf(sh[threadIdx.x][0], sh[threadIdx.x][1]),
+                                  fmaxf(sh[threadIdx.x][2], sh[threadIdx.x][3]));
+            const int64_t clip = rows_per_clip > 0 ? row0 / rows_per_clip : 0;
+            atomicMax(reinterpret_cast<unsigned *>(bounds) + 2 * clip + threadIdx.x, __float_as_uint(m));
+        }
+    }
+}
+
+// out[0] = max over rows of ||w_row||_2, out[1] = max |w| (atomic max; the caller zeroes out): the static
+// range information of a weight matrix / LayerNorm vector (rows = 1) for gemm_h2.hip's bounds
+__global__ __launch_bounds__(256) void weight_range_kernel(const float *__restrict__ w, int64_t ld, int rows, int K,
+                                                           float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    float ss = 0.0f, mx = 0.0f;
+    for (int k = lane; k < K; k += 64) {
+        const float v = w[(int64_t)n * ld + k];
+        ss += v * v;
+        mx = fmaxf(mx, fabsf(v));
+    }
+    ss = wave_allsum(ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) {
+        atomicMax(reinterpret_cast<unsigned *>(out), __float_as_uint(sqrtf(ss)));
+        atomicMax(reinterpret_cast<unsigned *>(out) + 1, __float_as_uint(mx));
+    }
 }
 
 // one wave per patch: gathers the (c, pt, p1, p2) features (p2 contiguous in memory) and
@@ -196,16 +256,25 @@ extern "C" int omnitok_layernorm(const float *x, const float *gamma, const float
     return OMNITOK_OK;
 }
 
-extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats,
-                                 omnitok_stream_t stream_) {
+extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats, float *bounds,
+                                 int64_t rows_per_clip, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(x && stats, "row_stats: null pointer");
     OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4, "row_stats: dim=%d unsupported", dim);
     OT_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "row_stats: alignment");
     if (rows == 0) return OMNITOK_OK;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, dim, eps,
-                       stats);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, x, rows, dim, eps,
+                       stats, bounds, rows_per_clip);
     OT_LAUNCH_CHECK("row_stats");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_weight_range(const float *w, int64_t ldw, int rows, int K, float *out2,
+                                    omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(w && out2 && rows > 0 && K > 0, "weight_range: bad arguments");
+    hipLaunchKernelGGL(weight_range_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, w, ldw, rows, K, out2);
+    OT_LAUNCH_CHECK("weight_range");
     return OMNITOK_OK;
 }
 

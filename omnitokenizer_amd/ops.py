@@ -94,12 +94,17 @@ def linear_bf16x3(x, weight, bias=None, residual=None, geglu=False, w_planes=Non
     return out
 
 
-def row_stats(x, eps=1e-5):
-    """[rows, 2] = (mean, rstd) per row of x[..., dim] (the statistics a fused-LN GEMM consumes)."""
+def row_stats(x, eps=1e-5, bounds=None, rows_per_clip=0):
+    """[rows, 2] = (mean, rstd) per row of x[..., dim] (the statistics a fused-LN GEMM consumes).
+    bounds: optional zeroed float32[n_clips, 2] that receives, per clip of rows_per_clip rows, upper bounds of
+    max|x| and max ||x_row||_2."""
     x = _req(x, "x")
     rows, dim = x.numel() // x.shape[-1], x.shape[-1]
     st = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
-    check(_lib.load().omnitok_row_stats(_p(x), rows, dim, eps, _p(st), _stream()), "row_stats")
+    if bounds is not None:
+        _req(bounds, "bounds")
+    check(_lib.load().omnitok_row_stats(_p(x), rows, dim, eps, _p(st), _p(bounds), int(rows_per_clip), _stream()),
+          "row_stats")
     return st
 
 
@@ -132,6 +137,44 @@ def linear_x3(x, weight, bias=None, residual=None, geglu=False, ln=None, ln_cols
     check(_lib.load().omnitok_gemm_x3(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), ncol, _p(out),
                                       ncol, M, N, K, flags, 0, 0, 0, _p(st), _p(g), _p(b),
                                       int(ln_cols if ln_cols is not None else N), _stream()), "gemm_x3")
+    return out
+
+
+def h2_pack_weight(weight):
+    """fp32 [N, K] -> (planes int16 [N, K/8, 2, 8] holding fp16 hi|lo of the row-scaled weight, scale [N])."""
+    weight = _req(weight, "weight")
+    N, K = weight.shape
+    planes = torch.empty(N, K // 8, 2, 8, device=weight.device, dtype=torch.float16)
+    scale = torch.empty(N, device=weight.device, dtype=torch.float32)
+    check(_lib.load().omnitok_h2_pack_weight(_p(weight), K, N, K, _p(planes), _p(scale), _stream()), "h2_pack_weight")
+    return planes, scale
+
+
+def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound_dev=None, ln=None, ln_cols=None,
+              ln_bound=0.0, a_bound_stride=1, rows_per_clip=0):
+    """y = x @ weight.T (+epilogue) from 2-way fp16 splits of both operands (three fp16 MFMA products, fp32
+    accumulate; csrc/gemm_h2.hip).  packed = h2_pack_weight(weight); a_bound >= max|x| (times *a_bound_dev)."""
+    x = _req(x, "x")
+    planes, scale = packed
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = planes.shape[0]
+    ncol = N // 2 if geglu else N
+    out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
+    if bias is not None:
+        _req(bias, "bias")
+    if residual is not None:
+        _req(residual, "residual")
+    flags = GEMM_GEGLU if geglu else ((GEMM_BIAS if bias is not None else 0) |
+                                      (GEMM_RESIDUAL if residual is not None else 0))
+    st = g = b = None
+    if ln is not None:
+        st, g, b = ln
+    check(_lib.load().omnitok_gemm_h2(_p(x), K, _p(planes), _p(scale), _p(bias), _p(residual), ncol, _p(out), ncol,
+                                      M, N, K, flags, 0, 0, 0, float(a_bound), _p(a_bound_dev), int(a_bound_stride),
+                                      int(rows_per_clip), _p(st), _p(g), _p(b),
+                                      int(ln_cols if ln_cols is not None else N), float(ln_bound), _stream()),
+          "gemm_h2")
     return out
 
 
