@@ -90,18 +90,6 @@ int omnitok_gemm(const float *a, int64_t lda, const float *w, int64_t ldw, const
                  int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
                  omnitok_stream_t stream);
 
-/* --- opt-in: fp32 GEMM on the bf16 matrix cores by exact 3-way operand splitting (gemm_split.hip) ---
- * omnitok_split3: x[M,K] fp32 (row m at x + row(m)*ldx, same row map as omnitok_gemm) -> three bf16
- * planes planes[3][M][K] with x == p0 + p1 + p2 exactly (8+8+8 significand bits).
- * omnitok_gemm_bf16x3: c = a . w^T (+epilogue as omnitok_gemm) from split planes of a [3][M][K] and
- * w [3][N][K], six bf16 MFMA products per element pair (the three dropped are < 2^-24 |a b|), fp32
- * accumulation.  K % 64 == 0, N % 64 == 0. */
-int omnitok_split3(const float *x, int64_t ldx, int64_t M, int K, int64_t rows_per_group,
-                   int64_t group_stride, int64_t group_offset, void *planes, omnitok_stream_t stream);
-int omnitok_gemm_bf16x3(const void *a_planes, const void *w_planes, const float *bias,
-                        const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N,
-                        int K, int flags, omnitok_stream_t stream);
-
 /* --- fp32 GEMM on the bf16 matrix cores, operands split in-kernel (csrc/gemm_x3.hip) ----------------
  * Same contract as omnitok_gemm (c = a . w^T + epilogue, fp32 operands in HBM, fp32 result) but each
  * fp32 operand element is split exactly into three bf16 numbers while it is staged to LDS and six

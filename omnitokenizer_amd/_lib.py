@@ -42,8 +42,6 @@ I64 = c_int64
 _PROTOS = {
     "omnitok_layernorm": [P, P, P, P, I64, c_int, c_float, I64, I64, I64, P],
     "omnitok_gemm": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P],
-    "omnitok_split3": [P, I64, I64, c_int, I64, I64, I64, P, P],
-    "omnitok_gemm_bf16x3": [P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, P],
     "omnitok_gemm_x3": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P, P, P, c_int, P],
     "omnitok_h2_pack_weight": [P, I64, c_int, c_int, P, P, P],
     "omnitok_gemm_h2": [P, I64, P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, c_float, P, c_int,

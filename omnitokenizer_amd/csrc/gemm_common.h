@@ -1,5 +1,5 @@
-// Shared pieces of the GEMM kernels (fp32-MFMA kernels in gemm.hip, split-bf16 kernel in
-// gemm_split.hip): parameters, tile order, LDS-only barrier, fused epilogue.
+// Shared pieces of the GEMM kernels (fp32-MFMA kernels in gemm.hip, split-operand kernels in gemm_x3.hip /
+// gemm_h2.hip): parameters, tile order, LDS-only barrier, fused epilogue.
 #pragma once
 #include "common.h"
 

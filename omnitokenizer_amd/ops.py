@@ -67,33 +67,6 @@ def linear(x, weight, bias=None, residual=None, leaky=False):
     return out
 
 
-def split3(x):
-    """fp32 [M, K] -> bf16 planes [3, M, K] (int16 storage) with x == p0 + p1 + p2 exactly."""
-    x = _req(x, "x")
-    K = x.shape[-1]
-    M = x.numel() // K
-    planes = torch.empty(3, M, K, device=x.device, dtype=torch.int16)
-    check(_lib.load().omnitok_split3(_p(x), K, M, K, 0, 0, 0, _p(planes), _stream()), "split3")
-    return planes
-
-
-def linear_bf16x3(x, weight, bias=None, residual=None, geglu=False, w_planes=None):
-    """y = x @ weight.T (+epilogue) on the bf16 matrix cores from exact 3-way splits of both operands."""
-    x = _req(x, "x")
-    K = x.shape[-1]
-    M = x.numel() // K
-    wp = w_planes if w_planes is not None else split3(_req(weight, "weight"))
-    N = wp.shape[1]
-    xp = split3(x)
-    ncol = N // 2 if geglu else N
-    out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
-    flags = GEMM_GEGLU if geglu else ((GEMM_BIAS if bias is not None else 0) |
-                                      (GEMM_RESIDUAL if residual is not None else 0))
-    check(_lib.load().omnitok_gemm_bf16x3(_p(xp), _p(wp), _p(bias), _p(residual), ncol, _p(out), ncol, M, N, K,
-                                          flags, _stream()), "gemm_bf16x3")
-    return out
-
-
 def row_stats(x, eps=1e-5, bounds=None, rows_per_clip=0):
     """[rows, 2] = (mean, rstd) per row of x[..., dim] (the statistics a fused-LN GEMM consumes).
     bounds: optional zeroed float32[n_clips, 2] that receives, per clip of rows_per_clip rows, upper bounds of

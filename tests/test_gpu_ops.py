@@ -117,54 +117,6 @@ def test_gemm_geglu_feedforward(ops, gemm_variant, M):
     assert maxerr(out, hid_ref @ w2.double().t() + x.double()) < 3e-5
 
 
-def _planes_to_f64(planes):
-    """bf16 planes stored as int16 -> float64 values."""
-    u = (planes.cpu().to(torch.int32) & 0xFFFF) << 16
-    return u.view(torch.float32).double()
-
-
-def test_split3_is_exact(ops):
-    x = rnd(777, 512, seed=14) * torch.logspace(-6, 6, 512)
-    x[0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.4e38, 1.2e-30, 1 + 2**-23, -(2 - 2**-23)])
-    pl = _planes_to_f64(ops.split3(dev(x)))
-    assert torch.equal(pl.sum(0), x.double()), "x != p0 + p1 + p2"
-
-
-@pytest.mark.parametrize("M,N,K", [(1024, 512, 512), (1000, 192, 512), (4096, 1536, 512), (257, 768, 1408),
-                                   (20000 + 77, 1024, 512), (640, 512, 64)])
-@pytest.mark.parametrize("mode", ["plain", "bias", "residual", "bias_residual"])
-def test_gemm_bf16x3(ops, M, N, K, mode):
-    """The split-operand GEMM on the bf16 matrix cores must sit in the same error class as the fp32
-    MFMA kernel (same tolerance against fp64)."""
-    a, w = rnd(M, K, seed=4), rnd(N, K, seed=5) * 0.05
-    bias = rnd(N, seed=6) if "bias" in mode else None
-    res = rnd(M, N, seed=7) if "residual" in mode else None
-    ref = a.double() @ w.double().t()
-    if bias is not None:
-        ref = ref + bias.double()
-    if res is not None:
-        ref = ref + res.double()
-    out = ops.linear_bf16x3(dev(a), dev(w), None if bias is None else dev(bias), None if res is None else dev(res))
-    scale = ref.abs().max().item()
-    err = maxerr(out, ref)
-    assert err < 3e-6 * max(scale, 1.0) * math.sqrt(K / 512), f"err {err} scale {scale}"
-    if mode == "plain":
-        err32 = maxerr(ops.linear(dev(a), dev(w)), ref)
-        assert err < 4 * err32 + 1e-7, f"bf16x3 err {err} vs fp32-MFMA err {err32}"
-
-
-def test_gemm_bf16x3_geglu(ops):
-    inner, D, pad, M = 1365, 512, 1408, 1000
-    x = rnd(M, D, seed=11)
-    w1 = rnd(2 * inner, D, seed=12) * 0.05
-    val, gate = (x.double() @ w1.double().t()).chunk(2, dim=-1)
-    hid_ref = F.gelu(gate) * val
-    hid = ops.linear_bf16x3(dev(x), ops.pack_geglu_weight(dev(w1), pad), geglu=True)
-    assert hid.shape == (M, pad)
-    assert maxerr(hid[:, :inner], hid_ref) < 1e-5 * max(1.0, hid_ref.abs().max().item())
-    assert hid[:, inner:].abs().max().item() == 0.0
-
-
 @pytest.mark.parametrize("pt,frames", [(1, 1), (4, 9), (2, 5)])
 def test_patchify_ln_and_unpatchify(ops, pt, frames):
     B, C, H, W, p = 2, 3, 64, 64, 8

@@ -54,19 +54,17 @@ def main():
         res["gemm_ff_in"] = (ms, 2.0 * L * D * 2730 / ms / 1e9, "TF")
     if want("x3_ff_in"):
         w = ops.pack_geglu_weight(r(2730, D) * 0.04, 1408)
-        wp = ops.split3(w)
-        ms = timeit(lambda: ops.linear_bf16x3(x, None, geglu=True, w_planes=wp), a.iters)
-        res["x3_ff_in(+split)"] = (ms, 2.0 * L * D * 2730 / ms / 1e9, "TF")
-        ms = timeit(lambda: ops.split3(x), a.iters)
-        res["split3_Lx512"] = (ms, L * D * 10.0 / ms / 1e6, "GB/s")
-    if want("x3_q"):
-        wp = ops.split3(r(D, D) * 0.04)
-        ms = timeit(lambda: ops.linear_bf16x3(x, None, w_planes=wp), a.iters)
-        res["x3_q(+split)"] = (ms, 2.0 * L * D * D / ms / 1e9, "TF")
-    if want("x3_kv"):
-        wp = ops.split3(r(2 * D, D) * 0.04)
-        ms = timeit(lambda: ops.linear_bf16x3(x, None, w_planes=wp), a.iters)
-        res["x3_kv(+split)"] = (ms, 2.0 * L * D * 2 * D / ms / 1e9, "TF")
+        ms = timeit(lambda: ops.linear_x3(x, w, geglu=True), a.iters)
+        res["x3_ff_in"] = (ms, 2.0 * L * D * 2730 / ms / 1e9, "TF")
+    if want("h2_ff_in"):
+        w = ops.pack_geglu_weight(r(2730, D) * 0.04, 1408)
+        pk = ops.h2_pack_weight(w)
+        ms = timeit(lambda: ops.linear_h2(x, pk, 8.0, geglu=True), a.iters)
+        res["h2_ff_in"] = (ms, 2.0 * L * D * 2730 / ms / 1e9, "TF")
+    if want("h2_kv"):
+        pk = ops.h2_pack_weight(r(2 * D, D) * 0.04)
+        ms = timeit(lambda: ops.linear_h2(x, pk, 8.0), a.iters)
+        res["h2_kv"] = (ms, 2.0 * L * D * 2 * D / ms / 1e9, "TF")
     if want("gemm_ff_out"):
         h = r(L, 1408)
         w = r(D, 1408) * 0.04
