@@ -32,7 +32,12 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA = fp32 vector peak
+PEAK_F16_TFLOPS = 2500.0  # dense fp16 / bf16 MFMA peak (same guide)
 PEAK_HBM_GBS = 8000.0
+# matrix-pipe products a GEMM kernel spends per fp32 multiply-add, by engine "gemm_mode"
+GEMM_MODES = {0: ("fp32-input MFMA", 1, PEAK_F32_TFLOPS),
+              1: ("fp32 operands as 3 bf16 planes, 6 bf16-MFMA products", 6, PEAK_F16_TFLOPS),
+              2: ("fp32 operands as 2 fp16 planes, 3 fp16-MFMA products", 3, PEAK_F16_TFLOPS)}
 
 
 def main():
@@ -44,6 +49,8 @@ def main():
     ap.add_argument("--frames", type=int, default=17)
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--n-codes", type=int, default=0, help="codebook size (default: the stage-2 8192; C5: 16384)")
+    ap.add_argument("--gemm-mode", type=int, default=2, choices=[0, 1, 2],
+                    help="engine GEMM arithmetic: 2 fp16x2 split (default), 1 bf16x3 split, 0 fp32-input MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
@@ -58,9 +65,10 @@ def main():
     info = launch.init_ranks(a.gpus, backend="nccl")   # RCCL on ROCm
     world, rank, local_rank = info.world, info.rank, info.local_rank
 
-    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib, make_args, synth
     from omnitokenizer_amd.config import OmniTokConfig
 
+    _lib.set_option("gemm_mode", a.gemm_mode)
     over = dict(resolution=a.resolution)
     if a.n_codes:
         over["n_codes"] = a.n_codes
@@ -105,11 +113,16 @@ def main():
                                  work_per_step=r["work"] / nprof)
         mfma = {"gemm_ff_in", "gemm_ff_out", "gemm_qkv", "gemm_out", "gemm_patch", "gemm_pixels", "attn_spatial",
                 "attn_window", "vq_argmin"}
+        gm_name, gm_products, gm_pipe_peak = GEMM_MODES[a.gemm_mode]
+        gemm_roof = gm_pipe_peak / gm_products   # fp32-equivalent roof of the GEMM kernels in this mode
         for name, k in kernels.items():
             if k["ms_per_step"] > 0:
                 if name in mfma:
+                    # algorithmic (fp32-equivalent) rate; GEMM families run on the split-operand kernels
                     k["tflops"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2)
                     k["frac_f32_peak"] = round(k["tflops"] / PEAK_F32_TFLOPS, 4)
+                    if name.startswith("gemm_"):
+                        k["frac_of_mode_roof"] = round(k["tflops"] / gemm_roof, 4)
                 else:
                     k["gbs"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9, 1)
                     k["frac_hbm_peak"] = round(k["gbs"] / PEAK_HBM_GBS, 4)
@@ -118,9 +131,16 @@ def main():
         if dom in mfma:
             per_launch_flops = dk["work_per_step"] / dk["launches_per_step"]
             avg_ms = dk["ms_per_step"] / dk["launches_per_step"]
+            is_gemm = dom.startswith("gemm_")
+            peak = gemm_roof if is_gemm else PEAK_F32_TFLOPS
             roofline = dict(kernel=dom, bound="mfma", achieved=round(per_launch_flops / (avg_ms * 1e-3) / 1e12, 2),
-                            peak=PEAK_F32_TFLOPS, unit="TFLOP/s", avg_launch_ms=round(avg_ms, 4),
+                            peak=round(peak, 1), unit="TFLOP/s", avg_launch_ms=round(avg_ms, 4),
                             flops_per_launch=per_launch_flops, traffic=None)
+            if is_gemm:
+                roofline["peak_definition"] = (f"{gm_pipe_peak:.0f} TF dense MFMA peak / {gm_products} matrix-pipe "
+                                               f"products per fp32 multiply-add ({gm_name}); algorithmic fp32 flops")
+                roofline["frac_of_f32_mfma_peak"] = round(roofline["achieved"] / PEAK_F32_TFLOPS, 4)
+                roofline["matrix_pipe_tflops"] = round(roofline["achieved"] * gm_products, 1)
         else:
             per_launch_bytes = dk["work_per_step"] / dk["launches_per_step"]
             avg_ms = dk["ms_per_step"] / dk["launches_per_step"]
@@ -132,7 +152,7 @@ def main():
         # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied; bench.py cannot
         # collect counters itself).  null if no PMC run covers this kernel / workload.
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"gemm_mode_{a.gemm_mode}", {})
             if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
                 roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
                 roofline["traffic_source"] = pmc[dom]["source"]
@@ -162,8 +182,9 @@ def main():
         out = {
             "metric": "patches/sec encode+decode", "value": round(value, 1), "unit": "patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.gemm_mode == 0 else f"f32 ({gm_name}, fp32 accumulate; attention / VQ on fp32 MFMA)",
+            "gemm_mode": a.gemm_mode, "data": "synthetic",
             "config": {"workload": wl_name + f": B={B}/GPU " + (f"{a.resolution}x{a.resolution} images" if is_image
                                     else f"{a.frames}x{a.resolution}x{a.resolution} clips")
                                    + f", stage-2 (imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes={cfg.n_codes}), encode + "

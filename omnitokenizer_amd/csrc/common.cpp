@@ -24,6 +24,7 @@ extern int g_peg_variant;
 extern int g_x3_tile;
 extern int g_x3_dbg;
 extern int g_h2_tile;
+extern int g_h2_dbg;
 extern int g_gemm_mode;
 }  // namespace omnitok
 
@@ -36,6 +37,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "vq_split")) omnitok::g_vq_split = value;
     else if (!strcmp(name, "x3_tile")) omnitok::g_x3_tile = value;
     else if (!strcmp(name, "gemm_mode")) omnitok::g_gemm_mode = value;
+    else if (!strcmp(name, "h2_dbg")) omnitok::g_h2_dbg = value;
     else if (!strcmp(name, "h2_tile")) omnitok::g_h2_tile = value;
     else if (!strcmp(name, "x3_dbg")) omnitok::g_x3_dbg = value;
     else if (!strcmp(name, "peg_variant")) omnitok::g_peg_variant = value;

@@ -34,6 +34,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
+extern int g_gemm_gn;
 int g_h2_tile = 0;  // "h2_tile": 0 auto, 1 256x256, 3 128x128, 4 64x64 / 64x128 (A/B measurements)
 
 struct H2Params {
@@ -77,7 +78,9 @@ __device__ __forceinline__ float h2_scale_of_bound(float bound) {
     return ldexpf(1.0f, -e);
 }
 
-template <int FLAGS, typename C, bool LN>
+// DBG (measurement builds only, wrong results): 1 skip the split arithmetic, 2 skip the LDS stores of the
+// K loop, 4 skip the global loads of the K loop, 8 skip the per-step barrier
+template <int FLAGS, typename C, bool LN, int DBG = 0>
 __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
     constexpr int MI = C::MI, NI = C::NI, NA = C::NA, NB = C::NB, NP = C::NP;
     constexpr int TM = C::TM, TN = C::TN, RPP = C::RPP, SBK = 16;
@@ -98,7 +101,11 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
         float b = hp.a_bound;
         if (hp.a_bound_dev) {
             const int64_t clip = hp.a_rpc > 0 ? tile_row0 / hp.a_rpc : 0;
-            b *= hp.a_bound_dev[clip * hp.a_bound_stride];
+            float m = 0.0f;
+#pragma unroll
+            for (int sub = 0; sub < OMNITOK_RANGE_SUBSLOTS; ++sub)
+                m = fmaxf(m, hp.a_bound_dev[(clip * OMNITOK_RANGE_SUBSLOTS + sub) * hp.a_bound_stride]);
+            b *= m;
         }
         return h2_scale_of_bound(b);
     };
@@ -151,7 +158,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
     int st_tab[2];
     bool st_ln[2];
     float st_sraw[2];
-    auto gload = [&](int set, int k0) {
+    auto gload = [&](int set, int k0, bool in_loop = true) {
+        if constexpr ((DBG & 4) != 0)
+            if (in_loop) return;
 #pragma unroll
         for (int i = 0; i < NA; ++i) ga[set][i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
 #pragma unroll
@@ -172,7 +181,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
     };
     const int st_a = (lq >> 1) * C::SUBA + lrow * 16 + (lq & 1) * 8;
     const int st_b = 2 * C::PLA + (lq & 1) * C::PLB + (lq >> 1) * C::SUBB + lrow * 16;
-    auto sstore_a = [&](int set, int i, int stage) {
+    auto sstore_a = [&](int set, int i, int stage, bool in_loop = true) {
+        if constexpr ((DBG & 2) != 0)
+            if (in_loop) return;
         f32x4 v = ga[set][i];
         float s = st_sraw[set];
         if constexpr (LN) {
@@ -193,12 +204,16 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
         }
         v *= s;  // exact (power of two)
         const f16x4 h = __builtin_convertvector(v, f16x4);                                // round to nearest
-        const f16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);  // exact difference
+        f16x4 l = h;
+        if constexpr ((DBG & 1) == 0)
+            l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), f16x4);  // exact difference
         char *base = smem_c + stage * C::STAGE + st_a + i * RPP * 16;
         *reinterpret_cast<u32x2 *>(base) = __builtin_bit_cast(u32x2, h);
         *reinterpret_cast<u32x2 *>(base + C::PLA) = __builtin_bit_cast(u32x2, l);
     };
-    auto sstore_w = [&](int set, int i, int stage) {
+    auto sstore_w = [&](int set, int i, int stage, bool in_loop = true) {
+        if constexpr ((DBG & 2) != 0)
+            if (in_loop) return;
         *reinterpret_cast<u32x4 *>(smem_c + stage * C::STAGE + st_b + i * RPP * 16) = gw[set][i];
     };
 
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) sstore_w(PAR ^ 1, i, PAR ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();
+        if constexpr ((DBG & 8) == 0) lds_barrier();
         mfma_group(fay, 0);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) lda(fax, PAR ^ 1, 0, mi);
@@ -266,13 +281,13 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
     using P1 = std::integral_constant<int, 1>;
 
     set_ptrs(0);
-    gload(0, 0);
-    gload(1, SBK);
+    gload(0, 0, false);
+    gload(1, SBK, false);
     if constexpr (LN) __syncthreads();
 #pragma unroll
-    for (int i = 0; i < NA; ++i) sstore_a(0, i, 0);
+    for (int i = 0; i < NA; ++i) sstore_a(0, i, 0, false);
 #pragma unroll
-    for (int i = 0; i < NB; ++i) sstore_w(0, i, 0);
+    for (int i = 0; i < NB; ++i) sstore_w(0, i, 0, false);
     lds_barrier();
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) lda(fax, 0, 0, mi);
@@ -331,11 +346,13 @@ __global__ __launch_bounds__(256) void h2_pack_weight_kernel(const float *__rest
     }
 }
 
-template <int FLAGS, typename C, bool LN>
+int g_h2_dbg = 0;  // "h2_dbg": ablation build of the plain 256x256 kernel (measurement only)
+
+template <int FLAGS, typename C, bool LN, int DBG = 0>
 static int launch_h2_cfg(H2Params hp, int n_cu, hipStream_t stream) {
     GemmParams &p = hp.g;
     const int lds = 2 * C::STAGE + (LN ? C::LN_TAB : 0);
-    OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_h2_kernel<FLAGS, C, LN>),
+    OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_h2_kernel<FLAGS, C, LN, DBG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
     const int nbn = (p.N + C::TN - 1) / C::TN;
@@ -350,7 +367,7 @@ static int launch_h2_cfg(H2Params hp, int n_cu, hipStream_t stream) {
     if (wg_per_cu < 1) wg_per_cu = 1;
     const int64_t cap = (int64_t)n_cu * wg_per_cu;
     const int grid = (int)(nt < cap ? nt : cap);
-    hipLaunchKernelGGL((gemm_h2_kernel<FLAGS, C, LN>), dim3(grid), dim3(C::NT), lds, stream, hp);
+    hipLaunchKernelGGL((gemm_h2_kernel<FLAGS, C, LN, DBG>), dim3(grid), dim3(C::NT), lds, stream, hp);
     OT_LAUNCH_CHECK("gemm_h2");
     return OMNITOK_OK;
 }
@@ -370,12 +387,29 @@ static int launch_h2(H2Params hp, hipStream_t stream) {
     }
     // a tile must lie inside one clip (one A scale per tile)
     const int64_t rpc = (hp.a_bound_dev && hp.a_rpc > 0) ? hp.a_rpc : 256;
-    if (t == 1 && rpc % 256) t = 3;
+    if ((t == 1 || t == 5) && rpc % 256) t = 3;
+    if (t == 6 && rpc % 128) t = 4;
     if (t == 3 && rpc % 128) t = 4;
     constexpr bool GEGLU = (FLAGS & OMNITOK_GEMM_GEGLU) != 0;
+    if constexpr (FLAGS == 0 && !LN) {
+        if (t == 1 && g_h2_dbg) {
+            using C1 = H2Cfg<2, 4, 4, 2>;
+            switch (g_h2_dbg) {
+                case 1: return launch_h2_cfg<0, C1, false, 1>(hp, n_cu, stream);
+                case 2: return launch_h2_cfg<0, C1, false, 2>(hp, n_cu, stream);
+                case 4: return launch_h2_cfg<0, C1, false, 4>(hp, n_cu, stream);
+                case 6: return launch_h2_cfg<0, C1, false, 6>(hp, n_cu, stream);
+                case 8: return launch_h2_cfg<0, C1, false, 8>(hp, n_cu, stream);
+                case 14: return launch_h2_cfg<0, C1, false, 14>(hp, n_cu, stream);
+                default: break;
+            }
+        }
+    }
     switch (t) {
         case 1: return launch_h2_cfg<FLAGS, H2Cfg<2, 4, 4, 2>, LN>(hp, n_cu, stream);
         case 3: return launch_h2_cfg<FLAGS, H2Cfg<2, 2, 2, 2>, LN>(hp, n_cu, stream);
+        case 5: return launch_h2_cfg<FLAGS, H2Cfg<2, 2, 4, 2>, LN>(hp, n_cu, stream);  // 256x128, 2 WGs per CU
+        case 6: return launch_h2_cfg<FLAGS, H2Cfg<2, 2, 2, 4>, LN>(hp, n_cu, stream);  // 128x256, 2 WGs per CU
         default:
             if constexpr (GEGLU) return launch_h2_cfg<FLAGS, H2Cfg<2, 2, 1, 2>, LN>(hp, n_cu, stream);
             else return launch_h2_cfg<FLAGS, H2Cfg<2, 2, 1, 1>, LN>(hp, n_cu, stream);
@@ -423,7 +457,7 @@ extern "C" int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes
     p.lda = lda; p.ldw = K; p.ldr = ldr; p.ldc = ldc;
     p.M = M; p.N = N; p.K = K;
     p.a_rpg = a_rows_per_group; p.a_stride = a_group_stride; p.a_off = a_group_offset;
-    p.gn = 8;
+    p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
     p.trace = nullptr;
     hp.wpl = w_planes; hp.wscale = w_scale; hp.a_bound = a_bound; hp.a_bound_dev = a_bound_dev;
     hp.a_bound_stride = a_bound_stride > 0 ? a_bound_stride : 1; hp.a_rpc = a_rows_per_clip;

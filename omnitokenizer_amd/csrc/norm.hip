@@ -64,25 +64,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 // statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
 // A operand (gemm_x3.hip / gemm_h2.hip), so LN(x) is never written to HBM.
-// bounds (optional, [n_clips][2] floats that the caller zeroed; clip of row m = m / rows_per_clip, one clip
+// bounds (optional, [n_clips][OMNITOK_RANGE_SUBSLOTS][2] floats that the caller zeroed; clip of row m = m / rows_per_clip, one clip
 // if rows_per_clip <= 0): atomic max over the rows of each clip of
 //   [0] |mean| + sqrt(dim) / rstd   >= max_k |x_k|      (|x_k - mean| <= sqrt(dim * var))
 //   [1] sqrt(dim * (mean^2 + 1 / rstd^2)) >= ||x||_2
 // -- the range information the fp16-split GEMM needs for operands derived from x (gemm_h2.hip).  Per
 // clip, so that a clip's results never depend on what else is in the batch.
-// 16 rows per workgroup (4 per wave): one atomic pair per workgroup when its rows share a clip.
-__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim, float eps,
-                                                        float *__restrict__ stats, float *__restrict__ bounds,
-                                                        int64_t rows_per_clip) {
+// One row per wave, RW rows per workgroup: one atomic pair per workgroup when its rows share a clip, spread
+// over OMNITOK_RANGE_SUBSLOTS sub-slots per clip (atomics on one address serialise at ~3 ns each; the
+// consumer takes the max over the sub-slots).
+// max-merge that skips the atomic when the slot already holds a value >= v (the L2-side read can only be
+// stale-low, which costs an unnecessary atomic, never a wrong result)
+__device__ __forceinline__ void range_max(unsigned *slot, float v) {
+    const unsigned u = __float_as_uint(v);
+    if (u > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, u);
+}
+
+template <int RW>
+__global__ __launch_bounds__(64 * RW) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim,
+                                                            float eps, float *__restrict__ stats,
+                                                            float *__restrict__ bounds, int64_t rows_per_clip) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int64_t row0 = (int64_t)blockIdx.x * RW;
+    const int64_t row = row0 + wave;
     const int nv = (dim / 4 + 63) / 64;
     float b0 = 0.0f, b1 = 0.0f;
-    const bool one_clip = rows_per_clip <= 0 || (row0 / rows_per_clip == (row0 + 15) / rows_per_clip);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int64_t row = row0 + wave * 4 + j;
-        if (row >= rows) break;
+    const bool one_clip = rows_per_clip <= 0 || (row0 / rows_per_clip == (row0 + RW - 1) / rows_per_clip);
+    if (row < rows) {
         const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
         f32x4 v[LN_MAX_V4];
 #pragma unroll
@@ -92,28 +100,31 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict_
         row_stats(v, nv, lane, dim, eps, mean, rstd);
         if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
         const float sd = 1.0f / rstd;
-        const float r0 = fabsf(mean) + sqrtf((float)dim) * sd;
-        const float r1 = sqrtf((float)dim * (mean * mean + sd * sd));
-        if (bounds && !one_clip && lane == 0 && r0 == r0 && r1 == r1) {
-            unsigned *bc = reinterpret_cast<unsigned *>(bounds) + 2 * (row / rows_per_clip);
-            atomicMax(bc, __float_as_uint(r0));  // non-negative floats order like their bit patterns
-            atomicMax(bc + 1, __float_as_uint(r1));
+        b0 = fabsf(mean) + sqrtf((float)dim) * sd;
+        b1 = sqrtf((float)dim * (mean * mean + sd * sd));
+        if (b0 != b0) b0 = 0.0f;  // NaN rows leave the range alone
+        if (b1 != b1) b1 = 0.0f;
+        if (bounds && !one_clip && lane == 0) {
+            unsigned *bc = reinterpret_cast<unsigned *>(bounds) +
+                           2 * ((row / rows_per_clip) * OMNITOK_RANGE_SUBSLOTS + (row % OMNITOK_RANGE_SUBSLOTS));
+            range_max(bc, b0);  // non-negative floats order like their bit patterns
+            range_max(bc + 1, b1);
         }
-        b0 = fmaxf(b0, r0 == r0 ? r0 : 0.0f);
-        b1 = fmaxf(b1, r1 == r1 ? r1 : 0.0f);
     }
     if (bounds && one_clip) {
-        __shared__ float sh[2][4];
+        __shared__ float sh[2][RW];
         if (lane == 0) {
             sh[0][wave] = b0;
             sh[1][wave] = b1;
         }
         __syncthreads();
         if (threadIdx.x < 2 && row0 < rows) {
-            const float m = fmaxf(fmaxf(sh[threadIdx.x][0], sh[threadIdx.x][1]),
-                                  fmaxf(sh[threadIdx.x][2], sh[threadIdx.x][3]));
+            float m = 0.0f;
+#pragma unroll
+            for (int i = 0; i < RW; ++i) m = fmaxf(m, sh[threadIdx.x][i]);
             const int64_t clip = rows_per_clip > 0 ? row0 / rows_per_clip : 0;
-            atomicMax(reinterpret_cast<unsigned *>(bounds) + 2 * clip + threadIdx.x, __float_as_uint(m));
+            const int sub = (int)(blockIdx.x % OMNITOK_RANGE_SUBSLOTS);
+            range_max(reinterpret_cast<unsigned *>(bounds) + 2 * (clip * OMNITOK_RANGE_SUBSLOTS + sub) + threadIdx.x, m);
         }
     }
 }
@@ -263,8 +274,9 @@ extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float ep
     OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4, "row_stats: dim=%d unsupported", dim);
     OT_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "row_stats: alignment");
     if (rows == 0) return OMNITOK_OK;
-    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, stream, x, rows, dim, eps,
-                       stats, bounds, rows_per_clip);
+    constexpr int RW = 8;
+    hipLaunchKernelGGL(row_stats_kernel<RW>, dim3((unsigned)((rows + RW - 1) / RW)), dim3(64 * RW), 0, stream, x, rows,
+                       dim, eps, stats, bounds, rows_per_clip);
     OT_LAUNCH_CHECK("row_stats");
     return OMNITOK_OK;
 }

@@ -18,11 +18,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--clips", type=int, default=32)
+    ap.add_argument("--tiles", default="1")
+    ap.add_argument("--skip-check", action="store_true")
     a = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
     r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
     print("== correctness vs fp64 (max abs err) ==")
-    for tile in (1, 3, 4):
+    for tile in (() if a.skip_check else (1, 3, 4)):
         _lib.set_option("h2_tile", tile)
         for (M, N, K, amp) in ((1000, 512, 512, 1.0), (4096, 1024, 512, 1.0), (777, 512, 1408, 1.0), (2048, 192, 512, 1.0),
                                (300, 64, 32, 1.0), (2000, 512, 512, 1e4), (2000, 512, 512, 1e-5)):
@@ -104,8 +106,11 @@ def main():
     for name, (fx3, fh2, flops) in shapes.items():
         ms = timeit(fx3, a.iters)
         line = f"{name:9s} x3 {ms:.3f} ms {flops / ms / 1e9:.0f} TF |"
-        ms = timeit(fh2, a.iters)
-        line += f" h2 {ms:.3f} ms {flops / ms / 1e9:.0f} TF |"
+        for t in [int(v) for v in a.tiles.split(",")]:
+            _lib.set_option("h2_tile", t)
+            ms = timeit(fh2, a.iters)
+            line += f" h2[t{t}] {ms:.3f} ms {flops / ms / 1e9:.0f} TF |"
+        _lib.set_option("h2_tile", 0)
         print(line, flush=True)
 
 

@@ -15,6 +15,7 @@ from tools.x3_bench import timeit  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--pmc", action="store_true", help="just run the kernels a few times (under rocprofv3 --pmc)")
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--kind", default="x3", choices=["x3", "h2"])
 a = ap.parse_args()
 g = torch.Generator(device="cuda").manual_seed(0)
 r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
@@ -24,6 +25,19 @@ wkv = r(2 * D, D) * 0.04
 h = r(L, 1408)
 wfo = r(D, 1408) * 0.04
 _lib.set_option("x3_tile", 1)
+_lib.set_option("h2_tile", 1)
+if a.kind == "h2":
+    pkv, pfo = ops.h2_pack_weight(wkv), ops.h2_pack_weight(wfo)
+    names = {0: "full", 1: "no lo-plane arithmetic", 2: "no LDS stores (and no split)", 4: "no global loads",
+             6: "no stores + no loads", 8: "no barrier", 14: "MFMA + fragment reads only"}
+    for dbg, nm in names.items():
+        _lib.set_option("h2_dbg", dbg)
+        ms1 = timeit(lambda: ops.linear_h2(x, pkv, 8.0), a.iters)
+        ms2 = timeit(lambda: ops.linear_h2(h, pfo, 8.0), a.iters)
+        print(f"h2 dbg {dbg:2d} {nm:32s} kv(N1024,K512) {ms1:.3f} ms {2.0 * L * D * 2 * D / ms1 / 1e9:.0f} TF | "
+              f"N512,K1408 {ms2:.3f} ms {2.0 * L * D * 1408 / ms2 / 1e9:.0f} TF", flush=True)
+    _lib.set_option("h2_dbg", 0)
+    sys.exit(0)
 if a.pmc:
     for _ in range(3):
         ops.linear_x3(x, wkv)
