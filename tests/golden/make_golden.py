@@ -50,6 +50,16 @@ CASES = [
 ]
 
 
+# the headline configuration itself (BASELINE C3 / C1 shapes at full length): one 17-frame 256x256 clip each
+FULL_CASES = [
+    ("s2_sdpa_r256_vid17", 2, "sdpa", dict(resolution=256), 1, 17, 8),
+    ("s1_legacy_r256_vid17", 1, "legacy", dict(resolution=256), 1, 17, 8),
+]
+# ... and four clips (first, two interior, last) of the 32 DISTINCT clips bench.py feeds at C3
+# (synth.synth_video(32, 17, 256, seed=1234)): the reference is run on each of them alone
+B32_CLIPS = (0, 11, 20, 31)
+
+
 # config coverage beyond the released checkpoints (SURVEY.md 8(a) rows a4', a18 and the deferred
 # pools / gen_upscale of omnitokenizer.py:792-804, 957-959); same fixture format as CASES
 VARIANT_CASES = [
@@ -329,9 +339,38 @@ def make_gpt_golden():
         print(f"{name}: logits {tuple(logits.shape)} absmax {logits.abs().max().item():.2f} greedy {greedy[0, :6].tolist()}")
 
 
+def run_b32_case(name="s2_sdpa_r256_vid17_b32", stride=8):
+    args = make_args(2, resolution=256)
+    cfg = OmniTokConfig.from_args(args, attention_mode="sdpa")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = rh.build_reference_model(args)
+    msg = model.load_state_dict(sd, strict=False)
+    assert not msg.unexpected_keys, msg.unexpected_keys
+    x = synth.synth_video(32, 17, 256, seed=1234)
+    ids_l, z_l, rec_l = [], [], []
+    with torch.no_grad(), rh.attention_mode("sdpa"):
+        for b in B32_CLIPS:
+            xb = x[b:b + 1].contiguous()
+            ids = model.encode(xb, False)
+            h = model.pre_vq_conv(model.encoder(xb, False))
+            z_l.append(torch.nn.functional.normalize(h, p=2, dim=1).permute(0, 2, 3, 4, 1).contiguous())
+            ids_l.append(ids)
+            rec_l.append(model.decode(ids, False)[..., ::stride, ::stride].contiguous())
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), clips=np.array(B32_CLIPS), batch=32, frames=17, stride=stride,
+        weight_seed=0, input_seed=1234, state_crc=np.uint32(synth.state_checksum(sd)),
+        input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
+        ids=torch.cat(ids_l).numpy().astype(np.int16), z=torch.cat(z_l).numpy(), recon=torch.cat(rec_l).numpy())
+    print(f"{name}: clips {B32_CLIPS} ids {tuple(torch.cat(ids_l).shape)}")
+
+
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "full"):
+        for c in FULL_CASES:
+            run_case(*c)
+        run_b32_case()
     if only in (None, "vq"):
         make_vq_kat()
     if only in (None, "e2e"):

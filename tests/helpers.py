@@ -16,6 +16,9 @@ E2E_CASES = ["s2_sdpa_r64_img", "s2_sdpa_r64_vid", "s2_sdpa_r64_vid9", "s1_legac
              "s1_legacy_r64_vid", "s1_sdpa_r64_img", "s2_sdpa_r128_vid_16k", "s2_sdpa_r256_img",
              "s2_sdpa_r256_vid", "s1_legacy_r256_img"]
 SMALL_CASES = [c for c in E2E_CASES if "r64" in c]
+# the headline configuration at full length: one 17-frame 256x256 clip of the stage-2 (C3) and of the
+# stage-1 / legacy-attention (C1-style) architectures
+FULL_CASES = ["s2_sdpa_r256_vid17", "s1_legacy_r256_vid17"]
 
 
 VARIANT_CASES = ["var_pool_a_r128_vid", "var_pool_m_r128_img", "var_pool_l_r128_vid", "var_cnn_r128_img",

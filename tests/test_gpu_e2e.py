@@ -9,12 +9,14 @@ Parity tiers (SURVEY.md sections 7, 8(c)):
         the reference's by fp32 summation order only; a flip is accepted only if the two candidate
         codes' fp64 distances differ by < 1e-5 relative) -- expected count 0.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import omnitok_oracle as orc
-from tests.helpers import E2E_CASES, EXT_CASES, VAE_CASES, VARIANT_CASES, GoldenCase
+from tests.helpers import E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, VAE_CASES, VARIANT_CASES, GoldenCase
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +55,7 @@ def assert_ids_match_or_near_tie(ids, ids_ref, z_ours, codebook, name):
     return int(bad.numel())
 
 
-@pytest.mark.parametrize("name", E2E_CASES + VARIANT_CASES)
+@pytest.mark.parametrize("name", E2E_CASES + FULL_CASES + VARIANT_CASES)
 def test_encode_decode_vs_reference_golden(models, name):
     c = GoldenCase(name)
     m = models(c)
@@ -227,6 +229,39 @@ def test_full_size_properties(models, is_image, batch):
     # encode -> decode -> encode round trip stays in range and is deterministic
     ids2 = m.encode(rec.contiguous(), is_image)
     assert torch.equal(ids2, m.encode(rec.contiguous(), is_image))
+
+
+def test_c3_batch_of_32_distinct_clips_vs_reference(models):
+    """BASELINE config C3 exactly as bench.py runs it: 32 DISTINCT 17x256x256 clips in one encode / decode;
+    the first, two interior and the last clip are compared with the reference's own outputs on those clips
+    (tests/golden/s2_sdpa_r256_vid17_b32.npz, generated by make_golden.run_b32_case)."""
+    import zlib
+    import numpy as np
+    from omnitokenizer_amd import synth
+    g = np.load(os.path.join(GOLDEN, "s2_sdpa_r256_vid17_b32.npz"))
+    c = GoldenCase("s2_sdpa_r256_vid17")     # same architecture / weights (seed 0)
+    assert int(g["state_crc"]) == synth.state_checksum(c.sd)
+    m = models(c)
+    x = synth.synth_video(32, 17, 256, seed=int(g["input_seed"]))
+    assert zlib.crc32(x.numpy().tobytes()) == int(g["input_crc"]), "synthetic input drifted"
+    clips = [int(v) for v in g["clips"]]
+    ids_ref = torch.from_numpy(g["ids"].astype(np.int64))
+    z_ref, rec_ref, stride = torch.from_numpy(g["z"]), torch.from_numpy(g["recon"]), int(g["stride"])
+    ids, z = m.encode(x.cuda(), False, return_latents=True)
+    assert tuple(ids.shape) == (32, 5, 32, 32)
+    zerr = (z[clips].cpu() - z_ref).abs().max().item()
+    assert zerr < Z_TOL, f"pre-VQ latents of clips {clips} differ from the reference by {zerr:.2e}"
+    flips = assert_ids_match_or_near_tie(ids[clips], ids_ref, z[clips], c.sd["codebook.embeddings"], "c3_b32")
+    # decode the whole batch from ids that carry the reference's ids in the checked slots
+    ids_in = ids.clone()
+    ids_in[clips] = ids_ref.cuda()
+    rec = m.decode(ids_in, False)
+    err = (rec[clips][..., ::stride, ::stride].cpu() - rec_ref).abs().max().item()
+    assert err < PIXEL_TOL, f"decoded pixels of clips {clips} differ from the reference by {err:.2e}"
+    # all 32 clips are distinct and each one's result is independent of the batch
+    assert len({zlib.crc32(ids[b].cpu().numpy().tobytes()) for b in range(32)}) == 32
+    assert torch.equal(m.encode(x[20:21].cuda().contiguous(), False), ids[20:21])
+    print(f"C3 batch of 32 distinct clips: id flips {flips}, z err {zerr:.1e}, pixel err {err:.1e}")
 
 
 def test_c5_long_sequence_stress(models):

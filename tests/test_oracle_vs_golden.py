@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
+from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -28,7 +28,7 @@ def test_vq_torch_oracle_matches_reference_kat(n_codes):
     assert np.array_equal(ids, g["ids"].astype(np.int64))
 
 
-@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"] + VARIANT_CASES)
+@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"] + FULL_CASES + VARIANT_CASES)
 def test_oracle_end_to_end_matches_reference(name):
     c = GoldenCase(name)
     with torch.no_grad():
