@@ -231,8 +231,18 @@ def main():
                 cpu_model = [l.split(":")[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
             except Exception:
                 cpu_model = "unknown"
+            try:   # the port calibrated against the reference itself (build container, same clip / threads)
+                cal = json.load(open(os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json")))
+                ref_over_port = cal["reference_over_port"]
+                cal_src = (f"profiles/cpu_reference_vs_port.json: reference {cal['reference_patches_per_s']} vs port "
+                           f"{cal['port_patches_per_s']} patches/s on {cal['threads']} threads of {cal['cpu']}, "
+                           f"ids equal, pixel diff {cal['pixel_max_abs_diff']}")
+            except Exception:
+                ref_over_port, cal_src = None, None
             out["cpu_baseline"] = {"value": round(tokens_per_clip / per, 1), "unit": "patches/s", "cores": ncpu_used,
-                                   "kind": "port", "host_logical_cpus": ncpu, "cpu": cpu_model,
+                                   "kind": "port", "reference_over_port": ref_over_port,
+                                   "reference_over_port_source": cal_src,
+                                   "host_logical_cpus": ncpu, "cpu": cpu_model,
                                    "sample": f"1 clip {a.frames}x{a.resolution}x{a.resolution} encode+decode, "
                                              f"{reps} timed reps after 1 warm-up, torch CPU fp32 oracle "
                                              f"(ATen/MKL, {ncpu_used} threads = best of a 8..128 probe)"}
