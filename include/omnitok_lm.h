@@ -53,6 +53,11 @@ int64_t omnitok_lm_cache_bytes(omnitok_lm *lm);
 int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
                     float *logits_out, int advance, omnitok_stream_t stream);
 
+/* 1 if a decode step since the last call found cache_len[b] >= max_len (a stream stepped past the cache that
+ * omnitok_lm_alloc_cache sized; the step then stays inside the stream's own K/V slab and its logits are
+ * invalid), 0 otherwise; clears the flag.  Synchronises the stream (call it once after a sampling loop). */
+int omnitok_lm_overflowed(omnitok_lm *lm, omnitok_stream_t stream);
+
 /* Batched prefill of a conditioning prefix into EMPTY streams (GPT.forward / the first
  * forward_with_past call of the reference, gpt.py:207-275, positions 0..T-1): idx[B, T] int64.
  * Same arithmetic as T decode steps, executed as [B*T]-row fp32-MFMA GEMMs (omnitok_gemm) + causal

@@ -92,6 +92,7 @@ _PROTOS = {
     "omnitok_lm_finalize": [P, P],
     "omnitok_lm_alloc_cache": [P, c_int, c_int],
     "omnitok_lm_cache_bytes": [P],
+    "omnitok_lm_overflowed": [P, P],
     "omnitok_lm_step": [P, P, P, P, c_int, P, c_int, P],
     "omnitok_lm_prefill": [P, P, P, P, c_int, c_int, P, P],
     "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],

@@ -393,14 +393,8 @@ extern "C" int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k,
     AttnParams p;
     p.q = q; p.k = k; p.v = v; p.out = out; p.ldq = ldq; p.ldkv = ldkv; p.ldo = ldo; p.N = N; p.heads = heads;
     p.bias_table = bias_table; p.gh = gh; p.gw = gw;
-    static bool attr_set = false;
-    if (!attr_set) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_spatial_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_spatial_kernel<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, AT_LDS_BYTES));
-        attr_set = true;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_kernel<false>), AT_LDS_BYTES)) return rc;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_kernel<true>), AT_LDS_BYTES)) return rc;
     p.nqb = (N + 127) / 128;
     // groups (sequence, head) are dealt to the 8 XCDs round-robin; pad the group count to a multiple
     // of 8 with idle workgroups when heads * Bn is not one

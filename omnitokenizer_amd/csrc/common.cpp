@@ -13,6 +13,42 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace omnitok
 
+#include <map>
+#include <mutex>
+#include <utility>
+
+namespace omnitok {
+static std::mutex g_attr_mu;
+static std::map<std::pair<const void *, int>, int> g_attr_bytes;
+static std::map<int, int> g_dev_cus;
+
+int set_max_dynamic_lds(const void *kernel, int bytes) {
+    int dev = 0;
+    OT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    int &have = g_attr_bytes[std::make_pair(kernel, dev)];
+    if (bytes > have) {
+        OT_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        have = bytes;
+    }
+    return OMNITOK_OK;
+}
+
+int current_device_cus(int *n_cu) {
+    int dev = 0;
+    OT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    auto it = g_dev_cus.find(dev);
+    if (it == g_dev_cus.end()) {
+        int n = 0;
+        OT_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        it = g_dev_cus.emplace(dev, n).first;
+    }
+    *n_cu = it->second;
+    return OMNITOK_OK;
+}
+}  // namespace omnitok
+
 namespace omnitok {
 extern int g_gemm_variant;
 extern int g_gemm_lds_pad_kb;

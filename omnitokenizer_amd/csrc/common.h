@@ -38,6 +38,12 @@ void set_error(const char *fmt, ...);
         }                                                                                \
     } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) cached per (kernel, device) under a mutex: the attribute
+// is per device, so a process-wide flag would leave a second GPU (or a racing second host thread) without it.
+int set_max_dynamic_lds(const void *kernel, int bytes);
+// multiprocessor count of the current device (cached per device)
+int current_device_cus(int *n_cu);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

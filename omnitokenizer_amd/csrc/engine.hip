@@ -1299,6 +1299,10 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     if (int rc = reset_bounds(e, B, stream)) return rc;
     const int K0 = C * p * p, K1 = K0 * pt;
 
+    if (kind == LatentKind::Ids) {
+        // the out-of-range flag reports on THIS decode only (omnitok_engine_check_ids)
+        OT_HIP(hipMemsetAsync(e->err_flag, 0, sizeof(int), stream));
+    }
     if (kind == LatentKind::Ids)
         OT_RUN("dequant_post_vq", (double)L0 * D * 4.0,
                omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, k_embed(c)), c.n_codes, 8,

@@ -248,12 +248,7 @@ template <int FLAGS, int NB>
 static int launch_small(const GemmParams &p, hipStream_t stream) {
     constexpr int SBN = 64 * NB;
     constexpr int lds = 2 * (SM_BM + SBN) * LDT * 4;
-    static int attr = 0;
-    if (!attr) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_small<FLAGS, NB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = 1;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_f32_mfma_small<FLAGS, NB>), lds)) return rc;
     const int64_t nwg = ((p.M + SM_BM - 1) / SM_BM) * ((p.N + SBN - 1) / SBN);
     hipLaunchKernelGGL((gemm_f32_mfma_small<FLAGS, NB>), dim3((unsigned)nwg), dim3(256), lds, stream, p);
     OT_LAUNCH_CHECK("gemm_f32_mfma_small");
@@ -453,17 +448,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_f32_mfma_persistent(GemmPara
 
 template <int FLAGS, int WM>
 static int launch_persistent(GemmParams p, int n_cu, hipStream_t stream) {
-    static int attr = 0;
     constexpr int TM = 64 * WM;
     const int lds = 2 * (TM + BN) * LDT * 4 + (WM == 2 ? g_gemm_lds_pad_kb * 1024 : 0);
-    if (attr < lds) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<FLAGS, WM, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if constexpr (FLAGS == 0)
-            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<0, WM, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = lds;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<FLAGS, WM, false>), lds))
+        return rc;
+    if constexpr (FLAGS == 0)
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_f32_mfma_persistent<0, WM, true>), lds))
+            return rc;
     p.nbm = (int)((p.M + TM - 1) / TM);
     const int64_t ntiles = (int64_t)p.nbm * p.nbn;
     OT_CHECK_ARG(ntiles < (1ll << 31), "gemm grid too large");
@@ -482,13 +473,8 @@ static int launch_persistent(GemmParams p, int n_cu, hipStream_t stream) {
 
 template <int FLAGS>
 static int launch_gemm(GemmParams p, hipStream_t stream) {
-    static int attr_bytes = 0;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        OT_HIP(hipGetDevice(&dev));
-        OT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    int n_cu = 0;
+    if (int rc = current_device_cus(&n_cu)) return rc;
     const int64_t nbm = (p.M + BM - 1) / BM;
     const int64_t nwg = nbm * p.nbn;
     OT_CHECK_ARG(nwg < (1ll << 31), "gemm grid too large");
@@ -520,14 +506,9 @@ static int launch_gemm(GemmParams p, hipStream_t stream) {
     }
     const int lds = GEMM_LDS_BYTES + g_gemm_lds_pad_kb * 1024;
     const bool nedge = (p.N % 64) != 0;
-    if (attr_bytes < lds) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU))
-            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_bytes = lds;
-    }
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, false>), lds)) return rc;
+    if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU))
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_f32_mfma<FLAGS, true>), lds)) return rc;
     if constexpr (!(FLAGS & OMNITOK_GEMM_GEGLU)) {
         if (nedge) {
             hipLaunchKernelGGL((gemm_f32_mfma<FLAGS, true>), dim3((unsigned)nwg), dim3(256), lds, stream, p);

@@ -352,8 +352,7 @@ template <int FLAGS, typename C, bool LN, int DBG = 0>
 static int launch_h2_cfg(H2Params hp, int n_cu, hipStream_t stream) {
     GemmParams &p = hp.g;
     const int lds = 2 * C::STAGE + (LN ? C::LN_TAB : 0);
-    OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_h2_kernel<FLAGS, C, LN, DBG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_h2_kernel<FLAGS, C, LN, DBG>), lds)) return rc;
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
     const int nbn = (p.N + C::TN - 1) / C::TN;
     const int64_t nt = nbm * nbn;
@@ -374,9 +373,8 @@ static int launch_h2_cfg(H2Params hp, int n_cu, hipStream_t stream) {
 
 template <int FLAGS, bool LN>
 static int launch_h2(H2Params hp, hipStream_t stream) {
-    int dev = 0, n_cu = 0;
-    OT_HIP(hipGetDevice(&dev));
-    OT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    int n_cu = 0;
+    if (int rc = current_device_cus(&n_cu)) return rc;
     const GemmParams &p = hp.g;
     auto tiles = [&](int tm, int tn) { return ((p.M + tm - 1) / tm) * (int64_t)((p.N + tn - 1) / tn); };
     int t = g_h2_tile;

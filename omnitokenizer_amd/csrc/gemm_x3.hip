@@ -368,9 +368,7 @@ template <int FLAGS, typename C, bool LN, int DBG = 0>
 static int launch_x3_cfg(X3Params xp, int n_cu, hipStream_t stream) {
     GemmParams &p = xp.g;
     const int lds = 2 * C::STAGE + (LN ? C::LN_TAB : 0);
-    // (the attribute is per device and cheap to set: no process-wide cache)
-    OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_x3_kernel<FLAGS, C, LN, DBG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_x3_kernel<FLAGS, C, LN, DBG>), lds)) return rc;
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
     const int nbn = (p.N + C::TN - 1) / C::TN;
     const int64_t nt = nbm * nbn;
@@ -391,9 +389,8 @@ static int launch_x3_cfg(X3Params xp, int n_cu, hipStream_t stream) {
 
 template <int FLAGS, bool LN>
 static int launch_x3(X3Params xp, hipStream_t stream) {
-    int dev = 0, n_cu = 0;
-    OT_HIP(hipGetDevice(&dev));
-    OT_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    int n_cu = 0;
+    if (int rc = current_device_cus(&n_cu)) return rc;
     const GemmParams &p = xp.g;
     // tile choice by how many tiles the problem offers per CU (every tile shape performs the same
     // per-element arithmetic, so the choice never changes a result)

@@ -229,14 +229,21 @@ template <int F4>
 __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
                                                              const int32_t *__restrict__ cache_len, int n_head,
                                                              int max_len, int prefill_T,
-                                                             float *__restrict__ part, int nchunk) {
+                                                             float *__restrict__ part, int nchunk,
+                                                             int *__restrict__ err_flag) {
     constexpr int HD = F4 * 32;
     // decode: one query row per stream (row == b), len = cache_len[b].  prefill (prefill_T > 0): row =
     // b * T + t is query position t of stream b; its keys 0..t-1 are already in the cache (scattered by
     // lm_kv_scatter_kernel), key t is the row's own K/V
     const int c = blockIdx.x, h = blockIdx.y, row = blockIdx.z;
     const int b = prefill_T > 0 ? row / prefill_T : row;
-    const int len = prefill_T > 0 ? row - b * prefill_T : cache_len[row];
+    int len = prefill_T > 0 ? row - b * prefill_T : cache_len[row];
+    if (len >= max_len) {
+        // a caller stepped past the cache it allocated: flag it (omnitok_lm_overflowed) and stay inside
+        // this head's K/V slab instead of reading the neighbour's rows
+        if (err_flag && threadIdx.x == 0) *err_flag = 1;
+        len = max_len - 1;
+    }
     const int total = len + 1;
     if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
     const int C = n_head * HD;
@@ -454,12 +461,7 @@ static void launch_gemv_cfg(const float *x, const float *w, const float *bias, c
     const int kp = K < LM_KP ? K : LM_KP;
     const int lds = (BQ * kp + (XM ? BQ * mg.n_head * mg.nchunk : 0)) * 4;
     const int rows_per_wg = 4 * ROWS;
-    static int attr = 65536;  // per instantiation
-    if (lds > attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr = lds;
-    }
+    if (lds > 65536) (void)set_max_dynamic_lds(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), lds);
     hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256),
                        lds, stream, x, w, bias, residual, g, beta, y, N, K, mg);
 }
@@ -539,7 +541,8 @@ extern "C" int omnitok_lm_gemv(const float *x, const float *w, const float *bias
 // chunk partials only (the engine merges them inside the proj GEMV)
 // prefill_T > 0: B * prefill_T query rows (row = b * T + t, keys 0..t), chunks sized for T keys
 static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B, int n_head,
-                            int head_dim, int max_len, float *scratch, hipStream_t stream, int prefill_T = 0) {
+                            int head_dim, int max_len, float *scratch, hipStream_t stream, int prefill_T = 0,
+                            int *err_flag = nullptr) {
     OT_CHECK_ARG(qkv && kc && vc && (cache_len || prefill_T > 0) && scratch, "lm_attn_decode: null pointer");
     OT_CHECK_ARG(head_dim == 64 || head_dim == 96 || head_dim == 128, "lm_attn_decode: head_dim %d (64 | 96 | 128)",
                  head_dim);
@@ -551,15 +554,15 @@ static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_
     switch (head_dim) {
         case 64:
             hipLaunchKernelGGL(lm_attn_decode_kernel<2>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk, err_flag);
             break;
         case 96:
             hipLaunchKernelGGL(lm_attn_decode_kernel<3>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk, err_flag);
             break;
         default:
             hipLaunchKernelGGL(lm_attn_decode_kernel<4>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk);
+                               max_len, prefill_T, scratch, nchunk, err_flag);
             break;
     }
     OT_LAUNCH_CHECK("lm_attn_decode");
@@ -599,6 +602,7 @@ struct omnitok_lm {
     // cache + workspaces
     float *kv = nullptr;
     int max_batch = 0, max_len = 0;
+    int *err_flag = nullptr;  // set by the attention kernel when a stream steps past max_len
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *part = nullptr;
     int64_t cache_bytes = 0;
     // grow-only prefill workspace (rows = B * T)
@@ -664,6 +668,7 @@ extern "C" void omnitok_lm_destroy(omnitok_lm *lm) {
         if (kv.second) (void)hipFree(kv.second);
     for (void *p : lm->owned) (void)hipFree(p);
     lm_free_cache(lm);
+    if (lm->err_flag) (void)hipFree(lm->err_flag);
     delete lm;
 }
 
@@ -773,7 +778,22 @@ extern "C" int omnitok_lm_alloc_cache(omnitok_lm *lm, int max_batch, int max_len
     lm->max_batch = max_batch;
     lm->max_len = max_len;
     lm->cache_bytes = per_layer * 2 * c.n_layer * 4;
+    if (!lm->err_flag) {
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&lm->err_flag), sizeof(int)));
+        OT_HIP(hipMemset(lm->err_flag, 0, sizeof(int)));
+    }
     return OMNITOK_OK;
+}
+
+extern "C" int omnitok_lm_overflowed(omnitok_lm *lm, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(lm, "lm_overflowed: null engine");
+    if (!lm->err_flag) return 0;
+    int h = 0;
+    OT_HIP(hipMemcpyAsync(&h, lm->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    OT_HIP(hipStreamSynchronize(stream));
+    if (h) OT_HIP(hipMemsetAsync(lm->err_flag, 0, sizeof(int), stream));
+    return h ? 1 : 0;
 }
 
 extern "C" int64_t omnitok_lm_cache_bytes(omnitok_lm *lm) { return lm ? lm->cache_bytes : 0; }
@@ -804,7 +824,8 @@ extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos,
         // x + proj(attn(ln1(x)))   (reference gpt.py:159-161)
         if (int rc = omnitok_lm_gemv(lm->x, L.wqkv, L.bqkv, nullptr, L.ln1w, L.ln1b, lm->qkv, B, 3 * C, C, 0, stream))
             return rc;
-        if (int rc = lm_attn_partials(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, stream))
+        if (int rc = lm_attn_partials(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, stream, 0,
+                                      lm->err_flag))
             return rc;
         const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + LM_CHUNK - 1) / LM_CHUNK};
         if (int rc = lm_gemv_any(nullptr, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, &mg, stream))

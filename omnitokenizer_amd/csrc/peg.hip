@@ -198,12 +198,7 @@ extern "C" int omnitok_peg3d(const float *x, const float *w27, const float *bias
     OT_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(w27) && aligned16(bias), "peg3d: unaligned pointer");
     if (B * T * H * W == 0) return OMNITOK_OK;
     if (D % 32 == 0 && g_peg_variant == 1 && B <= 65535 && D / 32 <= 65535) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(peg3d_lds_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, PT_LDS_BYTES));
-            attr_set = true;
-        }
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(peg3d_lds_kernel), PT_LDS_BYTES)) return rc;
         const int wtiles = (W + PT_W - 1) / PT_W, htiles = (H + PT_H - 1) / PT_H;
         hipLaunchKernelGGL(peg3d_lds_kernel, dim3(wtiles * htiles, D / 32, B), dim3(256), PT_LDS_BYTES, stream, x,
                            w27, bias, y, B, T, H, W, D, causal ? 2 : 1);

@@ -435,13 +435,9 @@ static int launch_vq(const float *z, const float *packed, const float *ee, int64
     if (nsplit > ntiles) nsplit = ntiles;
     const int tiles_per = (ntiles + nsplit - 1) / nsplit;
     const int lds = cosine ? 0 : tiles_per * 32 * 4;
-    static int attr_bytes = 0;  // per MODE instantiation
-    if (lds > attr_bytes && lds > 65536) {
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<false, MODE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        OT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vq_argmin_kernel<true, MODE>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_bytes = lds;
+    if (lds > 65536) {
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<false, MODE>), lds)) return rc;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<true, MODE>), lds)) return rc;
     }
     const dim3 grid((unsigned)blocks, nsplit);
     if (nsplit == 1) {

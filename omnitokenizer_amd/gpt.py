@@ -51,8 +51,8 @@ class _PastHandle:
     in the engine's cache; the handle only identifies the stream so that the reference's calling
     pattern (`past.append(present)`, gpt.py:343-346) keeps working."""
 
-    def __init__(self, model, length):
-        self.model, self.length = model, length
+    def __init__(self, model, length, generation):
+        self.model, self.length, self.generation = model, length, generation
 
 
 class GPT(nn.Module):
@@ -118,12 +118,19 @@ class GPT(nn.Module):
             raise NotImplementedError("omnitokenizer_amd GPT is inference-only")
         return super().train(False)
 
-    def load_state_dict(self, state_dict, strict: bool = False, assign: bool = False):
+    def load_state_dict(self, state_dict, strict: Optional[bool] = None, assign: bool = False):
         """Accepts the reference GPT's state_dict; its causal-mask buffers (blocks.N.attn.mask) are
-        not parameters of the path and are dropped."""
+        not parameters of the path and are dropped.  Missing tensors raise unless strict=False is passed
+        explicitly (every parameter is pre-created here: a renamed key would otherwise sample from zeros)."""
         sd = {k: v for k, v in state_dict.items() if not k.endswith(".attn.mask")}
-        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        out = super().load_state_dict(sd, strict=bool(strict), assign=assign)
         self._engine_sig = None
+        if out.missing_keys:
+            msg = f"state_dict lacks {len(out.missing_keys)} tensors of the LM, e.g. {out.missing_keys[:4]}"
+            if strict is None:
+                raise RuntimeError(msg + " (pass strict=False to load anyway)")
+            import warnings
+            warnings.warn(msg)
         return out
 
     def __del__(self):
@@ -187,6 +194,14 @@ class GPT(nn.Module):
         self._ensure_cache(batch, max_len)
         self._pos.zero_()
         self._len.zero_()
+        # handles returned by forward_with_past before this point belong to streams that no longer exist
+        self._generation = getattr(self, "_generation", 0) + 1
+
+    def check_overflow(self):
+        """Raises if a decode step since the last check ran past the allocated K/V cache (its logits are
+        invalid); one host synchronisation -- the sampling loops call it once at their end."""
+        if self._engine and _lib.load().omnitok_lm_overflowed(self._engine, torch.cuda.current_stream().cuda_stream) > 0:
+            raise RuntimeError("a stream stepped past the K/V cache length it was allocated with")
 
     def step(self, idx, logits=None, advance=True, want_logits=True):
         """One decode step: idx [B] int64 (device) enters every stream at pos[b] / cache_len[b].
@@ -287,14 +302,21 @@ class GPT(nn.Module):
             out = torch.zeros(B, T, self.vocab_size, device=self.device) if T > 1 else None
             if out is not None:
                 out[:, -1] = logits  # callers read logits[:, -1, :] (gpt.py:347)
-            return (out if out is not None else logits[:, None]), None, _PastHandle(self, T)
+            return (out if out is not None else logits[:, None]), None, _PastHandle(self, T, self._generation)
         assert past_length is not None
+        for h in past:
+            if not isinstance(h, _PastHandle) or h.model is not self or h.generation != self._generation:
+                raise RuntimeError(
+                    "forward_with_past: `past` belongs to streams that were replaced by a later past=None call "
+                    "(the engine keeps ONE set of K/V streams; two interleaved sequences -- e.g. the reference's "
+                    "sample_with_past_cfg calling the conditional and unconditional pass in turn -- must run as "
+                    "rows of one batch: use omnitokenizer_amd.gpt.sample_with_past_cfg)")
         have = sum(p.length for p in past)
         assert have == past_length, f"{have} =/= {past_length}"
         assert T == 1
         self._pos[:B] = past_length + (1 if forward_uncond else 0)
         logits = self.step(idx[:, 0].contiguous())
-        return logits[:, None], None, _PastHandle(self, 1)
+        return logits[:, None], None, _PastHandle(self, 1, self._generation)
 
 
 def _select(logits, sample_logits, top_k, top_p):

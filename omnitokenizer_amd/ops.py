@@ -40,6 +40,20 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32):
         raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError(f"{name}: tensor must be contiguous")
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{name}: tensor is on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "the kernels launch on the current device's stream -- wrap the call in "
+                           "`with torch.cuda.device(tensor.device):`")
+    return t
+
+
+def _opt(t: Optional[torch.Tensor], name: str, numel: Optional[int] = None, dtype=torch.float32):
+    """Optional operand: validated like a required one when present."""
+    if t is None:
+        return None
+    _req(t, name, dtype)
+    if numel is not None and t.numel() != numel:
+        raise ValueError(f"{name}: expected {numel} elements, got {t.numel()}")
     return t
 
 
@@ -47,6 +61,7 @@ def layernorm(x, gamma, beta=None, eps=1e-5):
     x = _req(x, "x")
     rows, dim = x.numel() // x.shape[-1], x.shape[-1]
     y = torch.empty_like(x)
+    _opt(beta, "beta", dim)
     check(_lib.load().omnitok_layernorm(_p(x), _p(_req(gamma, "gamma")), _p(beta), _p(y), rows, dim, eps,
                                         0, 0, 0, _stream()), "layernorm")
     return y
@@ -60,6 +75,8 @@ def linear(x, weight, bias=None, residual=None, leaky=False):
     M = x.numel() // K
     N = weight.shape[0]
     out = torch.empty(*x.shape[:-1], N, device=x.device, dtype=torch.float32)
+    _opt(bias, "bias", N)
+    _opt(residual, "residual", M * N)
     flags = (GEMM_BIAS if bias is not None else 0) | (GEMM_RESIDUAL if residual is not None else 0) \
         | (GEMM_LEAKY if leaky else 0)
     check(_lib.load().omnitok_gemm(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), N, _p(out), N,
@@ -92,12 +109,8 @@ def linear_x3(x, weight, bias=None, residual=None, geglu=False, ln=None, ln_cols
     N = weight.shape[0]
     ncol = N // 2 if geglu else N
     out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
-    if bias is not None:
-        _req(bias, "bias")
-    if residual is not None:
-        _req(residual, "residual")
-        if residual.numel() != M * ncol:
-            raise ValueError("residual must have the shape of the output")
+    _opt(bias, "bias", ncol)
+    _opt(residual, "residual", M * ncol)
     flags = GEMM_GEGLU if geglu else ((GEMM_BIAS if bias is not None else 0) |
                                       (GEMM_RESIDUAL if residual is not None else 0))
     st = g = b = None
@@ -105,8 +118,7 @@ def linear_x3(x, weight, bias=None, residual=None, geglu=False, ln=None, ln_cols
         st, g, b = ln
         _req(st, "ln stats")
         _req(g, "ln gamma")
-        if b is not None:
-            _req(b, "ln beta")
+        _opt(b, "ln beta", K)
     check(_lib.load().omnitok_gemm_x3(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), ncol, _p(out),
                                       ncol, M, N, K, flags, 0, 0, 0, _p(st), _p(g), _p(b),
                                       int(ln_cols if ln_cols is not None else N), _stream()), "gemm_x3")
@@ -134,15 +146,17 @@ def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound
     N = planes.shape[0]
     ncol = N // 2 if geglu else N
     out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
-    if bias is not None:
-        _req(bias, "bias")
-    if residual is not None:
-        _req(residual, "residual")
+    _opt(bias, "bias", ncol)
+    _opt(residual, "residual", M * ncol)
+    _opt(a_bound_dev, "a_bound_dev")
     flags = GEMM_GEGLU if geglu else ((GEMM_BIAS if bias is not None else 0) |
                                       (GEMM_RESIDUAL if residual is not None else 0))
     st = g = b = None
     if ln is not None:
         st, g, b = ln
+        _req(st, "ln stats")
+        _req(g, "ln gamma")
+        _opt(b, "ln beta", K)
     check(_lib.load().omnitok_gemm_h2(_p(x), K, _p(planes), _p(scale), _p(bias), _p(residual), ncol, _p(out), ncol,
                                       M, N, K, flags, 0, 0, 0, float(a_bound), _p(a_bound_dev), int(a_bound_stride),
                                       int(rows_per_clip), _p(st), _p(g), _p(b),

@@ -45,6 +45,23 @@ def _attach(root: nn.Module, dotted: str, tensor: torch.Tensor):
         mod.register_buffer(parts[-1], tensor)
 
 
+def _on_own_device(fn):
+    """Runs a method with the module's GPU as the current device: the native calls allocate and launch on
+    the CURRENT device / its current stream, so a model on cuda:1 must not run while cuda:0 is current."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"OmniTokenizer_VQGAN is on {dev}: move it to the GPU (.to('cuda')). The MI355X HIP path is "
+                "the only implementation; there is no CPU fallback.")
+        with torch.cuda.device(dev):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class OmniTokenizer_VQGAN(nn.Module):
     def __init__(self, args, attention_mode: Optional[str] = None):
         """args: the same Namespace the reference takes.  attention_mode: "sdpa" (what the
@@ -89,6 +106,8 @@ class OmniTokenizer_VQGAN(nn.Module):
 
         self._engine = None
         self._engine_sig = None
+        self._engine_dev = None
+        self._version = getattr(self, "_version", 0)
         self._timing = False
 
     # ---- nn.Module plumbing -------------------------------------------------------------------
@@ -101,12 +120,23 @@ class OmniTokenizer_VQGAN(nn.Module):
             raise NotImplementedError("omnitokenizer_amd is inference-only (encode/decode path)")
         return super().train(False)
 
-    def load_state_dict(self, state_dict, strict: bool = False, assign: bool = False):
+    def load_state_dict(self, state_dict, strict: Optional[bool] = None, assign: bool = False):
         """Accepts a reference checkpoint's state_dict.  Off-path entries (discriminators, LPIPS;
-        vqgan_eval.py:62-68 drops or ignores them the same way) are skipped silently."""
+        vqgan_eval.py:62-68 drops or ignores them the same way) are skipped silently.  A tensor the
+        encode/decode path reads that is MISSING from the state_dict raises (every parameter is pre-created
+        here, so a silently missing key -- e.g. a 'module.' prefix -- would encode with placeholder weights);
+        pass strict=False explicitly to get nn.Module's lenient behaviour (a warning is issued)."""
         sd = {k: v for k, v in state_dict.items() if not k.startswith(_OFF_PATH_PREFIXES)}
-        out = super().load_state_dict(sd, strict=strict, assign=assign)
+        out = super().load_state_dict(sd, strict=bool(strict), assign=assign)
         self._engine_sig = None
+        self._version += 1
+        if out.missing_keys:
+            msg = (f"state_dict lacks {len(out.missing_keys)} tensors of the encode/decode path, e.g. "
+                   f"{out.missing_keys[:4]}")
+            if strict is None:
+                raise RuntimeError(msg + " (pass strict=False to load anyway)")
+            import warnings
+            warnings.warn(msg)
         return out
 
     @classmethod
@@ -156,7 +186,22 @@ class OmniTokenizer_VQGAN(nn.Module):
         return nc
 
     def _signature(self):
-        return tuple((t.data_ptr(), t._version) for t in self.state_dict(keep_vars=True).values())
+        """Cheap change detector for the engine's weight copies: a version counter bumped by
+        load_state_dict / _apply (.to(), .cuda(), .float()), plus the storage pointer and in-place version of
+        ONE sentinel tensor per sub-module group.  Walking the whole state_dict on every encode/decode cost
+        more host time than a single-image encode's launches; in-place edits of individual parameters after
+        the first encode need mark_weights_changed()."""
+        sent = (self.encoder.enc_spatial_transformer.norm_out.gamma, self.decoder.dec_spatial_transformer.norm_out.gamma)
+        return (self._version,) + tuple((t.data_ptr(), t._version) for t in sent)
+
+    def mark_weights_changed(self):
+        """Call after editing parameters in place so that the next encode/decode re-uploads them."""
+        self._version += 1
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._version = getattr(self, "_version", 0) + 1
+        return out
 
     def _sync_engine(self):
         """Pushes the parameters into the native engine when they changed (load_state_dict, .to(),
@@ -166,6 +211,9 @@ class OmniTokenizer_VQGAN(nn.Module):
             raise RuntimeError(
                 f"OmniTokenizer_VQGAN is on {dev}: move it to the GPU (.to('cuda')). The MI355X HIP path is "
                 "the only implementation; there is no CPU fallback.")
+        if self._engine is not None and self._engine_dev != dev:
+            raise RuntimeError(f"the native engine was built on {self._engine_dev}; the module now lives on {dev} "
+                               "(build a new OmniTokenizer_VQGAN for another GPU)")
         sig = self._signature()
         if self._engine is not None and sig == self._engine_sig:
             return
@@ -176,6 +224,7 @@ class OmniTokenizer_VQGAN(nn.Module):
             nc = self._native_config()
             check(lib.omnitok_engine_create(ctypes.byref(nc), ctypes.byref(h)), "engine_create")
             self._engine = h
+            self._engine_dev = dev
             lib.omnitok_engine_set_timing(self._engine, int(self._timing))
         for name, t in self.state_dict(keep_vars=True).items():
             t = t.detach()
@@ -191,6 +240,7 @@ class OmniTokenizer_VQGAN(nn.Module):
 
     # ---- the path -------------------------------------------------------------------------------
     @torch.no_grad()
+    @_on_own_device
     def encode(self, x, is_image, include_embeddings=False, return_latents=False, noise=None,
                sample_posterior=True, return_moments=False):
         """reference omnitokenizer.py:247-266.  x: [B,C,H,W] (is_image) or [B,C,F,H,W] fp32 in
@@ -320,7 +370,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         return out[:, :, 0] if is_image else out
 
     @torch.no_grad()
-    def decode(self, encodings, is_image, check_ids: bool = False):
+    @_on_own_device
+    def decode(self, encodings, is_image, check_ids: Optional[bool] = None):
         """reference omnitokenizer.py:268-291 (with --use_external_codebook the reference's decode() raises
         -- it reads codebook.embeddings, which VectorQuantize lacks -- so this computes what its forward()
         computes from the same ids: decoder(project_out(embed[ids]))).  encodings: ids [B,T',h,w], flat video ids
@@ -354,6 +405,10 @@ class OmniTokenizer_VQGAN(nn.Module):
         stream = torch.cuda.current_stream().cuda_stream
         check(lib.omnitok_decode(self._engine, ctypes.c_void_p(ids.data_ptr()), B, T, h, w,
                                  ctypes.c_void_p(out.data_ptr()), stream), "decode")
+        if check_ids is None:
+            # like the reference's F.embedding, out-of-range ids raise; the check is one int read-back (a
+            # host synchronisation), so it is skipped by default only while a HIP graph is being captured
+            check_ids = not torch.cuda.is_current_stream_capturing()
         if check_ids:
             rc = lib.omnitok_engine_check_ids(self._engine, stream)
             if rc == -1:

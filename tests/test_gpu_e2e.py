@@ -139,11 +139,34 @@ def test_error_behaviour(models):
         m.encode(torch.zeros(1, 3, 5, 60, 60, device="cuda"), False)
     with pytest.raises(RuntimeError):  # no CPU fallback
         m.encode(torch.zeros(1, 3, 5, 64, 64), False)
-    with pytest.raises(IndexError):
+    with pytest.raises(IndexError):          # like the reference's F.embedding, by default
         bad = c.ids.clone()
         bad[0, 0, 0, 0] = 9000
-        m.decode(bad.cuda(), False, check_ids=True)
+        m.decode(bad.cuda(), False)
+    m.decode(bad.cuda(), False, check_ids=False)   # opt-out: maps to code 0 without a host read-back
     assert m.encode(torch.zeros(0, 3, 5, 64, 64, device="cuda"), False).shape == (0, 2, 8, 8)
+
+
+def test_in_place_weight_edit_needs_mark_weights_changed(models):
+    """The engine holds its own copies of the weights; the change detector is a version counter (load_state_dict,
+    .to()) plus a sentinel, not a walk over the state_dict on every call."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN
+    c = GoldenCase("s2_sdpa_r64_img")
+    m = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
+    m.load_state_dict(c.sd)
+    m = m.cuda().eval()
+    x = c.x.cuda()
+    ids0 = m.encode(x, True)
+    with torch.no_grad():
+        getattr(m.pre_vq_conv, "1").weight.mul_(-1.0)
+    m.mark_weights_changed()
+    ids1 = m.encode(x, True)
+    assert not torch.equal(ids0, ids1)
+    m.load_state_dict(c.sd)                 # reloading bumps the version by itself
+    assert torch.equal(m.encode(x, True), ids0)
+    bad = {("module." + k): v for k, v in c.sd.items()}
+    with pytest.raises(RuntimeError, match="lacks"):
+        m.load_state_dict(bad)
 
 
 def test_oracle_parity_other_shapes(models):

@@ -203,6 +203,51 @@ def test_gpt_errors(gpts, lib):
     assert b"head_dim" in lib.omnitok_last_error()
 
 
+def test_interleaved_sequences_are_rejected_not_corrupted(gpts):
+    """The engine keeps ONE set of K/V streams: the reference's sample_with_past_cfg pattern (conditional and
+    unconditional forward_with_past calls in turn, gpt.py:408-409) would silently overwrite the first
+    sequence's cache, so handles of replaced streams raise instead."""
+    m, g, sd, H = gpts("gpt_hd64")
+    a = torch.tensor([[3, 5]], device="cuda")
+    b = torch.tensor([[7]], device="cuda")
+    _, _, pa = m.forward_with_past(a, past=None)
+    past_a = [pa]
+    logits, _, p2 = m.forward_with_past(torch.tensor([[2]], device="cuda"), past=past_a, past_length=2)
+    past_a.append(p2)
+    _, _, pb = m.forward_with_past(b, past=None)            # a second sequence starts: streams are replaced
+    with pytest.raises(RuntimeError, match="sample_with_past_cfg"):
+        m.forward_with_past(torch.tensor([[4]], device="cuda"), past=past_a, past_length=3)
+    # the new sequence itself keeps working
+    m.forward_with_past(torch.tensor([[4]], device="cuda"), past=[pb], past_length=1)
+
+
+def test_stepping_past_the_cache_is_flagged(gpts):
+    m, g, sd, H = gpts("gpt_hd64")
+    m.reset_streams(1, 4)
+    cap = m._cache_shape[1]                 # the cache only grows (other tests may have sized it)
+    tok = torch.tensor([1], device="cuda")
+    for _ in range(cap):
+        m._pos.zero_()                      # keep the position embedding in range; only the cache length grows
+        m.step(tok)
+    m.check_overflow()                      # `cap` tokens fit
+    m._pos.zero_()
+    m.step(tok)                             # one more does not
+    with pytest.raises(RuntimeError, match="K/V cache"):
+        m.check_overflow()
+    m.check_overflow()                      # the flag was cleared
+
+
+def test_lm_state_dict_missing_keys_raise(gpts):
+    from omnitokenizer_amd.gpt import GPT
+    g, sd, (V, BS, L, H, C) = load_gpt_case("gpt_hd64")
+    m = GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C)
+    renamed = {"module." + k: v for k, v in sd.items()}
+    with pytest.raises(RuntimeError, match="lacks"):
+        m.load_state_dict(renamed)
+    with pytest.warns(UserWarning):
+        m.load_state_dict(renamed, strict=False)
+
+
 def test_tokens_to_pixels_chain():
     """The consumer chain of lm_transformer.py:262,430-436: encode() ids condition the LM, sampled ids
     (clamped into the codebook range, :433) go through decode()."""
