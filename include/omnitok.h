@@ -112,9 +112,8 @@ int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int64_t ldw, co
  * significand bits) and three v_mfma_f32_32x32x16_f16 products per element pair, fp32 accumulation.
  * The weight is packed once by omnitok_h2_pack_weight (row-scaled by a power of two, split, interleaved:
  * planes[N][K/8][2][8] fp16 = 4 bytes per element, scale[N]).  fp16 has 5 exponent bits, so the caller
- * states an UPPER BOUND of |a|: a_bound (> 0), multiplied by max_{s < OMNITOK_RANGE_SUBSLOTS}
- * a_bound_dev[a_bound_stride * ((m / a_rows_per_clip) * OMNITOK_RANGE_SUBSLOTS + s)] for row m when that device
- * pointer is given (bounds produced by an earlier kernel, e.g.
+ * states an UPPER BOUND of |a|: a_bound (> 0), multiplied by a_bound_dev[a_bound_stride * (m /
+ * a_rows_per_clip)] for row m when that device pointer is given (bounds produced by an earlier kernel, e.g.
  * omnitok_row_stats; a_rows_per_clip <= 0: one value for all rows); the kernel scales the rows of a clip by
  * one power of two so that |a'| <= 2^15 (tiles never straddle clips: a_rows_per_clip % 64 == 0).  A wrong (too small) bound overflows to inf; elements more than
  * 2^18 below the bound lose relative precision (absolute error <= 2^-40 of the bound).
@@ -130,12 +129,10 @@ int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes, const flo
                     const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
                     float ln_bound, omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
- * bounds (optional, [n_clips][OMNITOK_RANGE_SUBSLOTS][2] floats zeroed by the caller; a clip's range is the max
- * over its sub-slots -- they only spread the atomics, clip of row m = m / rows_per_clip, a single
+ * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of
  * max|x| (|mean| + sqrt(dim)/rstd) and of the row norm ||x||_2: the range information omnitok_gemm_h2
  * needs for operands derived from x, kept per clip so that results never depend on the rest of the batch. */
-#define OMNITOK_RANGE_SUBSLOTS 8
 int omnitok_row_stats(const float *x, int64_t rows, int dim, float eps, float *stats, float *bounds,
                       int64_t rows_per_clip, omnitok_stream_t stream);
 /* out2[0] = max_rows ||w_row||_2, out2[1] = max|w| (atomic max into floats zeroed by the caller). */

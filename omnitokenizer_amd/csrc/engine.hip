@@ -618,7 +618,7 @@ static bool x3_ok(int N, int K, int flags) {
 
 static float *next_bounds(omnitok_engine *e) {  // [n_clips][2] slots of one row-statistics launch
     if (e->bound_next >= N_BOUND_LAUNCHES) return nullptr;
-    return e->bounds + (int64_t)2 * OMNITOK_RANGE_SUBSLOTS * e->bound_clips * (e->bound_next++);
+    return e->bounds + (int64_t)2 * e->bound_clips * (e->bound_next++);
 }
 
 static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
@@ -817,12 +817,12 @@ static int reset_bounds(omnitok_engine *e, int B, hipStream_t stream) {
     if (B > e->bound_cap) {
         if (e->bounds) OT_HIP(hipFree(e->bounds));
         e->bounds = nullptr;
-        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->bounds), (size_t)2 * OMNITOK_RANGE_SUBSLOTS * B * N_BOUND_LAUNCHES * sizeof(float)));
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->bounds), (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float)));
         e->bound_cap = B;
     }
     e->bound_clips = B;
     e->bound_next = 0;
-    OT_HIP(hipMemsetAsync(e->bounds, 0, (size_t)2 * OMNITOK_RANGE_SUBSLOTS * B * N_BOUND_LAUNCHES * sizeof(float), stream));
+    OT_HIP(hipMemsetAsync(e->bounds, 0, (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float), stream));
     return OMNITOK_OK;
 }
 

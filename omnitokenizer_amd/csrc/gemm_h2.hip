@@ -101,11 +101,7 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
         float b = hp.a_bound;
         if (hp.a_bound_dev) {
             const int64_t clip = hp.a_rpc > 0 ? tile_row0 / hp.a_rpc : 0;
-            float m = 0.0f;
-#pragma unroll
-            for (int sub = 0; sub < OMNITOK_RANGE_SUBSLOTS; ++sub)
-                m = fmaxf(m, hp.a_bound_dev[(clip * OMNITOK_RANGE_SUBSLOTS + sub) * hp.a_bound_stride]);
-            b *= m;
+            b *= hp.a_bound_dev[clip * hp.a_bound_stride];
         }
         return h2_scale_of_bound(b);
     };

@@ -63,69 +63,61 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 }
 
 // statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
-// A operand (gemm_x3.hip / gemm_h2.hip), so LN(x) is never written to HBM.
-// bounds (optional, [n_clips][OMNITOK_RANGE_SUBSLOTS][2] floats that the caller zeroed; clip of row m = m / rows_per_clip, one clip
-// if rows_per_clip <= 0): atomic max over the rows of each clip of
-//   [0] |mean| + sqrt(dim) / rstd   >= max_k |x_k|      (|x_k - mean| <= sqrt(dim * var))
-//   [1] sqrt(dim * (mean^2 + 1 / rstd^2)) >= ||x||_2
-// -- the range information the fp16-split GEMM needs for operands derived from x (gemm_h2.hip).  Per
-// clip, so that a clip's results never depend on what else is in the batch.
-// One row per wave, RW rows per workgroup: one atomic pair per workgroup when its rows share a clip, spread
-// over OMNITOK_RANGE_SUBSLOTS sub-slots per clip (atomics on one address serialise at ~3 ns each; the
-// consumer takes the max over the sub-slots).
-// max-merge that skips the atomic when the slot already holds a value >= v (the L2-side read can only be
-// stale-low, which costs an unnecessary atomic, never a wrong result)
-__device__ __forceinline__ void range_max(unsigned *slot, float v) {
-    const unsigned u = __float_as_uint(v);
-    if (u > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, u);
+// A operand (gemm_x3.hip / gemm_h2.hip), so LN(x) is never written to HBM.  One row per wave.
+__global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim, float eps,
+                                                        float *__restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = (dim / 4 + 63) / 64;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = __builtin_nontemporal_load(xr + lane + 64 * i);
+    float mean, rstd;
+    row_stats(v, nv, lane, dim, eps, mean, rstd);
+    if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
 }
 
-template <int RW>
-__global__ __launch_bounds__(64 * RW) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim,
-                                                            float eps, float *__restrict__ stats,
-                                                            float *__restrict__ bounds, int64_t rows_per_clip) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * RW;
-    const int64_t row = row0 + wave;
-    const int nv = (dim / 4 + 63) / 64;
+// Per-clip ranges from the row statistics (clip of row m = m / rows_per_clip): atomic max into
+// bounds[clip][2] (zeroed by the caller) of
+//   [0] |mean| + sqrt(dim) / rstd   >= max_k |x_k|      (|x_k - mean| <= sqrt(dim * var))
+//   [1] sqrt(dim * (mean^2 + 1 / rstd^2)) >= ||x||_2
+// -- the range information the fp16-split GEMM needs for operands derived from x (gemm_h2.hip), per clip so
+// that a clip's results never depend on what else is in the batch.  Reads only the [rows][2] statistics;
+// grid (RANGE_SPLIT, n_clips): RANGE_SPLIT atomics per slot (hot-spot atomics from every row-statistics
+// workgroup cost ~5 us per 1000 and were measured at 0.2 ms per launch).
+constexpr int RANGE_SPLIT = 8;
+__global__ __launch_bounds__(256) void range_from_stats_kernel(const float *__restrict__ stats, int64_t rows,
+                                                               int64_t rows_per_clip, int dim,
+                                                               float *__restrict__ bounds) {
+    const int64_t clip = blockIdx.y;
+    const int64_t lo = clip * rows_per_clip, hi = lo + rows_per_clip < rows ? lo + rows_per_clip : rows;
+    const float sq = sqrtf((float)dim);
     float b0 = 0.0f, b1 = 0.0f;
-    const bool one_clip = rows_per_clip <= 0 || (row0 / rows_per_clip == (row0 + RW - 1) / rows_per_clip);
-    if (row < rows) {
-        const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
-        f32x4 v[LN_MAX_V4];
-#pragma unroll
-        for (int i = 0; i < LN_MAX_V4; ++i)
-            if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = __builtin_nontemporal_load(xr + lane + 64 * i);
-        float mean, rstd;
-        row_stats(v, nv, lane, dim, eps, mean, rstd);
-        if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, rstd);
-        const float sd = 1.0f / rstd;
-        b0 = fabsf(mean) + sqrtf((float)dim) * sd;
-        b1 = sqrtf((float)dim * (mean * mean + sd * sd));
-        if (b0 != b0) b0 = 0.0f;  // NaN rows leave the range alone
-        if (b1 != b1) b1 = 0.0f;
-        if (bounds && !one_clip && lane == 0) {
-            unsigned *bc = reinterpret_cast<unsigned *>(bounds) +
-                           2 * ((row / rows_per_clip) * OMNITOK_RANGE_SUBSLOTS + (row % OMNITOK_RANGE_SUBSLOTS));
-            range_max(bc, b0);  // non-negative floats order like their bit patterns
-            range_max(bc + 1, b1);
-        }
+    for (int64_t m = lo + blockIdx.x * 256 + threadIdx.x; m < hi; m += (int64_t)RANGE_SPLIT * 256) {
+        const float2 ms = *reinterpret_cast<const float2 *>(stats + 2 * m);
+        const float sd = 1.0f / ms.y;
+        const float r0 = fabsf(ms.x) + sq * sd, r1 = sqrtf((float)dim * (ms.x * ms.x + sd * sd));
+        b0 = fmaxf(b0, r0 == r0 ? r0 : 0.0f);  // NaN rows leave the range alone
+        b1 = fmaxf(b1, r1 == r1 ? r1 : 0.0f);
     }
-    if (bounds && one_clip) {
-        __shared__ float sh[2][RW];
-        if (lane == 0) {
-            sh[0][wave] = b0;
-            sh[1][wave] = b1;
-        }
-        __syncthreads();
-        if (threadIdx.x < 2 && row0 < rows) {
-            float m = 0.0f;
 #pragma unroll
-            for (int i = 0; i < RW; ++i) m = fmaxf(m, sh[threadIdx.x][i]);
-            const int64_t clip = rows_per_clip > 0 ? row0 / rows_per_clip : 0;
-            const int sub = (int)(blockIdx.x % OMNITOK_RANGE_SUBSLOTS);
-            range_max(reinterpret_cast<unsigned *>(bounds) + 2 * (clip * OMNITOK_RANGE_SUBSLOTS + sub) + threadIdx.x, m);
-        }
+    for (int o = 32; o > 0; o >>= 1) {
+        b0 = fmaxf(b0, __shfl_xor(b0, o));
+        b1 = fmaxf(b1, __shfl_xor(b1, o));
+    }
+    __shared__ float sh[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = b0;
+        sh[1][threadIdx.x >> 6] = b1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const float m = fmaxf(fmaxf(sh[threadIdx.x][0], sh[threadIdx.x][1]), fmaxf(sh[threadIdx.x][2], sh[threadIdx.x][3]));
+        // non-negative floats order like their bit patterns
+        atomicMax(reinterpret_cast<unsigned *>(bounds) + 2 * clip + threadIdx.x, __float_as_uint(m));
     }
 }
 
@@ -274,9 +266,15 @@ extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float ep
     OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4, "row_stats: dim=%d unsupported", dim);
     OT_CHECK_ARG(aligned16(x) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "row_stats: alignment");
     if (rows == 0) return OMNITOK_OK;
-    constexpr int RW = 8;
-    hipLaunchKernelGGL(row_stats_kernel<RW>, dim3((unsigned)((rows + RW - 1) / RW)), dim3(64 * RW), 0, stream, x, rows,
-                       dim, eps, stats, bounds, rows_per_clip);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, dim, eps,
+                       stats);
+    if (bounds) {
+        const int64_t rpc = rows_per_clip > 0 ? rows_per_clip : rows;
+        const int64_t n_clips = (rows + rpc - 1) / rpc;
+        OT_CHECK_ARG(n_clips <= 65535, "row_stats: %lld clips (max 65535)", (long long)n_clips);
+        hipLaunchKernelGGL(range_from_stats_kernel, dim3(RANGE_SPLIT, (unsigned)n_clips), dim3(256), 0, stream, stats,
+                           rows, rpc, dim, bounds);
+    }
     OT_LAUNCH_CHECK("row_stats");
     return OMNITOK_OK;
 }
