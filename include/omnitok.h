@@ -100,18 +100,20 @@ int omnitok_gemm(const float *a, int64_t lda, const float *w, int64_t ldw, const
  * to_q / qkv / the FeedForward's first Linear): ln_stats[rows][2] = (mean, rstd) per PHYSICAL a row
  * (omnitok_row_stats), ln_gamma[K], ln_beta[K] (NULL = 0), K <= 512; output columns [0, ln_cols) are
  * computed from LN(a), columns [ln_cols, N) from a itself (Q from LN(x), K/V from x in one launch,
- * attention.py:404-412).  ln_stats == NULL: no LayerNorm. */
+ * attention.py:404-412).  ln_stats == NULL: no LayerNorm.
+ * split_col > 0 (a multiple of 256, plain / bias epilogues only): output columns [split_col, N) are written
+ * to c2 (row stride ldc2) instead of c, so that one launch produces Q and K|V as two dense tensors. */
 int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
                     const float *residual, int64_t ldr, float *c, int64_t ldc,
                     int64_t M, int N, int K, int flags,
                     int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
                     const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
-                    omnitok_stream_t stream);
+                    float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream);
 /* --- fp32 GEMM on the fp16 matrix cores, 2-way split operands (csrc/gemm_h2.hip) ---------------------
  * c = a . w^T (+epilogue as omnitok_gemm) with each operand element a' = hi + lo (two fp16 numbers, 22
  * significand bits) and three v_mfma_f32_32x32x16_f16 products per element pair, fp32 accumulation.
- * The weight is packed once by omnitok_h2_pack_weight (row-scaled by a power of two, split, interleaved:
- * planes[N][K/8][2][8] fp16 = 4 bytes per element, scale[N]).  fp16 has 5 exponent bits, so the caller
+ * The weight is packed once by omnitok_h2_pack_weight (row-scaled by a power of two, split, in blocks of 64
+ * rows x 32 k: planes[ceil(N/64)][K/32][hi|lo][4][64][8] fp16 = 4 bytes per element, scale[N]).  fp16 has 5 exponent bits, so the caller
  * states an UPPER BOUND of |a|: a_bound (> 0), multiplied by a_bound_dev[a_bound_stride * (m /
  * a_rows_per_clip)] for row m when that device pointer is given (bounds produced by an earlier kernel, e.g.
  * omnitok_row_stats; a_rows_per_clip <= 0: one value for all rows); the kernel scales the rows of a clip by
@@ -127,7 +129,7 @@ int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes, const flo
                     int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
                     float a_bound, const float *a_bound_dev, int a_bound_stride, int64_t a_rows_per_clip,
                     const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
-                    float ln_bound, omnitok_stream_t stream);
+                    float ln_bound, float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of

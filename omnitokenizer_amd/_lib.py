@@ -42,10 +42,11 @@ I64 = c_int64
 _PROTOS = {
     "omnitok_layernorm": [P, P, P, P, I64, c_int, c_float, I64, I64, I64, P],
     "omnitok_gemm": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P],
-    "omnitok_gemm_x3": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P, P, P, c_int, P],
+    "omnitok_gemm_x3": [P, I64, P, I64, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, P, P, P, c_int, P, I64,
+                        c_int, P],
     "omnitok_h2_pack_weight": [P, I64, c_int, c_int, P, P, P],
     "omnitok_gemm_h2": [P, I64, P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, c_float, P, c_int,
-                        I64, P, P, P, c_int, c_float, P],
+                        I64, P, P, P, c_int, c_float, P, I64, c_int, P],
     "omnitok_row_stats": [P, I64, c_int, c_float, P, P, I64, P],
     "omnitok_weight_range": [P, I64, c_int, c_int, P, P],
     "omnitok_pack_geglu_weight": [P, c_int, c_int, c_int, P, P],

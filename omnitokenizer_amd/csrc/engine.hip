@@ -321,7 +321,7 @@ static int ln_range(omnitok_engine *e, const float *gamma, const float *beta, in
 static int pack_h2(omnitok_engine *e, const float *w, int64_t ld, int N, int K, hipStream_t stream) {
     if (!w || N % 32 || K % 32 || ld != K) return OMNITOK_OK;  // shapes the h2 kernel does not take: x3 / fp32 path
     float *pl, *sc;
-    if (int rc = alloc_f(e, &pl, (int64_t)N * K)) return rc;  // 2 planes x 2 B = 4 B per element
+    if (int rc = alloc_f(e, &pl, (int64_t)((N + 63) / 64 * 64) * K)) return rc;  // 2 planes x 2 B, 64-row blocks
     if (int rc = alloc_f(e, &sc, N)) return rc;
     if (int rc = omnitok_h2_pack_weight(w, ld, N, K, pl, sc, stream)) return rc;
     H2W h;
@@ -625,18 +625,18 @@ static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *
                    const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags,
                    int64_t rpg, int64_t gstride, int64_t goff, hipStream_t stream, ABound ab = ABound(),
                    const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
-                   int ln_cols = 0, float ln_bound = 0.0f) {
+                   int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0) {
     if (g_gemm_mode == 2 && ab.stat > 0.0f && x3_ok(N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
         (!ab.dev || (ab.rpc > 0 && ab.rpc % 64 == 0 && rpg == 0))) {
         auto it = e->h2w.find(w);
         if (it != e->h2w.end() && ldw == K)
             return omnitok_gemm_h2(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K, flags,
                                    rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b, ln_cols,
-                                   ln_bound, stream);
+                                   ln_bound, c2, ldc2, split_col, stream);
     }
     if (x3_ok(N, K, flags))
         return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
-                               ln_stats, ln_g, ln_b, ln_cols, stream);
+                               ln_stats, ln_g, ln_b, ln_cols, c2, ldc2, split_col, stream);
     if (ln_stats) {
         set_error("eg_gemm: fused LayerNorm needs the x3 / h2 kernel");
         return OMNITOK_ERR_STATE;
@@ -717,12 +717,11 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
                 // for the Q columns only; QKV rows are [q | k | v]
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
+                // ... and the two column ranges land in two dense tensors (Q [L, D], K|V [L, 2D]): the attention
+                // kernels read rows of D / 2D floats (with a [L, 3D] row pitch spatial attention ran 15 % slower)
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
-                       eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
-                               stream, ab_x, e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound));
-                KV = e->QKV.p + D;
-                ldq = 3 * D;
-                ldkv = 3 * D;
+                       eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, Q, D, L, 3 * D, D, 0, 0, 0, 0, stream, ab_x,
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D));
             } else if (fused) {
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,

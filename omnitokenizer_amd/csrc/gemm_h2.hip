@@ -39,7 +39,7 @@ int g_h2_tile = 0;  // "h2_tile": 0 auto, 1 256x256, 3 128x128, 4 64x64 / 64x128
 
 struct H2Params {
     GemmParams g;            // g.w is unused (the weight comes as packed planes)
-    const void *wpl;         // [N][K/8][2][8] fp16 (omnitok_h2_pack_weight)
+    const void *wpl;         // block layout of omnitok_h2_pack_weight
     const float *wscale;     // [N]: 2^f_n, the factor that undoes the row scaling
     float a_bound;           // static upper bound of |a|, multiplied by a_bound_dev[stride * clip] when set
     const float *a_bound_dev;
@@ -50,6 +50,9 @@ struct H2Params {
     const float *ln_beta;
     int ln_cols;
     float ln_bound;          // upper bound of |LN(a)|
+    float *c2;               // output columns [split_col, N) go to c2 (row stride ldc2) instead of c
+    int64_t ldc2;
+    int split_col;           // 0: everything to c
 };
 
 template <int WGM_, int WGN_, int MI_, int NI_>
@@ -145,7 +148,9 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
         for (int r = 0; r < NB; ++r) {
             int wr = tbn * TN + lrow + RPP * r;
             if (wr > p.N - 1) wr = p.N - 1;
-            wp[r] = static_cast<const char *>(hp.wpl) + (int64_t)wr * p.K * 4 + lq * 16;
+            // row wr of the block layout; the K-step's chunk (k half lq >> 1, plane lq & 1) is added per load
+            wp[r] = static_cast<const char *>(hp.wpl) + (int64_t)(wr >> 6) * (p.K >> 5) * 8192 + (wr & 63) * 16 +
+                    (lq & 1) * 4096 + (lq >> 1) * 1024;
         }
     };
     f32x4 ga[2][NA];
@@ -160,7 +165,8 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) ga[set][i] = *reinterpret_cast<const f32x4 *>(ap[i] + k0);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) gw[set][i] = *reinterpret_cast<const u32x4 *>(wp[i] + k0 * 4);
+        for (int i = 0; i < NB; ++i)  // K-step k0 (multiple of 16): block step k0 / 32, k groups (k0 / 8) % 4 + {0, 1}
+            gw[set][i] = *reinterpret_cast<const u32x4 *>(wp[i] + (k0 >> 5) * 8192 + ((k0 >> 3) & 3) * 1024);
         if constexpr (LN) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) {
@@ -311,18 +317,42 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
             const int col = col0 + ni * 32 + r32;
             cs[ni] = ainv * hp.wscale[col < p.N ? col : p.N - 1];
         }
-        x3_epilogue<FLAGS, MI, NI, true>(p, acc, ebm * TM + wm * MI * 32, col0, r32, hi, cs);
+        if (hp.split_col > 0 && col0 >= hp.split_col) {  // wave-uniform: split_col is a multiple of the tile width
+            GemmParams q = p;
+            q.c = hp.c2;
+            q.ldc = hp.ldc2;
+            q.N = p.N - hp.split_col;
+            if (q.bias) q.bias += hp.split_col;
+            x3_epilogue<FLAGS, MI, NI, true>(q, acc, ebm * TM + wm * MI * 32, col0 - hp.split_col, r32, hi, cs);
+        } else {
+            x3_epilogue<FLAGS, MI, NI, true>(p, acc, ebm * TM + wm * MI * 32, col0, r32, hi, cs);
+        }
         zero_acc();
     }
 }
 
 // weight row n -> scaled fp16 planes: w' = w * 2^(14 - x) with max|w_n| = m 2^x (m in [0.5, 1)), hi = fp16(w'),
-// lo = fp16(w' - hi); out[n][k / 8][plane][k % 8]; scale[n] = 2^(x - 14).  One wave per row.
+// lo = fp16(w' - hi); scale[n] = 2^(x - 14).  Layout in blocks of 64 rows x 32 k:
+// out[n / 64][k / 32][plane][(k / 8) % 4][n % 64][k % 8]  (8 KB per block; the loader's 16 lanes x 16 B of one
+// (plane, k-group) are 256 contiguous bytes).  Rows beyond N (up to the next multiple of 64) are zero.
+// One wave per row.
+__device__ __forceinline__ int64_t h2_w_offset(int n, int k, int plane, int K) {  // in fp16 elements
+    return (((int64_t)(n >> 6) * (K >> 5) + (k >> 5)) * 8 + plane * 4 + ((k >> 3) & 3)) * 512 + (n & 63) * 8 + (k & 7);
+}
+
 __global__ __launch_bounds__(256) void h2_pack_weight_kernel(const float *__restrict__ w, int64_t ldw, int N, int K,
                                                              _Float16 *__restrict__ out, float *__restrict__ scale) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    const int npad = ((N + 63) / 64) * 64;
+    if (n >= npad) return;
+    if (n >= N) {
+        for (int k = lane; k < K; k += 64) {
+            out[h2_w_offset(n, k, 0, K)] = (_Float16)0.0f;
+            out[h2_w_offset(n, k, 1, K)] = (_Float16)0.0f;
+        }
+        return;
+    }
     const float *wr = w + (int64_t)n * ldw;
     float mx = 0.0f;
     for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
@@ -332,13 +362,12 @@ __global__ __launch_bounds__(256) void h2_pack_weight_kernel(const float *__rest
     if (mx > 0.0f && mx < 3.0e38f) (void)frexpf(mx, &x);
     const float s = ldexpf(1.0f, 14 - x);
     if (lane == 0) scale[n] = ldexpf(1.0f, x - 14);
-    _Float16 *o = out + (int64_t)n * K * 2;
     for (int k = lane; k < K; k += 64) {
         const float v = wr[k] * s;
         const _Float16 h = (_Float16)v;
         const _Float16 l = (_Float16)(v - (float)h);
-        o[(k >> 3) * 16 + (k & 7)] = h;
-        o[(k >> 3) * 16 + 8 + (k & 7)] = l;
+        out[h2_w_offset(n, k, 0, K)] = h;
+        out[h2_w_offset(n, k, 1, K)] = l;
     }
 }
 
@@ -417,8 +446,9 @@ using namespace omnitok;
 extern "C" int omnitok_h2_pack_weight(const float *w, int64_t ldw, int N, int K, void *planes, float *scale,
                                       omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(w && planes && scale && N > 0 && K > 0 && K % 16 == 0, "h2_pack_weight: bad arguments");
-    hipLaunchKernelGGL(h2_pack_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, w, ldw, N, K,
+    OT_CHECK_ARG(w && planes && scale && N > 0 && K > 0 && K % 32 == 0, "h2_pack_weight: bad arguments (K %% 32)");
+    const int npad = ((N + 63) / 64) * 64;
+    hipLaunchKernelGGL(h2_pack_weight_kernel, dim3((npad + 3) / 4), dim3(256), 0, stream, w, ldw, N, K,
                        static_cast<_Float16 *>(planes), scale);
     OT_LAUNCH_CHECK("h2_pack_weight");
     return OMNITOK_OK;
@@ -429,9 +459,11 @@ extern "C" int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes
                                int64_t M, int N, int K, int flags, int64_t a_rows_per_group, int64_t a_group_stride,
                                int64_t a_group_offset, float a_bound, const float *a_bound_dev, int a_bound_stride,
                                int64_t a_rows_per_clip, const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
-                               float ln_bound, omnitok_stream_t stream_) {
+                               float ln_bound, float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(a && w_planes && w_scale && c, "gemm_h2: null pointer");
+    OT_CHECK_ARG(split_col == 0 || (c2 && split_col % 256 == 0 && split_col < N && !(flags & (OMNITOK_GEMM_GEGLU | OMNITOK_GEMM_RESIDUAL))),
+                 "gemm_h2: split output needs c2, split_col %% 256 == 0 and no GEGLU / residual epilogue");
     OT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_h2: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     if (M == 0) return OMNITOK_OK;
     OT_CHECK_ARG(K % 32 == 0 && N % 32 == 0, "gemm_h2: K=%d and N=%d must be multiples of 32", K, N);
@@ -457,6 +489,7 @@ extern "C" int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes
     hp.a_bound_stride = a_bound_stride > 0 ? a_bound_stride : 1; hp.a_rpc = a_rows_per_clip;
     hp.ln_stats = ln_stats; hp.ln_gamma = ln_gamma; hp.ln_beta = ln_beta; hp.ln_cols = ln ? ln_cols : 0;
     hp.ln_bound = ln_bound;
+    hp.c2 = c2; hp.ldc2 = ldc2; hp.split_col = split_col;
 #define H2_CASE(F)                                                    \
     case F:                                                           \
         return ln ? launch_h2<F, true>(hp, stream) : launch_h2<F, false>(hp, stream);

@@ -50,6 +50,9 @@ struct X3Params {
     const float *ln_gamma;   // [K]
     const float *ln_beta;    // [K] or null (= 0)
     int ln_cols;             // output columns [0, ln_cols) take LN(a), the rest takes a
+    float *c2;               // output columns [split_col, N) go to c2 (row stride ldc2) instead of c
+    int64_t ldc2;            //   (Q | K,V of the merged to_q / to_kv launch as two dense tensors)
+    int split_col;           // 0: everything to c
 };
 
 // ONE: a single staged register set (the global loads of K-step g+1 are issued at the start of step g
@@ -350,7 +353,19 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_x3_kernel(X3Params xp) {
         int64_t ebm;
         int ebn;
         tile_coords(lid, nbm, nbn, p.gn, ebm, ebn);
-        x3_epilogue<FLAGS, MI, NI>(p, acc, ebm * TM + wm * MI * 32, ebn * TN + wn * NI * 32, r32, hi);
+        {
+            const int col0 = ebn * TN + wn * NI * 32;
+            if (xp.split_col > 0 && col0 >= xp.split_col) {  // wave-uniform: split_col is a multiple of the tile width
+                GemmParams q = p;
+                q.c = xp.c2;
+                q.ldc = xp.ldc2;
+                q.N = p.N - xp.split_col;
+                if (q.bias) q.bias += xp.split_col;
+                x3_epilogue<FLAGS, MI, NI>(q, acc, ebm * TM + wm * MI * 32, col0 - xp.split_col, r32, hi);
+            } else {
+                x3_epilogue<FLAGS, MI, NI>(p, acc, ebm * TM + wm * MI * 32, col0, r32, hi);
+            }
+        }
         zero_acc();
     }
     if constexpr ((DBG & 16) != 0) {
@@ -439,9 +454,11 @@ extern "C" int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int6
                                const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K,
                                int flags, int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
                                const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
-                               omnitok_stream_t stream_) {
+                               float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(a && w && c, "gemm_x3: null pointer");
+    OT_CHECK_ARG(split_col == 0 || (c2 && split_col % 256 == 0 && split_col < N && !(flags & (OMNITOK_GEMM_GEGLU | OMNITOK_GEMM_RESIDUAL))),
+                 "gemm_x3: split output needs c2, split_col %% 256 == 0 and no GEGLU / residual epilogue");
     OT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "gemm_x3: bad sizes M=%lld N=%d K=%d", (long long)M, N, K);
     if (M == 0) return OMNITOK_OK;
     OT_CHECK_ARG(K % 32 == 0, "gemm_x3: K=%d must be a multiple of 32 (pad the weight)", K);
@@ -462,6 +479,7 @@ extern "C" int omnitok_gemm_x3(const float *a, int64_t lda, const float *w, int6
     p.gn = 8;
     p.trace = g_gemm_trace;
     xp.ln_stats = ln_stats; xp.ln_gamma = ln_gamma; xp.ln_beta = ln_beta; xp.ln_cols = ln ? ln_cols : 0;
+    xp.c2 = c2; xp.ldc2 = ldc2; xp.split_col = split_col;
 #define X3_CASE(F)                                                    \
     case F:                                                           \
         return ln ? launch_x3<F, true>(xp, stream) : launch_x3<F, false>(xp, stream);

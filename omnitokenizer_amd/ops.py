@@ -121,15 +121,18 @@ def linear_x3(x, weight, bias=None, residual=None, geglu=False, ln=None, ln_cols
         _opt(b, "ln beta", K)
     check(_lib.load().omnitok_gemm_x3(_p(x), K, _p(weight), weight.shape[1], _p(bias), _p(residual), ncol, _p(out),
                                       ncol, M, N, K, flags, 0, 0, 0, _p(st), _p(g), _p(b),
-                                      int(ln_cols if ln_cols is not None else N), _stream()), "gemm_x3")
+                                      int(ln_cols if ln_cols is not None else N), None, 0, 0, _stream()), "gemm_x3")
     return out
 
 
 def h2_pack_weight(weight):
-    """fp32 [N, K] -> (planes int16 [N, K/8, 2, 8] holding fp16 hi|lo of the row-scaled weight, scale [N])."""
+    """fp32 [N, K] -> (planes fp16 [ceil(N/64), K/32, 2, 4, 64, 8] = hi|lo of the row-scaled weight in blocks of
+    64 rows x 32 k (the LDS image of the K32 kernel), scale [N])."""
     weight = _req(weight, "weight")
     N, K = weight.shape
-    planes = torch.empty(N, K // 8, 2, 8, device=weight.device, dtype=torch.float16)
+    if K % 32:
+        raise ValueError("h2_pack_weight: K must be a multiple of 32")
+    planes = torch.empty((N + 63) // 64, K // 32, 2, 4, 64, 8, device=weight.device, dtype=torch.float16)
     scale = torch.empty(N, device=weight.device, dtype=torch.float32)
     check(_lib.load().omnitok_h2_pack_weight(_p(weight), K, N, K, _p(planes), _p(scale), _stream()), "h2_pack_weight")
     return planes, scale
@@ -143,7 +146,7 @@ def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound
     planes, scale = packed
     K = x.shape[-1]
     M = x.numel() // K
-    N = planes.shape[0]
+    N = scale.shape[0]
     ncol = N // 2 if geglu else N
     out = torch.empty(*x.shape[:-1], ncol, device=x.device, dtype=torch.float32)
     _opt(bias, "bias", ncol)
@@ -160,8 +163,8 @@ def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound
     check(_lib.load().omnitok_gemm_h2(_p(x), K, _p(planes), _p(scale), _p(bias), _p(residual), ncol, _p(out), ncol,
                                       M, N, K, flags, 0, 0, 0, float(a_bound), _p(a_bound_dev), int(a_bound_stride),
                                       int(rows_per_clip), _p(st), _p(g), _p(b),
-                                      int(ln_cols if ln_cols is not None else N), float(ln_bound), _stream()),
-          "gemm_h2")
+                                      int(ln_cols if ln_cols is not None else N), float(ln_bound), None, 0, 0,
+                                      _stream()), "gemm_h2")
     return out
 
 

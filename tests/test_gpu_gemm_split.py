@@ -102,12 +102,15 @@ def test_h2_pack_weight(ops):
     w = rnd(300, 512, seed=3) * torch.logspace(-4, 3, 300).view(-1, 1)
     w[7] = 0.0
     planes, scale = ops.h2_pack_weight(dev(w))
-    pl = planes.cpu().double()            # [N, K/8, 2, 8]
-    rec = (pl[:, :, 0] + pl[:, :, 1]).reshape(300, 512) * scale.cpu().double().view(-1, 1)
+    # [N/64 blocks, K/32, plane, k-group, row, 8] -> [rows, K] per plane
+    pl = planes.cpu().double().permute(2, 0, 4, 1, 3, 5).reshape(2, -1, 512)
+    assert pl[:, 300:].abs().max() == 0, "padding rows of the last block must be zero"
+    pl = pl[:, :300]
+    rec = (pl[0] + pl[1]) * scale.cpu().double().view(-1, 1)
     assert ((rec - w.double()).abs() <= 2.0 ** -21 * w.double().abs() + 1e-30).all()
     m, e = torch.frexp(scale.cpu())
     assert (m == 0.5).all(), "row scales must be powers of two"
-    top = pl[:, :, 0].abs().reshape(300, -1).max(1).values
+    top = pl[0].abs().max(1).values
     ok = (top >= 2.0 ** 13) & (top <= 2.0 ** 14)
     ok[7] = True
     assert ok.all()
@@ -220,13 +223,36 @@ def test_split_gemm_row_map(ops):
     ref = big[rows].double() @ w.double().t()
     out = torch.empty(256, N, device="cuda")
     assert lib.omnitok_gemm_x3(p(bd), K, p(wd), K, None, None, 0, p(out), N, 256, N, K, 0, 64, 160, 32, None, None,
-                               None, 0, s) == 0
+                               None, 0, None, 0, 0, s) == 0
     assert maxerr(out, ref) < 1e-5
     planes, scale = ops.h2_pack_weight(wd)
     out2 = torch.empty(256, N, device="cuda")
     assert lib.omnitok_gemm_h2(p(bd), K, p(planes), p(scale), None, None, 0, p(out2), N, 256, N, K, 0, 64, 160, 32,
-                               float(big.abs().max()), None, 1, 0, None, None, None, 0, 0.0, s) == 0
+                               float(big.abs().max()), None, 1, 0, None, None, None, 0, 0.0, None, 0, 0, s) == 0
     assert maxerr(out2, ref) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["x3", "h2"])
+def test_split_gemm_two_output_tensors(ops, tile, kind):
+    """Columns [split_col, N) of one launch land in a second dense tensor (Q and K|V of the merged projection)."""
+    from omnitokenizer_amd import _lib
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    M, K, N = 1000, 512, 1536
+    x, w = dev(rnd(M, K, seed=71)), dev(rnd(N, K, seed=72) * 0.05)
+    q = torch.full((M, 512), float("nan"), device="cuda")
+    kv = torch.full((M, 1024), float("nan"), device="cuda")
+    if kind == "x3":
+        whole = ops.linear_x3(x, w)
+        assert lib.omnitok_gemm_x3(p(x), K, p(w), K, None, None, 0, p(q), 512, M, N, K, 0, 0, 0, 0, None, None, None, 0,
+                                   p(kv), 1024, 512, s) == 0
+    else:
+        planes, scale = ops.h2_pack_weight(w)
+        whole = ops.linear_h2(x, (planes, scale), 6.0)
+        assert lib.omnitok_gemm_h2(p(x), K, p(planes), p(scale), None, None, 0, p(q), 512, M, N, K, 0, 0, 0, 0, 6.0, None,
+                                   1, 0, None, None, None, 0, 0.0, p(kv), 1024, 512, s) == 0
+    assert torch.equal(q, whole[:, :512]) and torch.equal(kv, whole[:, 512:])
 
 
 @pytest.mark.parametrize("rows_per_clip", [0, 64, 256, 1000])
