@@ -87,6 +87,12 @@ class OmniTokConfig:
         n_pool = sum(self.enc_block.count(c) for c in "aml")
         return (2 ** n_pool) * (2 if self._defer_s else 1)
 
+    @property
+    def enc_grid_multiplier(self) -> int:
+        """Up blocks ('n' / 'r', reference attention.py:116-150) in the encoder double the grid:
+        latent grid = (resolution / enc_patch_size) * enc_grid_multiplier / enc_grid_divisor."""
+        return 2 ** sum(self.enc_block.count(c) for c in "nr")
+
     @staticmethod
     def from_args(args, attention_mode: str = "sdpa") -> "OmniTokConfig":
         spatial_depth = args.spatial_depth
@@ -138,16 +144,17 @@ class OmniTokConfig:
             raise ValueError("patch_embed='cnn' needs norm_type='batch': the reference's "
                              "Normalize(image_channel, 'group') raises 'num_channels (3) must be divisible by "
                              "num_groups (32)' (base.py:274, omnitokenizer.py:1023)")
-        bad = sorted(set(self.enc_block) - set("twaml"))
+        bad = sorted(set(self.enc_block) - set("twamlnr"))
         if bad:
             raise NotImplementedError(f"enc_block={self.enc_block!r}: unknown block types {bad} "
                                       "(reference attention.py:614-649)")
         bad = sorted(set(self.dec_block) - set("tw"))
         if bad:
             raise NotImplementedError(
-                f"dec_block={self.dec_block!r}: block types {bad} are not built. 'n'/'r' (Up) blocks make the "
-                "reference decoder itself raise (einops shape mismatch at omnitokenizer.py:1078: it regroups "
-                "(b h w) rows with h // down_ratio), pooling blocks are encoder-side")
+                f"dec_block={self.dec_block!r}: block types {bad} are not built. In the DECODER 'n'/'r' (Up) blocks "
+                "make the reference itself raise (einops shape mismatch at omnitokenizer.py:1078: it regroups "
+                "(b h w) rows with h // down_ratio); in the encoder they are built. Pooling blocks are "
+                "encoder-side")
         if self.gen_upscale < 1:
             raise ValueError("gen_upscale must be >= 1")
         if (self._defer_s and self.patch_size % 2) or (self._defer_t and self.temporal_patch_size % 2):

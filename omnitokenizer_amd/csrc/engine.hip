@@ -67,11 +67,11 @@ struct ABound {  // upper bound of |A| of a row of clip c = stat * (dev ? dev[2 
     int64_t rpc = 0;             // rows per clip
 };
 struct Layer {
-    char kind;  // 't', 'w', or a pooling block 'a' / 'm' / 'l'
+    char kind;  // 't', 'w', a pooling block 'a' / 'm' / 'l', or an Up block 'n' / 'r' (encoder only)
     LayerT t;
     LayerW w;
     LayerFF ff;
-    const float *pool_w = nullptr, *pool_b = nullptr;  // 'l': Linear(4*dim, dim)
+    const float *pool_w = nullptr, *pool_b = nullptr;  // 'l': Linear(4*dim, dim); 'r': Linear(dim, dim)
 };
 
 // patch / grid geometry of a configuration (reference omnitokenizer.py:792-804, 957-959, 985-1003)
@@ -144,6 +144,26 @@ static Geo geometry(const omnitok_config &c) {
     return g;
 }
 
+// token grid after the encoder's spatial blocks (pooling blocks halve it, attention.py:683-684; Up blocks
+// double it, :686-687).  *peak (optional) = the largest tokens-per-frame count on the way (workspace size).
+// false if a pooling block meets an odd grid.
+static bool walk_enc_grid(const char *block, int *gh, int *gw, int64_t *peak) {
+    int64_t pk = (int64_t)*gh * *gw;
+    for (const char *q = block; *q; ++q) {
+        if (*q == 'a' || *q == 'm' || *q == 'l') {
+            if (*gh % 2 || *gw % 2) return false;
+            *gh /= 2;
+            *gw /= 2;
+        } else if (*q == 'n' || *q == 'r') {
+            *gh *= 2;
+            *gw *= 2;
+        }
+        if ((int64_t)*gh * *gw > pk) pk = (int64_t)*gh * *gw;
+    }
+    if (peak) *peak = pk;
+    return true;
+}
+
 static void add_transformer_spec(omnitok_engine *e, const std::string &prefix, const std::string &block,
                                  bool rel) {
     const omnitok_config &c = e->cfg;
@@ -171,8 +191,11 @@ static void add_transformer_spec(omnitok_engine *e, const std::string &prefix, c
         } else if (block[i] == 'l') {
             e->spec[p + ".1.pool.weight"] = {d, 4 * d};
             e->spec[p + ".1.pool.bias"] = {d};
-        } else if (block[i] == 'a' || block[i] == 'm') {
-            // parameter-free pooling
+        } else if (block[i] == 'r') {  // Up('r'): Upsample -> Rearrange -> Linear, reference attention.py:122-127
+            e->spec[p + ".1.up.2.weight"] = {d, d};
+            e->spec[p + ".1.up.2.bias"] = {d};
+        } else if (block[i] == 'a' || block[i] == 'm' || block[i] == 'n') {
+            // parameter-free pooling / nearest up-sampling
         } else {
             e->spec[p + ".1.relative_position_bias_table"] = {(2 * ws - 1) * (2 * ws - 1), heads};
             e->spec[p + ".1.relative_position_index"] = {ws * ws, ws * ws};
@@ -376,7 +399,10 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
         } else if (block[i] == 'l') {
             L.pool_w = W(e, p + ".1.pool.weight");
             L.pool_b = W(e, p + ".1.pool.bias");
-        } else if (block[i] == 'a' || block[i] == 'm') {
+        } else if (block[i] == 'r') {
+            L.pool_w = W(e, p + ".1.up.2.weight");
+            L.pool_b = W(e, p + ".1.up.2.bias");
+        } else if (block[i] == 'a' || block[i] == 'm' || block[i] == 'n') {
         } else {
             const int ntok = c.window_size * c.window_size;
             float *dense;
@@ -680,6 +706,31 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             gemm_f = 2.0 * (double)L * D;
             goto feed_forward;
         }
+        if (ly.kind == 'n' || ly.kind == 'r') {
+            // Up (reference attention.py:116-150): nearest 2x2 up-sampling of the token grid, no residual (:674),
+            // 'r' adds Linear(D, D).  A row-wise Linear commutes with the row duplication bit for bit, so it
+            // runs on the L source rows (a quarter of the work) and the result is up-sampled.
+            if (!spatial) {
+                set_error("Up block '%c' in a temporal transformer", ly.kind);
+                return OMNITOK_ERR_INVALID;
+            }
+            const float *src = e->X.p;
+            if (ly.kind == 'r') {
+                OT_RUN("pool", 2.0 * (double)L * D * D,
+                       eg_gemm(e, e->X.p, D, ly.pool_w, D, ly.pool_b, nullptr, 0, e->Y.p, D, L, D, D, OMNITOK_GEMM_BIAS, 0,
+                               0, 0, stream));
+                src = e->Y.p;
+            }
+            OT_RUN("pool", 1.25 * 4.0 * L * D * 4.0,
+                   omnitok_token_resample(src, e->X2.p, 2, (int64_t)B * T, 1, gh, gw, D, stream));
+            std::swap(e->X, e->X2);
+            gh *= 2;
+            gw *= 2;
+            S = gh * gw;
+            L = (int64_t)B * T * S;
+            gemm_f = 2.0 * (double)L * D;
+            goto feed_forward;
+        }
         if (ly.kind == 't') {
             OT_RUN("peg3d", 2.0 * L * D * 4.0,
                    omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
@@ -901,14 +952,14 @@ extern "C" int omnitok_engine_create(const omnitok_config *cfg, omnitok_engine *
     }
     const std::string eb(c.enc_block), db(c.dec_block);
     for (char ch : eb)
-        if (!strchr("twaml", ch)) {
+        if (!strchr("twamlnr", ch)) {
             set_error("engine_create: enc_block type '%c' unknown (reference attention.py:614-649)", ch);
             return OMNITOK_ERR_UNSUPPORTED;
         }
     for (char ch : db)
         if (ch != 't' && ch != 'w') {
-            set_error("engine_create: dec_block type '%c' not built ('n'/'r' Up blocks make the reference decoder "
-                      "raise at omnitokenizer.py:1078; pooling blocks are encoder-side)", ch);
+            set_error("engine_create: dec_block type '%c' not built (in the decoder 'n'/'r' Up blocks make the "
+                      "reference raise at omnitokenizer.py:1078; pooling blocks are encoder-side)", ch);
             return OMNITOK_ERR_UNSUPPORTED;
         }
     omnitok_engine *e = new omnitok_engine();
@@ -1103,10 +1154,13 @@ static int encode_shape(omnitok_engine *e, int F, int H, int W_, int *T, int *gh
     OT_CHECK_ARG(H > 0 && W_ > 0 && H % g.p_enc == 0 && W_ % g.p_enc == 0,
                  "image size %dx%d not divisible by patch size %d", H, W_, g.p_enc);
     int t = 1 + (F - 1) / g.pt_enc, h = H / g.p_enc, w = W_ / g.p_enc;
-    const int div = (1 << g.n_pool) * (g.defer_s ? 2 : 1);
-    OT_CHECK_ARG(h % div == 0 && w % div == 0, "token grid %dx%d not divisible by the pooling factor %d", h, w, div);
-    h /= div;
-    w /= div;
+    OT_CHECK_ARG(walk_enc_grid(c.enc_block, &h, &w, nullptr) && (!g.defer_s || (h % 2 == 0 && w % 2 == 0)),
+                 "token grid %dx%d not divisible by the pooling factor of enc_block '%s'%s", H / g.p_enc, W_ / g.p_enc,
+                 c.enc_block, g.defer_s ? " + deferred spatial pool" : "");
+    if (g.defer_s) {
+        h /= 2;
+        w /= 2;
+    }
     if (g.defer_t) t = 1 + (t - 1) / 2;  // AvgPool3d((2,1,1)) floors, omnitokenizer.py:909-914
     *T = t;
     *gh = h;
@@ -1134,6 +1188,11 @@ static int check_attention_grid(const char *who, const std::string &block, int g
         } else if (ch == 'w') {
             OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0 && gh == gw, "%s: token grid %dx%d not divisible by the 8x8 window",
                          who, gh, gw);
+        } else if (ch == 'n' || ch == 'r') {
+            OT_CHECK_ARG(gh == gw, "%s: Up block on a %dx%d grid (the reference assumes a square grid, attention.py:141)",
+                         who, gh, gw);
+            gh *= 2;
+            gw *= 2;
         } else {
             OT_CHECK_ARG(gh % 2 == 0 && gw % 2 == 0 && gh == gw, "%s: pooling block on a %dx%d grid", who, gh, gw);
             gh /= 2;
@@ -1160,7 +1219,12 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
     const int S = gh * gw, T = 1 + (F - 1) / pt;
     if (int rc = check_attention_grid("encode", c.enc_block, gh, gw)) return rc;
     const int64_t L = (int64_t)B * T * S;
-    if (int rc = ensure_workspace(e, L)) return rc;
+    {
+        int ph = gh, pw = gw;
+        int64_t peak = S;  // Up blocks grow the sequence: size the workspace for the largest grid on the way
+        (void)walk_enc_grid(c.enc_block, &ph, &pw, &peak);
+        if (int rc = ensure_workspace(e, (int64_t)B * T * peak)) return rc;
+    }
     if (int rc = reset_bounds(e, B, stream)) return rc;
     const char *names[2] = {"encoder.to_patch_emb_first_frame", "encoder.to_patch_emb"};
 

@@ -59,6 +59,11 @@ def _transformer_spec(prefix: str, block: str, cfg: OmniTokConfig, spatial_pos: 
             spec[f"{p}.1.pool.bias"] = (d,)
         elif c in "am":  # parameter-free AvgPool2d / MaxPool2d
             pass
+        elif c == "n":  # Up('n'): nn.Upsample(2, 'nearest'), reference attention.py:119-120
+            pass
+        elif c == "r":  # Up('r'): Upsample -> Rearrange -> Linear(dim, dim), reference attention.py:122-127
+            spec[f"{p}.1.up.2.weight"] = (d, d)
+            spec[f"{p}.1.up.2.bias"] = (d,)
         else:
             raise NotImplementedError(c)
         spec[f"{p}.3.0.weight"] = (d,)

@@ -205,6 +205,19 @@ def pooling(sd, p, x, kind):
     return F.linear(x.reshape(B, N // 4, 4 * C), sd[f"{p}.pool.weight"], sd[f"{p}.pool.bias"])
 
 
+def up(sd, p, x, kind):
+    """reference attention.py:116-150 Up.forward on [B, N, C] tokens of a sqrt(N) x sqrt(N) grid:
+    'n' nn.Upsample(2, 'nearest') -> [B, 4N, C]; 'r' the same followed by Linear(C, C) (+bias)."""
+    B, N, C = x.shape
+    H = W = int(math.sqrt(N))
+    y = x.view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+    y = F.interpolate(y, scale_factor=2, mode="nearest")
+    y = y.view(B, C, -1).transpose(1, 2).contiguous()  # 'n': :142; 'r': Rearrange('b c h w -> b (h w) c')
+    if kind == "r":
+        y = F.linear(y, sd[f"{p}.up.2.weight"], sd[f"{p}.up.2.bias"])
+    return y
+
+
 def transformer(sd, prefix, x, block, video_shape, cfg, is_spatial, causal, spatial_pos, taps=None):
     """reference attention.py:655-689 Transformer.forward: per block PEG(+res) -> attention(+res)
     -> FF(+res); final custom LayerNorm."""
@@ -218,13 +231,17 @@ def transformer(sd, prefix, x, block, video_shape, cfg, is_spatial, causal, spat
             x = window_attention(sd, f"{p}.1", x, cfg) + x
         elif c in "aml":
             x = pooling(sd, f"{p}.1", x, c)  # no residual, attention.py:674
+        elif c in "nr":
+            # Up blocks, no residual (attention.py:674). Encoder only: the reference DECODER raises on them
+            # (einops shape mismatch at omnitokenizer.py:1078, probed), decode() below rejects them
+            x = up(sd, f"{p}.1", x, c)
         else:
-            # 'n' / 'r' (Up) blocks: the reference decoder itself raises on them (einops shape
-            # mismatch at omnitokenizer.py:1078, probed), so there is nothing to restate
             raise NotImplementedError(c)
         x = feed_forward(sd, f"{p}.3", x) + x
         if c in "aml":  # attention.py:683-684
             video_shape = (video_shape[0], video_shape[1], video_shape[2] // 2, video_shape[3] // 2)
+        elif c in "nr":  # attention.py:686-687
+            video_shape = (video_shape[0], video_shape[1], video_shape[2] * 2, video_shape[3] * 2)
         if taps is not None:
             taps[f"{prefix}.layers.{i}"] = x
     return layer_norm(x, sd[f"{prefix}.norm_out.gamma"], sd[f"{prefix}.norm_out.beta"])

@@ -73,6 +73,11 @@ VARIANT_CASES = [
     ("var_defer_ts_r128_img", 2, "sdpa", dict(resolution=128, defer_spatial_pool=True, defer_temporal_pool=True),
      1, 1, 2),
     ("var_genup2_r64_vid", 2, "sdpa", dict(resolution=64, gen_upscale=2), 1, 5, 2),
+    # encoder-side Up blocks (reference attention.py:116-150, 640-645, 686): the latent grid doubles, the
+    # decoder (patch 8) then emits 2x the input resolution
+    ("var_up_n_r64_vid", 2, "sdpa", dict(resolution=64, enc_block="ttnw"), 1, 5, 2),
+    ("var_up_r_r64_img", 2, "sdpa", dict(resolution=64, enc_block="trtw"), 2, 1, 2),
+    ("var_up_r_pool_r128_vid", 2, "sdpa", dict(resolution=128, enc_block="artw"), 1, 5, 2),
 ]
 
 
@@ -367,6 +372,10 @@ def run_b32_case(name="s2_sdpa_r256_vid17_b32", stride=8):
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "up":  # only the Up-block variants
+        for c in VARIANT_CASES:
+            if c[0].startswith("var_up_"):
+                run_case(*c)
     if only in (None, "full"):
         for c in FULL_CASES:
             run_case(*c)

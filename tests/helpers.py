@@ -23,7 +23,7 @@ FULL_CASES = ["s2_sdpa_r256_vid17", "s1_legacy_r256_vid17"]
 
 VARIANT_CASES = ["var_pool_a_r128_vid", "var_pool_m_r128_img", "var_pool_l_r128_vid", "var_cnn_r128_img",
                  "var_cnn_r128_vid", "var_defer_t_r128_vid", "var_defer_s_r128_vid", "var_defer_ts_r128_img",
-                 "var_genup2_r64_vid"]
+                 "var_genup2_r64_vid", "var_up_n_r64_vid", "var_up_r_r64_img", "var_up_r_pool_r128_vid"]
 # external VectorQuantize: cosine-similarity codebook (l2_code) and Euclidean codebook (no l2_code)
 EXT_CASES = ["ext_s2_sdpa_r64_img", "ext_s2_sdpa_r64_vid", "ext_s1_legacy_r128_vid", "ext_euclid_s2_sdpa_r64_img",
              "ext_euclid_s2_sdpa_r64_vid"]

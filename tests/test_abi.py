@@ -84,10 +84,11 @@ def test_state_dict_contract(lib):
 def test_config_rejects_unbuilt_variants():
     from omnitokenizer_amd import make_args
     from omnitokenizer_amd.config import OmniTokConfig
-    # 'n'/'r' Up blocks make the reference decoder itself raise (omnitokenizer.py:1078); GroupNorm(32)
-    # over the cnn decoder's 3 channels cannot be constructed (base.py:274); the external VectorQuantize
-    # exists for codebook_type 'vq' only (omnitokenizer.py:139-140)
-    for bad in (dict(dec_block="tntt"), dict(dec_block="trtt"), dict(dec_block="tatt"), dict(enc_block="ttnw"),
+    # in the DECODER 'n'/'r' Up blocks make the reference itself raise (omnitokenizer.py:1078; in the encoder
+    # they run and are built, see below); GroupNorm(32) over the cnn decoder's 3 channels cannot be
+    # constructed (base.py:274); the external VectorQuantize exists for codebook_type 'vq' only
+    # (omnitokenizer.py:139-140)
+    for bad in (dict(dec_block="tntt"), dict(dec_block="trtt"), dict(dec_block="tatt"), dict(enc_block="ttxw"),
                 dict(patch_embed="cnn", norm_type="group"), dict(patch_embed="conv"),
                 dict(use_external_codebook=True, codebook_type="lfq"),
                 dict(use_external_codebook=True, use_vae=True), dict(dim_head=32)):
@@ -98,6 +99,9 @@ def test_config_rejects_unbuilt_variants():
     assert (c.enc_patch_size, c.enc_temporal_patch_size, c.dec_patch_size, c.enc_grid_divisor) == (4, 2, 8, 2)
     c = OmniTokConfig.from_args(make_args(2, patch_embed="cnn", defer_spatial_pool=True, enc_block="tawl"))
     assert (c.enc_patch_size, c.dec_patch_size, c.enc_grid_divisor) == (8, 8, 4)  # defer_* ignored for cnn
+    # encoder-side Up blocks (reference attention.py:116-150, 640-645): enc_block="ttnw" runs in the reference
+    c = OmniTokConfig.from_args(make_args(2, enc_block="trnw"))
+    assert (c.enc_grid_multiplier, c.enc_grid_divisor) == (4, 1)
 
 
 def test_vae_state_dict_contract(lib):

@@ -36,7 +36,9 @@ def test_oracle_end_to_end_matches_reference(name):
         ids = orc.encode(c.sd, c.x, c.is_image, c.cfg, taps=taps)
         recon = orc.decode(c.sd, c.ids, c.is_image, c.cfg)
     assert torch.equal(ids, c.ids), f"{(ids != c.ids).sum().item()} ids differ"
-    assert (taps["z"] - c.z).abs().max().item() < 2e-6
+    # fp32 noise only: ATen's blocked CPU SDPA (the reference) vs the oracle's explicit softmax; the largest
+    # observed is 2.3e-6 (var_up_r_r64_img, 256-token sequences after the Up block), |z| <= 1
+    assert (taps["z"] - c.z).abs().max().item() < 4e-6
     assert (c.strided(recon) - c.recon).abs().max().item() < 2e-5
     # flat ids decode identically (reference omnitokenizer.py:272-286)
     if c.is_image or c.cfg.resolution // c.cfg.patch_size == c.ids.shape[-1]:
