@@ -204,6 +204,28 @@ int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k, const floa
                          float *out, int64_t ldo, int Bn, int N, int heads,
                          const float *bias_table, int gh, int gw, omnitok_stream_t stream);
 
+/* fp16-split spatial attention (csrc/attn_h2.hip), the default of the engine ("attn_mode" 1): the same
+ * operator as omnitok_qk_prep + omnitok_attn_spatial (reference attention.py:417-483) on the fp16 matrix
+ * cores, every operand as an exact-scale fp16 hi|lo pair, three MFMA products per fp32 product, fp32
+ * accumulation and softmax.
+ *   omnitok_attn_pack: RoPE + l2norm + q/k scales exactly as omnitok_qk_prep, then q, k and v are written as
+ *     hi|lo planes in MFMA-fragment order: qp / kp / vp are rows*heads*64*4 bytes each (blocks of 32 tokens of
+ *     one head, 8 KiB).  q_bound >= max|q| (= scale * max|q_scale|), k_bound >= max|k| (= max|k_scale|);
+ *     v_bound (times v_bound_dev[v_bound_stride * clip] if given, clip = row / rows_per_clip) >= max|v| of the
+ *     rows of a clip.  n_tokens % 32 == 0.
+ *   omnitok_attn_spatial_h2: out[Bn*N, heads*64] = softmax(q k^T [+ bias]) v from the packed operands; the same
+ *     bounds must be passed (they define the power-of-two operand scales); seq_per_clip = sequences per clip
+ *     for v_bound_dev.  N % 64 == 0. */
+int omnitok_attn_pack(const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv, int64_t rows,
+                      int n_tokens, int heads, const float *cos, const float *sin, const float *q_scale,
+                      const float *k_scale, float scale, float q_bound, float k_bound, float v_bound,
+                      const float *v_bound_dev, int v_bound_stride, int64_t rows_per_clip, void *qp, void *kp,
+                      void *vp, omnitok_stream_t stream);
+int omnitok_attn_spatial_h2(const void *qp, const void *kp, const void *vp, float *out, int64_t ldo, int Bn, int N,
+                            int heads, float q_bound, float k_bound, float v_bound, const float *v_bound_dev,
+                            int v_bound_stride, int seq_per_clip, const float *bias_table, int gh, int gw,
+                            omnitok_stream_t stream);
+
 /* WindowAttention core (reference attention.py:266-286): qkv[Bn*N, 3*heads*64] from LN(x),
  * ws x ws (ws = 8) non-overlapping windows of the gh x gw grid, softmax(0.125 q k^T + bias) v.
  * bias_dense[heads, 64(kv), 64(q)] = relative_position_bias_table gathered by

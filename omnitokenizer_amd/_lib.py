@@ -58,6 +58,10 @@ _PROTOS = {
     "omnitok_rope_table": [c_int, c_int, c_float, P, P],
     "omnitok_qk_prep": [P, I64, P, I64, I64, c_int, c_int, P, P, P, P, c_float, P],
     "omnitok_attn_spatial": [P, I64, P, P, I64, P, I64, c_int, c_int, c_int, P, c_int, c_int, P],
+    "omnitok_attn_pack": [P, I64, P, P, I64, I64, c_int, c_int, P, P, P, P, c_float, c_float, c_float, c_float, P, c_int,
+                          I64, P, P, P, P],
+    "omnitok_attn_spatial_h2": [P, P, P, P, I64, c_int, c_int, c_int, c_float, c_float, c_float, P, c_int, c_int, P,
+                                c_int, c_int, P],
     "omnitok_attn_window": [P, I64, P, P, I64, c_int, c_int, c_int, c_int, P],
     "omnitok_attn_temporal": [P, I64, P, P, I64, P, I64, I64, c_int, c_int, P, P, c_float, c_int, P, P],
     "omnitok_pre_vq": [P, P, P, P, I64, c_int, c_int, c_int, P],

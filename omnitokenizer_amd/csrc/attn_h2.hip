@@ -1,0 +1,393 @@
+// Spatial attention on the fp16 matrix cores from 2-way splits of every operand ("h2" attention):
+//   * attn_pack          -- RoPE(2-D) + l2norm + q/k scale (reference attention.py:417-437), then Q, K and V are
+//                           written as fp16 hi|lo planes in MFMA-fragment order
+//   * attn_spatial_h2    -- full attention over N tokens, flash style (attention.py:439-483)
+//
+// Why: after the GEMMs moved to the fp16 pipe (gemm_h2.hip) the fp32-MFMA attention kernel was 21 % of the
+// C3 step at 110 TF.  The same operand split applies here with rigorous ranges for free: q and k are
+// l2-normalised (|q_d| <= 8 max|q_scale|, |k_d| <= max|k_scale|), P = exp(s - m) is in (0, 1], and V is bounded
+// per clip by the row-statistics pass (|V_j| <= ||x_row|| ||Wv_j||).
+//
+// Arithmetic.  Every operand element x (scaled by an exact power of two so that the bound maps to (2^14, 2^15])
+// is split  x = hi + lo + r,  hi = fp16(x),  lo = fp16(x - hi),  |r| <= 2^-22 |x|;  each product is accumulated
+// in fp32 as lo.hi' + hi.lo' + hi.hi' (three v_mfma_f32_32x32x16_f16; the dropped lo.lo' and r terms are below
+// 2^-21 |x y|).  The softmax itself (max, exp2, sum, rescale) is the fp32 code of attn_spatial.hip; P is scaled
+// by 2^14 before it is split (the factor cancels in O / l).  Error class: tests/test_gpu_attn_h2.py puts the
+// result within the fp32-MFMA kernel's distance of an fp64 reference.
+//
+// MFMA formulation: transposed like attn_spatial.hip so that each lane owns one query column --
+//     S^T[key][q] = K . Q^T      A = K fragment, B = Q fragment   (4 k-steps of 16 channels, 12 MFMA / 32x32)
+//     O^T[d][q]   = V^T . P^T    A = V fragment, B = P fragment   (2 k-steps of 16 keys x 2 d-halves, 12 MFMA)
+// In the 32x32 C/D layout lane l holds S^T rows 8 i + 4 (l >> 5) + r (i, r in 0..3) of column q = l & 31, and
+// the B operand of 32x32x16 wants from lane l eight consecutive k.  The key order inside a 16-key step is ours
+// to choose (the contraction runs over keys), so k-slot 8 h + 4 ii + r of step j is DEFINED to be key
+// 16 j + 8 ii + 4 h + r: P goes from the S^T accumulators to the second MFMA without any cross-lane move, and
+// the V planes are stored in exactly that order by attn_pack.
+//
+// Packed layouts (all in units of one 32-token block of one (sequence, head): 8 KiB = the fp32 size):
+//   Q, K:  [plane 2][k-step 4][h 2][token 32][8 halfs]   element = x[token][16 ks + 8 h + e]
+//   V:     [plane 2][j 2][d-half 2][h 2][d 32][8 halfs]  element = v[16 j + 8 (e >> 2) + 4 h + (e & 3)][32 mt + d]
+// so that every fragment is one conflict-free ds_read_b128 per lane (lanes 0-31 and 32-63 read two contiguous
+// 512-byte runs) and a K/V tile is staged by a linear copy.
+#include "h2_common.h"
+
+namespace omnitok {
+
+constexpr int PK_CHUNK = 528;  // LDS stride of a 512-byte run in attn_pack (16 B pad: conflict-free b64 stores)
+constexpr float P_SHIFT = 14.0f;  // P is scaled by 2^14 before the fp16 split
+
+struct PackParams {
+    const float *q; int64_t ldq;
+    const float *k; const float *v; int64_t ldkv;
+    int n_tokens, heads, nblk;       // tokens per sequence, heads, 32-token blocks per sequence
+    const float *cosT, *sinT, *q_scale, *k_scale;
+    float scale;                     // SDPA scale folded into q (reference attention.py:431-437)
+    float sq, sk;                    // power-of-two operand scales of q and k
+    float v_bound; const float *v_bound_dev; int v_bound_stride; int64_t rows_per_clip;
+    unsigned char *qp, *kp, *vp;
+};
+
+// One workgroup packs one 32-token block of one head (Q, K and V).
+__global__ __launch_bounds__(256) void attn_pack_kernel(PackParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * 16 * PK_CHUNK];
+    const int tid = threadIdx.x;
+    const int64_t unit = blockIdx.x;  // (seq, head, blk) with blk fastest
+    const int blk = (int)(unit % p.nblk);
+    const int head = (int)((unit / p.nblk) % p.heads);
+    const int64_t seq = unit / ((int64_t)p.nblk * p.heads);
+    const int64_t row0 = seq * p.n_tokens + (int64_t)blk * 32;
+
+    // ---- Q and K: one 16-lane row per token, 4 consecutive channels per lane (RoPE pairs are lane-local,
+    //      the l2 norm is a DPP all-reduce) -- the arithmetic of qk_prep_kernel, bit for bit ---------------
+    {
+        const int l16 = tid & 15, tk = tid >> 4;
+        const int ks = l16 >> 2, h = (l16 >> 1) & 1, e0 = 4 * (l16 & 1);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int tok = pass * 16 + tk;
+            const int64_t row = row0 + tok;
+            const int n = (int)(row % p.n_tokens);
+            float c0 = 1.f, c1 = 1.f, s0 = 0.f, s1 = 0.f;
+            if (p.cosT) {
+                c0 = p.cosT[n * 32 + 2 * l16]; c1 = p.cosT[n * 32 + 2 * l16 + 1];
+                s0 = p.sinT[n * 32 + 2 * l16]; s1 = p.sinT[n * 32 + 2 * l16 + 1];
+            }
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                const float *base = which == 0 ? p.q + row * p.ldq : p.k + row * p.ldkv;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(base + head * 64 + l16 * 4);
+                if (p.cosT) {  // (a + ib)(c + is) = (ac - bs) + i(as + bc), reference attention.py:65-69
+                    const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+                    v[0] = a0 * c0 - b0 * s0; v[1] = a0 * s0 + b0 * c0;
+                    v[2] = a1 * c1 - b1 * s1; v[3] = a1 * s1 + b1 * c1;
+                }
+                float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                ss = row16_allsum(ss);
+                const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, attention.py:24-25
+                const f32x4 sc = *reinterpret_cast<const f32x4 *>((which == 0 ? p.q_scale : p.k_scale) + l16 * 4);
+                const float mul = which == 0 ? p.scale : 1.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * inv * sc[e] * mul;
+                v *= which == 0 ? p.sq : p.sk;  // exact (power of two)
+                const f16x4 hh = __builtin_convertvector(v, f16x4);
+                const f16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), f16x4);
+                unsigned char *dst = lds + which * 16 * PK_CHUNK + (ks * 2 + h) * PK_CHUNK + tok * 16 + e0 * 2;
+                *reinterpret_cast<u32x2 *>(dst) = __builtin_bit_cast(u32x2, hh);
+                *reinterpret_cast<u32x2 *>(dst + 8 * PK_CHUNK) = __builtin_bit_cast(u32x2, ll);
+            }
+        }
+    }
+    // ---- V: lane = channel d, each wave takes two key quads (j, ii, h): four keys 16 j + 8 ii + 4 h + r --------
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const int mt = lane >> 5, dd = lane & 31;
+        float bound = p.v_bound;
+        if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (row0 / p.rows_per_clip)];
+        const float sv = h2_scale_of_bound(bound);
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi) {
+            const int quad = wave * 2 + qi;
+            const int j = quad >> 2, ii = (quad >> 1) & 1, h = quad & 1;
+            const int kl0 = 16 * j + 8 * ii + 4 * h;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = p.v[(row0 + kl0 + r) * p.ldkv + head * 64 + lane];
+            v *= sv;
+            const f16x4 hh = __builtin_convertvector(v, f16x4);
+            const f16x4 ll = __builtin_convertvector(v - __builtin_convertvector(hh, f32x4), f16x4);
+            unsigned char *dst = lds + 2 * 16 * PK_CHUNK + ((j * 2 + mt) * 2 + h) * PK_CHUNK + dd * 16 + ii * 8;
+            *reinterpret_cast<u32x2 *>(dst) = __builtin_bit_cast(u32x2, hh);
+            *reinterpret_cast<u32x2 *>(dst + 8 * PK_CHUNK) = __builtin_bit_cast(u32x2, ll);
+        }
+    }
+    __syncthreads();
+    // ---- linear 8 KiB stores of the three blocks --------------------------------------------------------
+    unsigned char *outs[3] = {p.qp, p.kp, p.vp};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int s = tid + 256 * i;  // 16-byte slot 0..511
+            const u32x4 w = *reinterpret_cast<const u32x4 *>(lds + (t * 16 + (s >> 5)) * PK_CHUNK + (s & 31) * 16);
+            *reinterpret_cast<u32x4 *>(outs[t] + unit * 8192 + (int64_t)s * 16) = w;
+        }
+}
+
+// -------------------------------------------------------------------------------------------
+// Attention.  Workgroup = 4 waves = 128 queries of one (sequence, head); each wave owns 32 queries.
+// K/V tiles of 64 keys (16 KiB + 16 KiB, already in fragment order) are staged global -> registers ->
+// LDS, double-buffered: the next tile's loads are in flight during the current tile's 48 MFMAs.
+// -------------------------------------------------------------------------------------------
+constexpr int AH_TILE_BYTES = 32768;            // K (2 blocks) | V (2 blocks)
+constexpr int AH_LDS_BYTES = 2 * AH_TILE_BYTES;
+
+struct AttnH2Params {
+    const unsigned char *qp, *kp, *vp;
+    float *out; int64_t ldo;
+    int N, heads, nqb, ngrp_real;
+    float s_unscale;  // 1 / (sq sk): undoes the q/k operand scales (exact power of two)
+    float v_bound; const float *v_bound_dev; int v_bound_stride; int seq_per_clip;
+    const float *bias_table;  // [(2gh-1)*(2gw-1), heads] or null
+    int gh, gw;
+};
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void attn_spatial_h2_kernel(AttnH2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    // XCD-aware mapping as attn_spatial_kernel: all query blocks of one (sequence, head) on one XCD
+    const int nqb = p.nqb;
+    const int b = blockIdx.x, jb = b >> 3;
+    const int grp = (jb / nqb) * 8 + (b & 7);
+    if (grp >= p.ngrp_real) return;
+    const int qb = jb % nqb, head = grp % p.heads, seq = grp / p.heads;
+    const int nblk = p.N / 32;
+    const int64_t unit0 = ((int64_t)seq * p.heads + head) * nblk;  // first 32-token block of this (sequence, head)
+    const bool wave_active = qb * 128 + wave * 32 < p.N;
+    const int qblk = wave_active ? qb * 4 + wave : 0;
+    const int q_local = qblk * 32 + r32;  // this lane's query
+
+    // Q fragments (B operand): plane, k-step -> 8 halfs of query r32, channels 16 ks + 8 hi + (0..7)
+    u32x4 qf[2][4];
+    {
+        const unsigned char *qb_ = p.qp + (unit0 + qblk) * 8192 + hi * 512 + r32 * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pl][ks] = *reinterpret_cast<const u32x4 *>(qb_ + (pl * 4 + ks) * 1024);
+    }
+    int qy = 0, qx = 0;
+    const float *btab = nullptr;
+    if constexpr (HAS_BIAS) {
+        qy = q_local / p.gw; qx = q_local % p.gw;
+        btab = p.bias_table + head;
+    }
+
+    // loader: a tile is 2 x 16 KiB of contiguous global memory; thread -> 16-byte slots tid + 256 i
+    const unsigned char *kg = p.kp + unit0 * 8192 + tid * 16;
+    const unsigned char *vg = p.vp + unit0 * 8192 + tid * 16;
+    u32x4 rk[4], rv[4];
+    auto gload = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rk[i] = *reinterpret_cast<const u32x4 *>(kg + (int64_t)t * 16384 + i * 4096);
+            rv[i] = *reinterpret_cast<const u32x4 *>(vg + (int64_t)t * 16384 + i * 4096);
+        }
+    };
+    auto lstore = [&](int buf) {
+        unsigned char *s = smem_h2 + buf * AH_TILE_BYTES + tid * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4 *>(s + i * 4096) = rk[i];
+            *reinterpret_cast<u32x4 *>(s + 16384 + i * 4096) = rv[i];
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    // logits = s_unscale * acc (+ bias); softmax in exp2 form
+    const float cs = HAS_BIAS ? 1.44269504088896340736f : p.s_unscale * 1.44269504088896340736f;
+
+    const int ntiles = p.N / 64;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) gload(t + 1);
+        const unsigned char *Ks = smem_h2 + buf * AH_TILE_BYTES + hi * 512 + r32 * 16;
+        const unsigned char *Vs = Ks + 16384;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            // ---- S^T = K . Q^T for 32 keys x 32 queries ---------------------------------------
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(Ks + sub * 8192 + ks * 1024));
+                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(Ks + sub * 8192 + (4 + ks) * 1024));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[1][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+            }
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + sub * 32 + mfma32_row(r, hi);
+                    const int ky = kv / p.gw, kx = kv % p.gw;
+                    st[r] = fmaf(st[r], p.s_unscale,
+                                 btab[((qy - ky + p.gh - 1) * (2 * p.gw - 1) + (qx - kx + p.gw - 1)) * p.heads]);
+                }
+            }
+            // ---- online softmax (per-lane query), in units of the raw accumulators -----------------
+            float mx = st[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+            mx = fmaxf(mx, swap32(mx));
+            const float m_new = fmaxf(m_run, mx);
+            const float mc = fmaf(m_new, cs, -P_SHIFT);  // exp2(s cs - mc) = 2^14 exp(logit - max)
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], cs, -mc));
+                ps += st[r];
+            }
+            ps += swap32(ps);
+            if (__any(m_new != m_run)) {  // wave-uniform; alpha == 1 for every lane otherwise
+                const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);  // 0 on the first tile
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            }
+            l_run += ps;
+            m_run = m_new;
+            // ---- split P (2 k-steps of 16 keys: accumulators 8 j .. 8 j + 7) and O^T += V^T . P^T ------
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = st[8 * j + e];
+                    pb[e] = st[8 * j + 4 + e];
+                }
+                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                const f16x8 ph = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 pl = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 vh = __builtin_bit_cast(
+                        f16x8, *reinterpret_cast<const u32x4 *>(Vs + sub * 8192 + (j * 2 + mt) * 1024));
+                    const f16x8 vl = __builtin_bit_cast(
+                        f16x8, *reinterpret_cast<const u32x4 *>(Vs + sub * 8192 + 4096 + (j * 2 + mt) * 1024));
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, ot[mt], 0, 0, 0);
+                }
+            }
+        }
+        if (t + 1 < ntiles) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: O[q][d] = O^T[d][q] / (l sv); lane owns q, d = mt*32 + 8g + 4hi + (0..3) -------------
+    if (!wave_active) return;
+    float bound = p.v_bound;
+    if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
+    const float inv_l = 1.0f / (l_run * h2_scale_of_bound(bound));  // the scale is a power of two: exact
+    float *orow = p.out + ((int64_t)seq * p.N + q_local) * p.ldo + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[d][g * 4 + e] * inv_l;
+            *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+        }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+// q_bound / k_bound: upper bounds of |q| (after RoPE, l2norm, q_scale and `scale`) and |k|: scale * max|q_scale|
+// and max|k_scale| (l2-normalised vectors have |x_d| <= 1).  v_bound (x v_bound_dev[stride * clip] when given):
+// upper bound of |v| for the rows of a clip (rows_per_clip consecutive rows).
+extern "C" int omnitok_attn_pack(const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv,
+                                 int64_t rows, int n_tokens, int heads, const float *cos, const float *sin,
+                                 const float *q_scale, const float *k_scale, float scale, float q_bound, float k_bound,
+                                 float v_bound, const float *v_bound_dev, int v_bound_stride, int64_t rows_per_clip,
+                                 void *qp, void *kp, void *vp, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(q && k && v && q_scale && k_scale && qp && kp && vp, "attn_pack: null pointer");
+    OT_CHECK_ARG((cos == nullptr) == (sin == nullptr), "attn_pack: cos/sin must both be given or both null");
+    OT_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(qp) &&
+                     aligned16(kp) && aligned16(vp), "attn_pack: unaligned");
+    OT_CHECK_ARG(n_tokens > 0 && n_tokens % 32 == 0 && rows % n_tokens == 0, "attn_pack: %lld rows of %d-token sequences",
+                 (long long)rows, n_tokens);
+    OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && v_bound > 0.0f, "attn_pack: operand bounds must be positive");
+    OT_CHECK_ARG(!v_bound_dev || (rows_per_clip > 0 && rows_per_clip % n_tokens == 0),
+                 "attn_pack: rows_per_clip must be a whole number of sequences");
+    if (rows == 0) return OMNITOK_OK;
+    PackParams p;
+    p.q = q; p.ldq = ldq; p.k = k; p.v = v; p.ldkv = ldkv; p.n_tokens = n_tokens; p.heads = heads;
+    p.nblk = n_tokens / 32; p.cosT = cos; p.sinT = sin; p.q_scale = q_scale; p.k_scale = k_scale; p.scale = scale;
+    p.sq = h2_scale_of_bound(q_bound); p.sk = h2_scale_of_bound(k_bound);
+    p.v_bound = v_bound; p.v_bound_dev = v_bound_dev; p.v_bound_stride = v_bound_stride;
+    p.rows_per_clip = v_bound_dev ? rows_per_clip : rows;
+    p.qp = static_cast<unsigned char *>(qp); p.kp = static_cast<unsigned char *>(kp);
+    p.vp = static_cast<unsigned char *>(vp);
+    const int64_t units = rows / 32 * heads;
+    OT_CHECK_ARG(units < (1ll << 31), "attn_pack: grid too large");
+    hipLaunchKernelGGL(attn_pack_kernel, dim3((unsigned)units), dim3(256), 0, stream, p);
+    OT_LAUNCH_CHECK("attn_pack");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_attn_spatial_h2(const void *qp, const void *kp, const void *vp, float *out, int64_t ldo, int Bn,
+                                       int N, int heads, float q_bound, float k_bound, float v_bound,
+                                       const float *v_bound_dev, int v_bound_stride, int seq_per_clip,
+                                       const float *bias_table, int gh, int gw, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(qp && kp && vp && out, "attn_spatial_h2: null pointer");
+    OT_CHECK_ARG(N % 64 == 0 && N > 0, "attn_spatial_h2: N=%d must be a multiple of 64 tokens", N);
+    OT_CHECK_ARG(!bias_table || gh * gw == N, "attn_spatial_h2: bias grid %dx%d != N=%d", gh, gw, N);
+    OT_CHECK_ARG(ldo % 4 == 0 && aligned16(qp) && aligned16(kp) && aligned16(vp) && aligned16(out),
+                 "attn_spatial_h2: unaligned");
+    OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && v_bound > 0.0f, "attn_spatial_h2: operand bounds must be positive");
+    OT_CHECK_ARG(!v_bound_dev || seq_per_clip > 0, "attn_spatial_h2: seq_per_clip");
+    OT_CHECK_ARG((int64_t)heads * Bn * ((N + 127) / 128) < (1ll << 31) - 8, "attn_spatial_h2: grid too large");
+    if (Bn == 0) return OMNITOK_OK;
+    AttnH2Params p;
+    p.qp = static_cast<const unsigned char *>(qp); p.kp = static_cast<const unsigned char *>(kp);
+    p.vp = static_cast<const unsigned char *>(vp);
+    p.out = out; p.ldo = ldo; p.N = N; p.heads = heads;
+    p.s_unscale = 1.0f / (h2_scale_of_bound(q_bound) * h2_scale_of_bound(k_bound));
+    p.v_bound = v_bound; p.v_bound_dev = v_bound_dev; p.v_bound_stride = v_bound_stride;
+    p.seq_per_clip = v_bound_dev ? seq_per_clip : (Bn > 0 ? Bn : 1);
+    p.bias_table = bias_table; p.gh = gh; p.gw = gw;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2_kernel<false>), AH_LDS_BYTES)) return rc;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2_kernel<true>), AH_LDS_BYTES)) return rc;
+    p.nqb = (N + 127) / 128;
+    const int ngrp = ((heads * Bn + 7) / 8) * 8;
+    p.ngrp_real = heads * Bn;
+    dim3 grid((unsigned)((int64_t)ngrp * p.nqb));
+    if (bias_table)
+        hipLaunchKernelGGL(attn_spatial_h2_kernel<true>, grid, dim3(256), AH_LDS_BYTES, stream, p);
+    else
+        hipLaunchKernelGGL(attn_spatial_h2_kernel<false>, grid, dim3(256), AH_LDS_BYTES, stream, p);
+    OT_LAUNCH_CHECK("attn_spatial_h2");
+    return OMNITOK_OK;
+}

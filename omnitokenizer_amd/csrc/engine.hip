@@ -47,6 +47,7 @@ struct LayerT {  // 't' block (+ FF)
     const float *q_scale, *k_scale;
     float ln_bound = 0.0f;  // >= max |LN(x)|            (ranges for the fp16-split GEMM, gemm_h2.hip)
     float vnorm = 0.0f;     // max_j ||Wv_j||_2: |attention output| <= max_rows ||x||_2 * vnorm
+    float q_amax = 0.0f, k_amax = 0.0f;  // max |q_scale|, max |k_scale|: ranges of the l2-normalised q / k (attn_h2.hip)
     std::string bias_prefix;  // spatial_rel_pos_bias prefix ("" if none)
 };
 struct LayerW {  // 'w' block
@@ -395,6 +396,8 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
                 return rc;
             L.t.q_scale = W(e, p + ".1.q_scale");
             L.t.k_scale = W(e, p + ".1.k_scale");
+            if (int rc = weight_range(e, L.t.q_scale, c.dim_head, 1, c.dim_head, nullptr, &L.t.q_amax, stream)) return rc;
+            if (int rc = weight_range(e, L.t.k_scale, c.dim_head, 1, c.dim_head, nullptr, &L.t.k_amax, stream)) return rc;
             L.t.bias_prefix = (spatial && c.legacy_attention && !c.spatial_rope) ? p + ".1.spatial_rel_pos_bias" : "";
         } else if (block[i] == 'l') {
             L.pool_w = W(e, p + ".1.pool.weight");
@@ -636,6 +639,11 @@ static int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, 
 // All three have fp32-class error (tests/test_gpu_ops.py).  The mode is process-wide and the per-element
 // arithmetic of each kernel is independent of the problem / tile size (batch-size independence).
 int g_gemm_mode = 2;
+// Spatial attention arithmetic.  "attn_mode"
+//   1 (default): fp16-split operands on the fp16 MFMA (attn_h2.hip) wherever the per-clip ranges of the row
+//      statistics pass exist (the split-operand GEMM path) and the q/k scales are usable;
+//   0: the fp32-input MFMA kernel of attn_spatial.hip.
+int g_attn_mode = 1;
 
 static bool x3_ok(int N, int K, int flags) {
     return g_gemm_mode >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
@@ -794,15 +802,30 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 const float *cosp = nullptr, *sinp = nullptr;
                 if (c.spatial_rope)
                     if (int rc = get_rope(e, S, &cosp, &sinp, stream)) return rc;
-                OT_RUN("qk_prep", 4.0 * L * D * 4.0,
-                       omnitok_qk_prep(Q, ldq, KV, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
-                                       stream));
                 const float *bias = nullptr;
                 if (!ly.t.bias_prefix.empty())
                     if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
-                OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
-                       omnitok_attn_spatial(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, B * T, S, heads, bias, gh, gw,
-                                            stream));
+                const float qb = 1.01f * 8.0f * ly.t.q_amax, kb = 1.01f * ly.t.k_amax;
+                if (g_attn_mode == 1 && bs && qb > 0.0f && kb > 0.0f && ly.t.vnorm > 0.0f && qb < 1e30f && kb < 1e30f) {
+                    // fp16-split attention: Q, K (RoPE + l2norm + scales applied) and V as hi|lo planes in MFMA
+                    // fragment order (Y, HD are free here); |V| <= ||x_row|| ||Wv_j|| per clip from the row statistics
+                    unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
+                    unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
+                    unsigned char *vp = kp + (size_t)L * D * 4;
+                    OT_RUN("qk_prep", 6.0 * L * D * 4.0,
+                           omnitok_attn_pack(Q, ldq, KV, KV + D, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale,
+                                             8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp, vp, stream));
+                    OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
+                           omnitok_attn_spatial_h2(qp, kp, vp, e->AO.p, D, B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev,
+                                                   2, T, bias, gh, gw, stream));
+                } else {
+                    OT_RUN("qk_prep", 4.0 * L * D * 4.0,
+                           omnitok_qk_prep(Q, ldq, KV, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
+                                           stream));
+                    OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
+                           omnitok_attn_spatial(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, B * T, S, heads, bias, gh, gw,
+                                                stream));
+                }
             } else {
                 const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
                 OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
@@ -885,6 +908,7 @@ static int ensure_workspace(omnitok_engine *e, int64_t L) {
     const int kmax = kenc > kdec ? kenc : kdec;
     int64_t hdw = e->inner_pad;
     if (kmax > hdw) hdw = kmax;
+    if (2 * D > hdw) hdw = 2 * D;  // packed K | V of the fp16-split attention
     if (int rc = ensure(e->X, L * D)) return rc;
     if (int rc = ensure(e->X2, L * D)) return rc;
     if (int rc = ensure(e->Y, L * D)) return rc;

@@ -24,15 +24,12 @@
 // pre-split / pre-scaled once (omnitok_h2_pack_weight: [N][K/8][hi|lo][8] fp16, the same 4 B per
 // element as the fp32 weight) so only the A operand costs VALU work in the loop.
 #include "gemm_x_common.h"
+#include "h2_common.h"
 
 #include <type_traits>
 
 namespace omnitok {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 extern int g_gemm_gn;
 int g_h2_tile = 0;  // "h2_tile": 0 auto, 1 256x256, 3 128x128, 4 64x64 / 64x128 (A/B measurements)
@@ -69,17 +66,6 @@ struct H2Cfg {
     static constexpr int LN_TAB = 2 * 512 * 4;
     static_assert(TM % RPP == 0 && TN % RPP == 0, "loader passes");
 };
-
-// power-of-two scale s = 2^-e with bound * s in (2^14, 2^15]  (bound <= 0 or non-finite: s = 1)
-__device__ __forceinline__ float h2_scale_of_bound(float bound) {
-    if (!(bound > 0.0f) || !(bound < 3.0e38f)) return 1.0f;
-    int x;
-    (void)frexpf(bound, &x);  // bound = m * 2^x, m in [0.5, 1)  ->  bound <= 2^x
-    int e = x - 15;
-    if (e > 100) e = 100;
-    if (e < -100) e = -100;
-    return ldexpf(1.0f, -e);
-}
 
 // DBG (measurement builds only, wrong results): 1 skip the split arithmetic, 2 skip the LDS stores of the
 // K loop, 4 skip the global loads of the K loop, 8 skip the per-step barrier

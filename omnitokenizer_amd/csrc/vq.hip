@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
 
     const int64_t row_base = (int64_t)blockIdx.x * VQ_ROWS_PER_BLOCK + wave * VQ_ROWS_PER_WAVE;
     float xb[2][4], xx[2], best[2];
-    int bidx[2];
+    f32x4 zlo[2], zhi[2];  // 2 z of the lane's rows (all 8 channels): the end-of-sweep rescan needs the full row
+    int btile[2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         int64_t row = row_base + g * 32 + r32;
@@ -95,15 +96,24 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(hi4[k], hi4[k]));
         xx[g] = MODE == VQ_COS ? 0.0f : acc;
+        zlo[g] = lo * 2.0f;  // exact
+        zhi[g] = hi4 * 2.0f;
         // k = 2s + hi for MFMA step s
-        xb[g][0] = 2.0f * (hi ? lo[1] : lo[0]);
-        xb[g][1] = 2.0f * (hi ? lo[3] : lo[2]);
-        xb[g][2] = 2.0f * (hi ? hi4[1] : hi4[0]);
-        xb[g][3] = 2.0f * (hi ? hi4[3] : hi4[2]);
+        xb[g][0] = hi ? zlo[g][1] : zlo[g][0];
+        xb[g][1] = hi ? zlo[g][3] : zlo[g][2];
+        xb[g][2] = hi ? zhi[g][1] : zhi[g][0];
+        xb[g][3] = hi ? zhi[g][3] : zhi[g][2];
         best[g] = INFINITY;
-        bidx[g] = 0;
+        btile[g] = t0;
     }
+    auto dist = [&](float xxg, float dot, float ee) {
+        if (MODE == VQ_EUCLID)  // + 0.0f: sqrt(-0.0) = -0.0 must not order below +0.0 in the split key
+            return __fadd_rn(__fsqrt_rn(fmaxf(__fsub_rn(__fadd_rn(xxg, ee), dot), 0.0f)), 0.0f);
+        return __fadd_rn(__fsub_rn(xxg, dot), ee);
+    };
 
+    // Sweep: per 32-code tile only the lane's minimum distance (v_min3 tree, ~2.5 VALU per element instead of
+    // the 5 of a running (value, index) pair) and the tile that holds it; strict '<' keeps the FIRST tile of a tie.
     const f32x4 *pk = reinterpret_cast<const f32x4 *>(packed) + lane;
     f32x4 a_next = pk[(int64_t)t0 * 64];
     for (int t = t0; t < t1; ++t) {
@@ -119,27 +129,57 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xb[g][s], acc[g], 0, 0, 0);
         }
         const int cbase = t * 32 + 4 * hi;
+        float tmin[2] = {INFINITY, INFINITY};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 e4 = MODE == VQ_COS ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
                                  : *reinterpret_cast<const f32x4 *>(ee_s + cbase - c0 + 8 * q);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int code = cbase + 8 * q + e;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    float d;
-                    if (MODE == VQ_EUCLID)  // + 0.0f: sqrt(-0.0) = -0.0 must not order below +0.0 in the split key
-                        d = __fadd_rn(__fsqrt_rn(fmaxf(__fsub_rn(__fadd_rn(xx[g], e4[e]), acc[g][q * 4 + e]), 0.0f)), 0.0f);
-                    else
-                        d = __fadd_rn(__fsub_rn(xx[g], acc[g][q * 4 + e]), e4[e]);
-                    if (d < best[g]) {
-                        best[g] = d;
-                        bidx[g] = code;
-                    }
-                }
+            for (int g = 0; g < 2; ++g) {
+                const float d0 = dist(xx[g], acc[g][q * 4 + 0], e4[0]), d1 = dist(xx[g], acc[g][q * 4 + 1], e4[1]);
+                const float d2 = dist(xx[g], acc[g][q * 4 + 2], e4[2]), d3 = dist(xx[g], acc[g][q * 4 + 3], e4[3]);
+                tmin[g] = fminf(fminf(tmin[g], d0), d1);
+                tmin[g] = fminf(fminf(tmin[g], d2), d3);
             }
         }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            if (tmin[g] < best[g]) {
+                best[g] = tmin[g];
+                btile[g] = t;
+            }
+    }
+    // Resolve the index: redo the lane's 16 codes of its winning tile with the same arithmetic -- the fp32 MFMA is
+    // bitwise the k-ordered fmaf chain from 0 (oracle/vq_argmin.c), so the scalar chain reproduces the distances --
+    // in increasing code order with a strict '<' (first minimum inside the tile).
+    int bidx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int t = btile[g];
+        const float *pt = packed + (int64_t)t * 256;  // float index of code r (half hh) step s: (hh*32 + r)*4 + s
+        float bd = INFINITY;
+        int bi = t * 32 + 4 * hi;
+        const float zz[8] = {zlo[g][0], zlo[g][1], zlo[g][2], zlo[g][3], zhi[g][0], zhi[g][1], zhi[g][2], zhi[g][3]};
+#pragma unroll 4
+        for (int qe = 0; qe < 16; ++qe) {
+            const int r = 8 * (qe >> 2) + (qe & 3) + 4 * hi;  // row of accumulator register qe inside the tile
+            const f32x4 ev = *reinterpret_cast<const f32x4 *>(pt + r * 4);        // k = 0, 2, 4, 6
+            const f32x4 od = *reinterpret_cast<const f32x4 *>(pt + (32 + r) * 4);  // k = 1, 3, 5, 7
+            float dot = 0.0f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                dot = __fmaf_rn(ev[s], zz[2 * s], dot);
+                dot = __fmaf_rn(od[s], zz[2 * s + 1], dot);
+            }
+            const float ee = MODE == VQ_COS ? 0.0f : ee_s[t * 32 + r - c0];
+            const float d = dist(xx[g], dot, ee);
+            if (d < bd) {
+                bd = d;
+                bi = t * 32 + r;
+            }
+        }
+        best[g] = bd;
+        bidx[g] = bi;
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {

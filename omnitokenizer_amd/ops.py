@@ -249,6 +249,8 @@ def rope_table(n_tokens, dim_head=64, theta=10000.0):
 def qk_prep_(q, k, n_tokens, heads, q_scale, k_scale, cos=None, sin=None, scale=8.0):
     """In place on q [rows, heads*64] and k (a [rows, heads*64] view with row stride k.stride(0))."""
     assert q.dim() == 2 and k.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1
+    _opt(cos, "cos", n_tokens * 32)
+    _opt(sin, "sin", n_tokens * 32)
     check(_lib.load().omnitok_qk_prep(_p(q), q.stride(0), _p(k), k.stride(0), q.shape[0], n_tokens, heads, _p(cos),
                                       _p(sin), _p(_req(q_scale, "q_scale")), _p(_req(k_scale, "k_scale")), scale,
                                       _stream()), "qk_prep")
@@ -260,6 +262,42 @@ def attn_spatial(q, k, v, Bn, N, heads, bias_table=None, gh=0, gw=0):
     out = torch.empty(q.shape[0], heads * 64, device=q.device, dtype=torch.float32)
     check(_lib.load().omnitok_attn_spatial(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), _p(out), heads * 64, Bn, N,
                                            heads, _p(bias_table), gh, gw, _stream()), "attn_spatial")
+    return out
+
+
+def attn_pack(q, k, v, n_tokens, heads, q_scale, k_scale, cos=None, sin=None, scale=8.0, v_bound=None,
+              v_bound_dev=None, v_bound_stride=1, rows_per_clip=0):
+    """fp16-split attention operands (csrc/attn_h2.hip): RoPE + l2norm + scales as qk_prep_, then q, k, v as hi|lo
+    planes in MFMA fragment order.  Returns (packed, bounds) for attn_spatial_h2.  v_bound: upper bound of |v|
+    (default: measured max|v|), multiplied per clip by v_bound_dev[v_bound_stride * clip] when given."""
+    assert q.dim() == 2 and k.dim() == 2 and q.stride(1) == 1 and k.stride(1) == 1 and k.stride(0) == v.stride(0)
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if t.device.type != "cuda" or t.dtype != torch.float32:
+            raise RuntimeError(f"{n}: expected a float32 CUDA tensor (no CPU path)")
+    q_scale, k_scale = _req(q_scale, "q_scale"), _req(k_scale, "k_scale")
+    rows = q.shape[0]
+    q_bound = 1.01 * scale * float(q_scale.abs().max())
+    k_bound = 1.01 * float(k_scale.abs().max())
+    if v_bound is None:
+        v_bound = 1.01 * float(v.abs().max()) if v_bound_dev is None else 1.01
+    packed = torch.empty(3, rows * heads * 64, device=q.device, dtype=torch.int32)
+    _opt(v_bound_dev, "v_bound_dev")
+    _opt(cos, "cos", n_tokens * 32)
+    _opt(sin, "sin", n_tokens * 32)
+    check(_lib.load().omnitok_attn_pack(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), rows, n_tokens, heads, _p(cos),
+                                        _p(sin), _p(q_scale), _p(k_scale), scale, q_bound, k_bound, v_bound,
+                                        _p(v_bound_dev), v_bound_stride, rows_per_clip, _p(packed[0]), _p(packed[1]),
+                                        _p(packed[2]), _stream()), "attn_pack")
+    return packed, (q_bound, k_bound, v_bound)
+
+
+def attn_spatial_h2(packed, bounds, Bn, N, heads, bias_table=None, gh=0, gw=0, v_bound_dev=None, v_bound_stride=1,
+                    seq_per_clip=0):
+    """softmax(q k^T [+ bias]) v on the fp16 matrix cores from the operands of attn_pack -> [Bn*N, heads*64]."""
+    out = torch.empty(Bn * N, heads * 64, device=packed.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_spatial_h2(_p(packed[0]), _p(packed[1]), _p(packed[2]), _p(out), heads * 64, Bn, N,
+                                              heads, bounds[0], bounds[1], bounds[2], _p(v_bound_dev), v_bound_stride,
+                                              seq_per_clip, _p(bias_table), gh, gw, _stream()), "attn_spatial_h2")
     return out
 
 

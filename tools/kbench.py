@@ -88,6 +88,15 @@ def main():
         kv[:, :D] = torch.nn.functional.normalize(kv[:, :D].reshape(L, 8, 64), dim=-1).reshape(L, D)
         ms = timeit(lambda: ops.attn_spatial(q, kv[:, :D], kv[:, D:], L // 1024, 1024, 8), a.iters)
         res["attn_spatial"] = (ms, 4.0 * (L // 1024) * 8 * 1024 * 1024 * 64 / ms / 1e9, "TF")
+    if want("attn_h2"):
+        q, kv = r(L, D), r(L, 2 * D)
+        qs = torch.ones(64, device="cuda")
+        cos, sin = (t.cuda() for t in ops.rope_table(1024))
+        ms = timeit(lambda: ops.attn_pack(q, kv[:, :D], kv[:, D:], 1024, 8, qs, qs, cos, sin, v_bound=8.0), a.iters)
+        res["attn_pack"] = (ms, 6.0 * L * D * 4 / ms / 1e6, "GB/s")
+        packed, bounds = ops.attn_pack(q, kv[:, :D], kv[:, D:], 1024, 8, qs, qs, cos, sin, v_bound=8.0)
+        ms = timeit(lambda: ops.attn_spatial_h2(packed, bounds, L // 1024, 1024, 8), a.iters)
+        res["attn_spatial_h2"] = (ms, 4.0 * (L // 1024) * 8 * 1024 * 1024 * 64 / ms / 1e9, "TF")
     if want("attn_window"):
         qkv = r(L, 3 * D)
         bias = r(8, 64, 64)
