@@ -276,6 +276,15 @@ int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_cod
                             const float *w, const float *b, float *tok, int64_t n, int D,
                             int *err_flag, omnitok_stream_t stream);
 
+/* The same operator as a table: omnitok_dequant_table builds table[n_codes, D] = E w^T + b with the kernel of
+ * omnitok_dequant_post_vq on ids 0..n_codes-1 (rows bit-identical; scratch_ids: n_codes int64 of device scratch),
+ * omnitok_gather_rows then is tok[n, :] = table[ids[n], :] with the same out-of-range check.  The engine builds
+ * the table once at finalize and decodes by gather. */
+int omnitok_dequant_table(const float *codebook, int n_codes, int cdim, const float *w, const float *b,
+                          float *table, int D, int64_t *scratch_ids, omnitok_stream_t stream);
+int omnitok_gather_rows(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n, int D,
+                        int *err_flag, omnitok_stream_t stream);
+
 /* --use_vae posterior sample (reference modules/vae.py:4-17 on top of pre_vq_conv with 2*cdim
  * outputs): h = x[n,:] . w[2*cdim, D]^T + b, n = B*thw rows in (b, thw) order;
  * z[B,cdim,thw] = h[:, :cdim] + exp(0.5*clamp(h[:, cdim:], -30, 20)) * noise[B,cdim,thw]

@@ -318,6 +318,196 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2_kernel(AttnH2Params p)
         }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Variant 2 ("attn_h2_variant" 1, the default): the same arithmetic, restructured around what the first kernel
+// measured (matrix pipe ~35 % busy: every wave alternates MFMA bursts with ~140-instruction softmax bursts):
+//   * K/V tiles go global -> LDS directly (global_load_lds_dwordx4: the packed layout is lane-linear), no
+//     staging registers and no ds_write pass;
+//   * inside a 64-key tile the two 32-key sub-blocks are software-pipelined: S^T of sub-block b is issued
+//     before the softmax of sub-block a, and the P.V MFMAs of a before the softmax of b, so the VALU work of one
+//     sub-block sits in the shadow of the other's MFMAs within ONE wave (regions without branches);
+//   * the two half-wave reductions use v_permlane32_swap instead of ds_bpermute.
+// -------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glob_void_t;
+
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256, 2) void attn_spatial_h2p_kernel(AttnH2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int nqb = p.nqb;
+    const int b = blockIdx.x, jb = b >> 3;
+    const int grp = (jb / nqb) * 8 + (b & 7);
+    if (grp >= p.ngrp_real) return;
+    const int qb = jb % nqb, head = grp % p.heads, seq = grp / p.heads;
+    const int nblk = p.N / 32;
+    const int64_t unit0 = ((int64_t)seq * p.heads + head) * nblk;
+    const bool wave_active = qb * 128 + wave * 32 < p.N;
+    const int qblk = wave_active ? qb * 4 + wave : 0;
+    const int q_local = qblk * 32 + r32;
+
+    u32x4 qf[2][4];
+    {
+        const unsigned char *qb_ = p.qp + (unit0 + qblk) * 8192 + hi * 512 + r32 * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pl][ks] = *reinterpret_cast<const u32x4 *>(qb_ + (pl * 4 + ks) * 1024);
+    }
+    int qy = 0, qx = 0;
+    const float *btab = nullptr;
+    if constexpr (HAS_BIAS) {
+        qy = q_local / p.gw; qx = q_local % p.gw;
+        btab = p.bias_table + head;
+    }
+
+    // tile t = 16 KiB of K + 16 KiB of V, contiguous in global memory and lane-linear in LDS: wave w moves the
+    // 1 KiB chunks 4 i + w (i = 0..3) of each half
+    const unsigned char *kg = p.kp + unit0 * 8192 + wave * 1024 + lane * 16;
+    const unsigned char *vg = p.vp + unit0 * 8192 + wave * 1024 + lane * 16;
+    auto dma = [&](int t, int buf) {
+        unsigned char *s = smem_h2 + buf * AH_TILE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(kg + (int64_t)t * 16384 + i * 4096),
+                                             (lds_void_t *)(s + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(vg + (int64_t)t * 16384 + i * 4096),
+                                             (lds_void_t *)(s + 16384 + i * 4096), 16, 0, 0);
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float cs = HAS_BIAS ? 1.44269504088896340736f : p.s_unscale * 1.44269504088896340736f;
+
+    const int ntiles = p.N / 64;
+    dma(0, 0);
+    __syncthreads();  // (the compiler drains vmcnt before the barrier)
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) dma(t + 1, buf ^ 1);
+        const unsigned char *Ks = smem_h2 + buf * AH_TILE_BYTES + hi * 512 + r32 * 16;
+        const unsigned char *Vs = Ks + 16384;
+
+        auto qk = [&](int sub) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(Ks + sub * 8192 + ks * 1024));
+                const f16x8 kl = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(Ks + sub * 8192 + (4 + ks) * 1024));
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[1][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+            }
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 64 + sub * 32 + mfma32_row(r, hi);
+                    const int ky = kv / p.gw, kx = kv % p.gw;
+                    st[r] = fmaf(st[r], p.s_unscale,
+                                 btab[((qy - ky + p.gh - 1) * (2 * p.gw - 1) + (qx - kx + p.gw - 1)) * p.heads]);
+                }
+            }
+            return st;
+        };
+        // online softmax of one sub-block: updates m_run / l_run, returns alpha (1 when the maximum did not grow)
+        // and P as hi|lo fp16 fragments of the two 16-key steps
+        auto softmax = [&](f32x16 &st, f16x8 (&ph)[2], f16x8 (&pl)[2]) {
+            float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+            mx = halves_max(fmaxf(mx, st[15]));
+            const float m_new = fmaxf(m_run, mx);
+            const float mc = fmaf(m_new, cs, -P_SHIFT);
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], cs, -mc));
+                ps += st[r];
+            }
+            ps = halves_sum(ps);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);  // 1 if unchanged, 0 on the first block
+            l_run = fmaf(l_run, alpha, ps);
+            m_run = m_new;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = st[8 * j + e];
+                    pb[e] = st[8 * j + 4 + e];
+                }
+                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                ph[j] = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                pl[j] = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            return alpha;
+        };
+        auto rescale = [&](float alpha) {
+            if (__any(alpha != 1.0f)) {  // wave-uniform branch; exact: alpha == 1 for every lane otherwise
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            }
+        };
+        auto pv = [&](int sub, const f16x8 (&ph)[2], const f16x8 (&pl)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 vh = __builtin_bit_cast(
+                        f16x8, *reinterpret_cast<const u32x4 *>(Vs + sub * 8192 + (j * 2 + mt) * 1024));
+                    const f16x8 vl = __builtin_bit_cast(
+                        f16x8, *reinterpret_cast<const u32x4 *>(Vs + sub * 8192 + 4096 + (j * 2 + mt) * 1024));
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[j], ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[j], ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[j], ot[mt], 0, 0, 0);
+                }
+        };
+
+        f16x8 pha[2], pla[2], phb[2], plb[2];
+        f32x16 sa = qk(0);
+        f32x16 sb = qk(1);                       // S^T(b) MFMAs ...
+        const float alpha_a = softmax(sa, pha, pla);   // ... beside the softmax of a
+        rescale(alpha_a);
+        pv(0, pha, pla);                         // P.V(a) MFMAs ...
+        const float alpha_b = softmax(sb, phb, plb);   // ... beside the softmax of b
+        rescale(alpha_b);
+        pv(1, phb, plb);
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    float bound = p.v_bound;
+    if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
+    const float inv_l = 1.0f / (l_run * h2_scale_of_bound(bound));
+    float *orow = p.out + ((int64_t)seq * p.N + q_local) * p.ldo + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[d][g * 4 + e] * inv_l;
+            *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+        }
+}
+
+int g_attn_h2_variant = 1;  // "attn_h2_variant": 1 pipelined + LDS-DMA kernel (default), 0 the first kernel
+
 }  // namespace omnitok
 
 using namespace omnitok;
@@ -384,7 +574,14 @@ extern "C" int omnitok_attn_spatial_h2(const void *qp, const void *kp, const voi
     const int ngrp = ((heads * Bn + 7) / 8) * 8;
     p.ngrp_real = heads * Bn;
     dim3 grid((unsigned)((int64_t)ngrp * p.nqb));
-    if (bias_table)
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<false>), AH_LDS_BYTES)) return rc;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<true>), AH_LDS_BYTES)) return rc;
+    if (g_attn_h2_variant == 1) {
+        if (bias_table)
+            hipLaunchKernelGGL(attn_spatial_h2p_kernel<true>, grid, dim3(256), AH_LDS_BYTES, stream, p);
+        else
+            hipLaunchKernelGGL(attn_spatial_h2p_kernel<false>, grid, dim3(256), AH_LDS_BYTES, stream, p);
+    } else if (bias_table)
         hipLaunchKernelGGL(attn_spatial_h2_kernel<true>, grid, dim3(256), AH_LDS_BYTES, stream, p);
     else
         hipLaunchKernelGGL(attn_spatial_h2_kernel<false>, grid, dim3(256), AH_LDS_BYTES, stream, p);

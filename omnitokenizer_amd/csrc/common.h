@@ -87,6 +87,19 @@ __device__ __forceinline__ float wave_allsum(float v) {
 // value held by the partner lane (lane ^ 32)
 __device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32); }
 
+// all-reduce over the two 32-lane halves of a wave (lane l with lane l ^ 32) through v_permlane32_swap (gfx950):
+// no LDS crossbar round trip.  r[0] = value of lanes 0-31 in both halves, r[1] = value of lanes 32-63.
+__device__ __forceinline__ float halves_max(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)r[0]), __builtin_bit_cast(float, (unsigned)r[1]));
+}
+__device__ __forceinline__ float halves_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
 // row index inside a 32x32 MFMA C/D tile for accumulator register r of a lane in half `hi`
 // (cdna guide section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31)
 __device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

@@ -111,6 +111,7 @@ struct omnitok_engine {
     const float *px_w[2] = {nullptr, nullptr}, *px_b[2] = {nullptr, nullptr};
     // derived
     float *cb_packed = nullptr, *cb_ee = nullptr, *alibi = nullptr;
+    float *dq_table = nullptr;  // [n_codes, dim] = E . post_vq^T + b (decode = row gather)
     std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
     std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
     // workspace
@@ -1136,6 +1137,13 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
         if (int rc = alloc_f(e, &e->cb_ee, c.n_codes)) return rc;
         if (int rc = omnitok_vq_prepare(W(e, k_embed(c)), c.n_codes, 8, e->cb_packed, e->cb_ee, stream))
             return rc;
+        // F.embedding + post_vq_conv as one table (reference omnitokenizer.py:270, 156-160)
+        float *scratch;
+        if (int rc = alloc_f(e, &e->dq_table, (int64_t)c.n_codes * c.dim)) return rc;
+        if (int rc = alloc_f(e, &scratch, (int64_t)c.n_codes * 2)) return rc;
+        if (int rc = omnitok_dequant_table(W(e, k_embed(c)), c.n_codes, 8, W(e, k_post_w(c)), W(e, k_post_b(c)),
+                                           e->dq_table, c.dim, reinterpret_cast<int64_t *>(scratch), stream))
+            return rc;
     }
     {
         // ALiBi slopes, reference attention.py:506-517 (_get_slopes)
@@ -1349,8 +1357,7 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
                    omnitok_vq_argmin_cdist(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
         if (emb_out)  // eval: quantize = embed[ids] -> project_out, no straight-through term; [B,T',h,w,dim]
             OT_RUN("dequant_post_vq", (double)L * D * 4.0,
-                   omnitok_dequant_post_vq(ids_out, W(e, k_embed(c)), c.n_codes, 8, W(e, k_post_w(c)), W(e, k_post_b(c)),
-                                           emb_out, L, D, nullptr, stream));
+                   omnitok_gather_rows(ids_out, e->dq_table, c.n_codes, emb_out, L, D, nullptr, stream));
     } else {
         OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
                omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
@@ -1392,9 +1399,8 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     }
     if (kind == LatentKind::Ids)
         OT_RUN("dequant_post_vq", (double)L0 * D * 4.0,
-               omnitok_dequant_post_vq(static_cast<const int64_t *>(latent), W(e, k_embed(c)), c.n_codes, 8,
-                                       W(e, k_post_w(c)), W(e, k_post_b(c)), e->X.p, L0, D,
-                                       e->err_flag, stream));
+               omnitok_gather_rows(static_cast<const int64_t *>(latent), e->dq_table, c.n_codes, e->X.p, L0, D,
+                                   e->err_flag, stream));
     else
         OT_RUN("post_vq", (double)L0 * D * 4.0,
                omnitok_post_vq(static_cast<const float *>(latent), kind == LatentKind::ChannelFirst, B,

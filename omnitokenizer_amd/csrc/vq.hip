@@ -272,6 +272,29 @@ __global__ __launch_bounds__(256) void dequant_post_vq_kernel(const int64_t *__r
     reinterpret_cast<f32x4 *>(tok)[gid] = o;
 }
 
+// tok[n, :] = table[ids[n], :]: the decode-side form of dequant_post_vq once table = E W^T + b has been built (by
+// dequant_post_vq_kernel itself on ids = 0..n_codes-1, so the rows are bit-identical).  Pure row gather from an
+// L2 / Infinity-Cache resident table (16 MiB at 8192 x 512): one 16-byte load + store per thread.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t *__restrict__ ids,
+                                                          const f32x4 *__restrict__ table, int n_codes,
+                                                          f32x4 *__restrict__ tok, int64_t n, int d4n, int *err_flag) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n * d4n) return;
+    const int64_t row = gid / d4n;
+    const int c4 = (int)(gid % d4n);
+    int64_t id = ids[row];
+    if (id < 0 || id >= n_codes) {
+        if (err_flag) atomicOr(err_flag, 1);
+        id = 0;
+    }
+    __builtin_nontemporal_store(table[id * d4n + c4], tok + gid);
+}
+
+__global__ void iota_i64_kernel(int64_t *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
 __global__ __launch_bounds__(256) void vq_embed_st_kernel(const int64_t *__restrict__ ids,
                                                           const float *__restrict__ z, const float *__restrict__ E,
                                                           int64_t B, int64_t thw, float *__restrict__ emb) {
@@ -522,6 +545,34 @@ extern "C" int omnitok_vq_argmin_cdist(const float *z, const float *packed, cons
                  n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin_cdist: unaligned");
     return launch_vq<VQ_EUCLID>(z, packed, ee, n, n_codes, ids, stream);
+}
+
+extern "C" int omnitok_dequant_table(const float *codebook, int n_codes, int cdim, const float *w, const float *b,
+                                     float *table, int D, int64_t *scratch_ids, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(codebook && w && b && table && scratch_ids, "dequant_table: null pointer");
+    OT_CHECK_ARG(cdim == 8 && D % 4 == 0 && n_codes > 0, "dequant_table: need cdim == 8, D %% 4 == 0, n_codes > 0");
+    hipLaunchKernelGGL(iota_i64_kernel, dim3((n_codes + 255) / 256), dim3(256), 0, stream, scratch_ids, n_codes);
+    OT_LAUNCH_CHECK("iota");
+    const int64_t total = (int64_t)n_codes * (D / 4);
+    hipLaunchKernelGGL(dequant_post_vq_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, scratch_ids,
+                       codebook, n_codes, w, b, table, (int64_t)n_codes, D, nullptr);
+    OT_LAUNCH_CHECK("dequant_table");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_gather_rows(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n, int D,
+                                   int *err_flag, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(ids && table && tok, "gather_rows: null pointer");
+    OT_CHECK_ARG(D % 4 == 0 && aligned16(table) && aligned16(tok), "gather_rows: need D %% 4 == 0 and 16-byte alignment");
+    if (n == 0) return OMNITOK_OK;
+    const int64_t total = n * (D / 4);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids,
+                       reinterpret_cast<const f32x4 *>(table), n_codes, reinterpret_cast<f32x4 *>(tok), n, D / 4,
+                       err_flag);
+    OT_LAUNCH_CHECK("gather_rows");
+    return OMNITOK_OK;
 }
 
 extern "C" int omnitok_dequant_post_vq(const int64_t *ids, const float *codebook, int n_codes, int cdim,

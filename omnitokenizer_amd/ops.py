@@ -383,6 +383,31 @@ def dequant_post_vq(ids, codebook, w, b):
     return tok
 
 
+
+def dequant_table(codebook, w, b):
+    """table[n_codes, D] = codebook @ w.T + b with the dequant_post_vq kernel (rows bit-identical to it)."""
+    codebook, w, b = _req(codebook, "codebook"), _req(w, "w"), _req(b, "b")
+    n_codes, D = codebook.shape[0], w.shape[0]
+    table = torch.empty(n_codes, D, device=w.device, dtype=torch.float32)
+    scratch = torch.empty(n_codes, device=w.device, dtype=torch.int64)
+    check(_lib.load().omnitok_dequant_table(_p(codebook), n_codes, 8, _p(w), _p(b), _p(table), D, _p(scratch),
+                                            _stream()), "dequant_table")
+    return table
+
+
+def gather_rows(ids, table):
+    """tok[..., :] = table[ids[...], :]; out-of-range ids raise IndexError like F.embedding."""
+    ids, table = _req(ids, "ids", torch.int64), _req(table, "table")
+    D = table.shape[1]
+    tok = torch.empty(*ids.shape, D, device=ids.device, dtype=torch.float32)
+    err = torch.zeros(1, device=ids.device, dtype=torch.int32)
+    check(_lib.load().omnitok_gather_rows(_p(ids), _p(table), table.shape[0], _p(tok), ids.numel(), D, _p(err),
+                                          _stream()), "gather_rows")
+    if int(err.item()):
+        raise IndexError("token id out of range")
+    return tok
+
+
 def token_resample(x, mode):
     """Token-grid resampling used by the pooling blocks and the deferred pools.  mode:
     "avg2d" / "max2d": x [n, gh, gw, D] -> [n, gh/2, gw/2, D]   (Pooling 'a' / 'm', attention.py:83-106)

@@ -18,6 +18,15 @@ def ops():
     return _ops
 
 
+@pytest.fixture(params=[1, 0], ids=["pipelined_dma", "reg_staged"])
+def variant(request):
+    """both builds of the attention kernel ("attn_h2_variant": 1 = software-pipelined + LDS-DMA, the default)."""
+    from omnitokenizer_amd import _lib
+    _lib.set_option("attn_h2_variant", request.param)
+    yield request.param
+    _lib.set_option("attn_h2_variant", 1)
+
+
 def dev(t):
     return t.contiguous().cuda()
 
@@ -95,7 +104,7 @@ def test_attn_pack_layout_and_split(ops, rope):
 
 @pytest.mark.parametrize("rope", [True, False])
 @pytest.mark.parametrize("Bn,N", [(3, 64), (2, 192), (1, 1024), (2, 576)])
-def test_attn_h2_vs_fp64(ops, Bn, N, rope):
+def test_attn_h2_vs_fp64(ops, variant, Bn, N, rope):
     h, d = 8, 64
     q, k, v = rnd(Bn, N, h, d, seed=161), rnd(Bn, N, h, d, seed=162), rnd(Bn, N, h, d, seed=163, scale=2.0)
     qs, ks = rnd(d, seed=164) * 0.1 + 1, rnd(d, seed=165) * 0.1 + 1
@@ -113,12 +122,12 @@ def test_attn_h2_vs_fp64(ops, Bn, N, rope):
     ops.qk_prep_(qd, kvd[:, : h * d], N, h, dev(qs), dev(ks), cos, sin)
     out32 = ops.attn_spatial(qd, kvd[:, : h * d], kvd[:, h * d:], Bn, N, h)
     e_h2, e_32 = maxerr(out, ref), maxerr(out32, ref)
-    print(f"attn Bn={Bn} N={N} rope={rope}: fp16-split err {e_h2:.2e}, fp32-MFMA err {e_32:.2e}")
+    print(f"attn variant={variant} Bn={Bn} N={N} rope={rope}: fp16-split err {e_h2:.2e}, fp32-MFMA err {e_32:.2e}")
     assert e_h2 < 1e-5
     assert e_h2 < 4 * e_32 + 2e-6
 
 
-def test_attn_h2_forced_rescale(ops):
+def test_attn_h2_forced_rescale(ops, variant):
     """A key whose logit towers over the others late in the sweep forces the online-softmax rescale branch."""
     Bn, N, h, d = 1, 256, 8, 64
     q = orc.l2norm(rnd(Bn, N, h, d, seed=64)) * 8.0
@@ -136,7 +145,7 @@ def test_attn_h2_forced_rescale(ops):
     assert maxerr(out, ref) < 2e-5
 
 
-def test_attn_h2_legacy_bias(ops):
+def test_attn_h2_legacy_bias(ops, variant):
     c = GoldenCase("s1_legacy_r64_img")
     p = "encoder.enc_spatial_transformer.layers.0.1.spatial_rel_pos_bias"
     gh = gw = 8
@@ -155,7 +164,7 @@ def test_attn_h2_legacy_bias(ops):
     assert maxerr(out, ref) < 2e-5
 
 
-def test_attn_h2_per_clip_ranges_and_batch_independence(ops):
+def test_attn_h2_per_clip_ranges_and_batch_independence(ops, variant):
     """v of very different magnitude per clip with device-side per-clip bounds: every clip keeps its relative
     accuracy, and a clip's result does not depend on what else is in the batch (bitwise)."""
     clips, T, N, h, d = 3, 2, 64, 8, 64

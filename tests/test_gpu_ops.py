@@ -315,6 +315,14 @@ def test_pre_vq_and_dequant(ops):
         bad = ids.clone()
         bad[0, 0, 0, 0] = 8192
         ops.dequant_post_vq(dev(bad), dev(E), dev(pw), dev(pb))
+    # the table form the engine decodes with: rows bit-identical to the kernel above, gather exact
+    table = ops.dequant_table(dev(E), dev(pw), dev(pb))
+    assert tuple(table.shape) == (8192, 512)
+    assert torch.equal(ops.gather_rows(dev(ids), table), tok)
+    with pytest.raises(IndexError):
+        ops.gather_rows(dev(bad), table)
+    with pytest.raises(IndexError):
+        ops.gather_rows(dev(-bad), table)
 
 
 def test_torch_custom_ops_dispatch(ops):
