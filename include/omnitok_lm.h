@@ -53,6 +53,13 @@ int64_t omnitok_lm_cache_bytes(omnitok_lm *lm);
 int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
                     float *logits_out, int advance, omnitok_stream_t stream);
 
+/* The same step with the reference's optional inputs (gpt.py:236-258): emb [B, C] != NULL replaces the token
+ * embedding (an explicit `embeddings=` vector; idx may then be NULL), pos_extra [B, C] != NULL is added to the
+ * position embedding (the vtokens_pos term: rows of vtokens_pos_emb gathered by the caller from cbox). */
+int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const float *emb, const float *pos_extra,
+                       int32_t *pos, int32_t *cache_len, int B, float *logits_out, int advance,
+                       omnitok_stream_t stream);
+
 /* 1 if a decode step since the last call found cache_len[b] >= max_len (a stream stepped past the cache that
  * omnitok_lm_alloc_cache sized; the step then stays inside the stream's own K/V slab and its logits are
  * invalid), 0 otherwise; clears the flag.  Synchronises the stream (call it once after a sampling loop). */
@@ -66,6 +73,26 @@ int omnitok_lm_overflowed(omnitok_lm *lm, omnitok_stream_t stream);
  * B * T <= 65535; may hipMalloc its (grow-only) workspace. */
 int omnitok_lm_prefill(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
                        int T, float *logits_out, omnitok_stream_t stream);
+
+/* ... with explicit embeddings prepended (GPT.forward(idx, embeddings=...), gpt.py:214-216): the sequence is
+ * emb[B, T_emb, C] followed by tok_emb[idx[B, T_tok]], T = T_emb + T_tok positions; pos_extra [B, T, C] (optional)
+ * is the vtokens_pos term added to the position embeddings (gpt.py:222-226).  logits_out [B, T, vocab]. */
+int omnitok_lm_prefill_ex(omnitok_lm *lm, const int64_t *idx, int T_tok, const float *emb, int T_emb,
+                          const float *pos_extra, int32_t *pos, int32_t *cache_len, int B,
+                          float *logits_out, omnitok_stream_t stream);
+
+/* Token selection of the sampling loops (gpt.py:347-357; CFG blend :428-431) for B streams, one workgroup each:
+ *   v = logits / temperature,  or with logits_uncond:  v = cfg_c1 * (logits / T) - cfg_c2 * (logits_uncond / T)
+ *   (cfg_c1 = 1 + t, cfg_c2 = t as fp32, the reference's roundings);
+ *   top_k < 0: no filtering (the reference's top_k=None);  top_k >= 0: keep v >= k-th largest (0: all), then the
+ *   nucleus top_p (1.0: off) as top_k_top_p_filtering (gpt.py:19-51);
+ *   sample == 0: out[b] = argmax (lowest index on ties);  else one draw from softmax of the survivors by inverse
+ *   CDF with the caller's uniform u[b] in [0, 1).
+ * blend_out (optional) [B, V] receives v.  err_flag (optional) is set when more than 16384 values survive top_k
+ * while a nucleus cut is requested (the LDS sort buffer; the argmax is returned then). */
+int omnitok_lm_select(const float *logits, const float *logits_uncond, int B, int V, float temperature,
+                      float cfg_c1, float cfg_c2, int top_k, float top_p, int sample, const float *u,
+                      int64_t *out, float *blend_out, int *err_flag, omnitok_stream_t stream);
 
 /* building blocks, exported for the parity tests */
 /* y[b, n] = act(sum_k x[b, k] * w[n, k] + bias[n]) (+ residual[b, n]);  act: 0 none, 1 exact-erf

@@ -102,6 +102,9 @@ _PROTOS = {
     "omnitok_lm_overflowed": [P, P],
     "omnitok_lm_step": [P, P, P, P, c_int, P, c_int, P],
     "omnitok_lm_prefill": [P, P, P, P, c_int, c_int, P, P],
+    "omnitok_lm_step_ex": [P, P, P, P, P, P, c_int, P, c_int, P],
+    "omnitok_lm_prefill_ex": [P, P, c_int, P, c_int, P, P, P, c_int, P, P],
+    "omnitok_lm_select": [P, P, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, P, P, P, P, P],
     "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "omnitok_lm_attn_decode": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
     "omnitok_set_option": [c_char_p, c_int],

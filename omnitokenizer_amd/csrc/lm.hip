@@ -29,17 +29,24 @@ namespace omnitok {
 
 constexpr int LM_CHUNK = 256;   // keys per attention workgroup
 
+// x = token_embedding + position_embedding (reference gpt.py:209-226 / 238-258): the token embedding is
+// tok_emb[idx] or an explicit vector (`embeddings=`, emb [B, C]); the position embedding is pos_emb[pos],
+// plus the vtokens_pos term (extra [B, C], gathered from vtokens_pos_emb by the caller) when given -- summed
+// in the reference's order: tok + (pos + extra).
 __global__ __launch_bounds__(256) void lm_embed_kernel(const int64_t *__restrict__ idx, const int32_t *__restrict__ pos,
                                                        const float *__restrict__ tok, const float *__restrict__ pe,
+                                                       const float *__restrict__ emb, const float *__restrict__ extra,
                                                        float *__restrict__ x, int C, int vocab, int block_size) {
     const int b = blockIdx.x;
-    int64_t id = idx[b];
+    int64_t id = idx ? idx[b] : 0;
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     int p = pos[b];
     p = p < 0 ? 0 : (p >= block_size ? block_size - 1 : p);
+    const float *src = emb ? emb + (int64_t)b * C : tok + id * C;
     for (int i = threadIdx.x * 4; i < C; i += 256 * 4) {
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(tok + id * C + i);
-        const f32x4 c = *reinterpret_cast<const f32x4 *>(pe + (int64_t)p * C + i);
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(src + i);
+        f32x4 c = *reinterpret_cast<const f32x4 *>(pe + (int64_t)p * C + i);
+        if (extra) c = c + *reinterpret_cast<const f32x4 *>(extra + (int64_t)b * C + i);
         *reinterpret_cast<f32x4 *>(x + (int64_t)b * C + i) = a + c;
     }
 }
@@ -367,16 +374,27 @@ __global__ void lm_attn_merge_kernel(const float *__restrict__ part, const int32
 }
 
 // ---- batched prefill of a conditioning prefix (the same arithmetic as T decode steps, as GEMMs) ------
+// positions t < Te take the explicit embeddings emb[b, t] (prepended, gpt.py:214-216), the rest tok_emb[idx[b, t - Te]]
 __global__ __launch_bounds__(256) void lm_embed_seq_kernel(const int64_t *__restrict__ idx, const float *__restrict__ tok,
-                                                           const float *__restrict__ pe, float *__restrict__ x, int T,
-                                                           int C, int vocab) {
+                                                           const float *__restrict__ pe, const float *__restrict__ emb,
+                                                           int Te, const float *__restrict__ extra,
+                                                           float *__restrict__ x, int T, int C, int vocab) {
     const int64_t row = blockIdx.x;  // b * T + t
     const int t = (int)(row % T);
-    int64_t id = idx[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-    for (int i = threadIdx.x * 4; i < C; i += 256 * 4)
-        *reinterpret_cast<f32x4 *>(x + row * C + i) = *reinterpret_cast<const f32x4 *>(tok + id * C + i) +
-                                                     *reinterpret_cast<const f32x4 *>(pe + (int64_t)t * C + i);
+    const int64_t b = row / T;
+    const float *src;
+    if (t < Te) {
+        src = emb + (b * Te + t) * C;
+    } else {
+        int64_t id = idx[b * (T - Te) + (t - Te)];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = tok + id * C;
+    }
+    for (int i = threadIdx.x * 4; i < C; i += 256 * 4) {
+        f32x4 c = *reinterpret_cast<const f32x4 *>(pe + (int64_t)t * C + i);
+        if (extra) c = c + *reinterpret_cast<const f32x4 *>(extra + row * C + i);
+        *reinterpret_cast<f32x4 *>(x + row * C + i) = *reinterpret_cast<const f32x4 *>(src + i) + c;
+    }
 }
 
 // nn.LayerNorm over rows of any width (two-pass, eps 1e-5): one wave per row
@@ -800,10 +818,16 @@ extern "C" int64_t omnitok_lm_cache_bytes(omnitok_lm *lm) { return lm ? lm->cach
 
 extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B,
                                float *logits_out, int advance, omnitok_stream_t stream_) {
+    return omnitok_lm_step_ex(lm, idx, nullptr, nullptr, pos, cache_len, B, logits_out, advance, stream_);
+}
+
+extern "C" int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const float *emb, const float *pos_extra,
+                                  int32_t *pos, int32_t *cache_len, int B, float *logits_out, int advance,
+                                  omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(lm, "lm_step: null engine");
     if (B == 0) return OMNITOK_OK;
-    OT_CHECK_ARG(idx && pos && cache_len, "lm_step: null pointer");
+    OT_CHECK_ARG((idx || emb) && pos && cache_len, "lm_step: null pointer");
     if (!lm->finalized) {
         set_error("lm_step: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -816,7 +840,7 @@ extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos,
     const int C = c.n_embd, hd = C / c.n_head;
     const int64_t per_layer = (int64_t)lm->max_batch * c.n_head * lm->max_len * hd;
     hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, stream, idx, pos, LW(lm, "tok_emb.weight"),
-                       LW(lm, "pos_emb"), lm->x, C, c.vocab_size, c.block_size);
+                       LW(lm, "pos_emb"), emb, pos_extra, lm->x, C, c.vocab_size, c.block_size);
     OT_LAUNCH_CHECK("lm_embed");
     for (int i = 0; i < c.n_layer; ++i) {
         const LmLayer &L = lm->layers[i];
@@ -849,10 +873,18 @@ extern "C" int omnitok_lm_step(omnitok_lm *lm, const int64_t *idx, int32_t *pos,
 
 extern "C" int omnitok_lm_prefill(omnitok_lm *lm, const int64_t *idx, int32_t *pos, int32_t *cache_len, int B, int T,
                                   float *logits_out, omnitok_stream_t stream_) {
+    return omnitok_lm_prefill_ex(lm, idx, T, nullptr, 0, nullptr, pos, cache_len, B, logits_out, stream_);
+}
+
+extern "C" int omnitok_lm_prefill_ex(omnitok_lm *lm, const int64_t *idx, int T_tok, const float *emb, int T_emb,
+                                     const float *pos_extra, int32_t *pos, int32_t *cache_len, int B,
+                                     float *logits_out, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(lm, "lm_prefill: null engine");
+    OT_CHECK_ARG(T_tok >= 0 && T_emb >= 0, "lm_prefill: negative length");
+    const int T = T_tok + T_emb;
     if (B == 0 || T == 0) return OMNITOK_OK;
-    OT_CHECK_ARG(idx && pos && cache_len, "lm_prefill: null pointer");
+    OT_CHECK_ARG((idx || T_tok == 0) && (emb || T_emb == 0) && pos && cache_len, "lm_prefill: null pointer");
     if (!lm->finalized) {
         set_error("lm_prefill: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -881,7 +913,7 @@ extern "C" int omnitok_lm_prefill(omnitok_lm *lm, const int64_t *idx, int32_t *p
     const int64_t per_layer = (int64_t)lm->max_batch * c.n_head * lm->max_len * hd;
     const dim3 ln_grid((unsigned)((M + 3) / 4));
     hipLaunchKernelGGL(lm_embed_seq_kernel, dim3((unsigned)M), dim3(256), 0, stream, idx, LW(lm, "tok_emb.weight"),
-                       LW(lm, "pos_emb"), x, T, C, V);
+                       LW(lm, "pos_emb"), emb, T_emb, pos_extra, x, T, C, V);
     OT_LAUNCH_CHECK("lm_embed_seq");
     const int BR = OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL;
     for (int i = 0; i < c.n_layer; ++i) {

@@ -7,8 +7,9 @@ The class owns the parameters under the reference's state_dict key names; all ar
 step runs in libomnitok.so (include/omnitok_lm.h, csrc/lm.hip): a preallocated K/V cache instead of
 the reference's per-step torch.cat of all pasts, GEMV kernels that stream each fp32 weight matrix
 once per step, flash-decode attention, and -- because the step's launch sequence does not depend on
-the position -- one captured HIP graph replayed per token.  Token selection (temperature, top-k /
-top-p filtering, multinomial) is the reference's own few torch ops on the GPU logits.
+the position -- one captured HIP graph replayed per token.  Token selection (temperature, the CFG blend,
+top-k / top-p filtering, argmax or one multinomial draw) is one more kernel (csrc/lm_select.hip); the only
+thing torch contributes is the uniform random number per stream (so torch.manual_seed governs the samples).
 Inference only; there is no CPU fallback.
 """
 from __future__ import annotations
@@ -22,23 +23,6 @@ import torch.nn.functional as F
 
 from . import _lib
 from ._lib import OmnitokLmConfig, check
-
-
-def top_k_top_p_filtering(logits, top_k=0, top_p=1.0, filter_value=-float("Inf"), min_tokens_to_keep=1):
-    """reference gpt.py:19-51, same semantics (filters in place and returns logits)."""
-    if top_k > 0:
-        top_k = min(max(top_k, min_tokens_to_keep), logits.size(-1))
-        logits[logits < torch.topk(logits, top_k)[0][..., -1, None]] = filter_value
-    if top_p < 1.0:
-        sorted_logits, sorted_indices = torch.sort(logits, descending=True)
-        cumulative_probs = torch.cumsum(F.softmax(sorted_logits, dim=-1), dim=-1)
-        remove = cumulative_probs > top_p
-        if min_tokens_to_keep > 1:
-            remove[..., :min_tokens_to_keep] = 0
-        remove[..., 1:] = remove[..., :-1].clone()
-        remove[..., 0] = 0
-        logits[remove.scatter(1, sorted_indices, remove)] = filter_value
-    return logits
 
 
 class _Holder(nn.Module):
@@ -58,11 +42,16 @@ class _PastHandle:
 class GPT(nn.Module):
     def __init__(self, args, vocab_size, block_size, n_layer=12, n_head=8, n_embd=256, embd_pdrop=0.,
                  resid_pdrop=0., attn_pdrop=0., n_unmasked=0, vtokens_pos=False):
-        """Same signature as the reference (gpt.py:172).  Dropouts are inference no-ops;
-        n_unmasked / vtokens_pos (unused by the released scripts) are not built."""
+        """Same signature as the reference (gpt.py:172).  Dropouts are inference no-ops; vtokens_pos adds the
+        reference's vtokens_pos_emb parameter [1, sequence_length, resolution, resolution, n_embd] (gpt.py:183-184).
+        n_unmasked (a bidirectional prefix in the causal mask, gpt.py:98-100; no script sets it) is not built."""
         super().__init__()
-        if n_unmasked or vtokens_pos:
-            raise NotImplementedError("n_unmasked / vtokens_pos are not built (no released config uses them)")
+        if n_unmasked:
+            raise NotImplementedError("n_unmasked is not built (no released config uses it)")
+        self.vtokens_pos = bool(vtokens_pos)
+        if self.vtokens_pos:
+            self.vtokens_pos_emb = nn.Parameter(
+                torch.zeros(1, args.sequence_length, args.resolution, args.resolution, n_embd), requires_grad=False)
         self.block_size = block_size
         self.vocab_size, self.n_layer, self.n_head, self.n_embd = vocab_size, n_layer, n_head, n_embd
 
@@ -159,6 +148,8 @@ class GPT(nn.Module):
             check(lib.omnitok_lm_create(ctypes.byref(cfg), ctypes.byref(h)), "lm_create")
             self._engine = h
         for name, t in self.state_dict(keep_vars=True).items():
+            if name == "vtokens_pos_emb":  # gathered per call on the host side (cbox / tbox), not an engine weight
+                continue
             t = t.detach()
             if t.dtype != torch.float32:
                 raise TypeError(f"{name}: parameters must be float32 (the path computes in fp32 like the reference)")
@@ -203,42 +194,93 @@ class GPT(nn.Module):
         if self._engine and _lib.load().omnitok_lm_overflowed(self._engine, torch.cuda.current_stream().cuda_stream) > 0:
             raise RuntimeError("a stream stepped past the K/V cache length it was allocated with")
 
-    def step(self, idx, logits=None, advance=True, want_logits=True):
+    @staticmethod
+    def _fp(t):
+        return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+    def _f32(self, t, shape, name):
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def step(self, idx, logits=None, advance=True, want_logits=True, emb=None, pos_extra=None):
         """One decode step: idx [B] int64 (device) enters every stream at pos[b] / cache_len[b].
-        Returns logits [B, vocab] (or None if want_logits is False)."""
-        B = idx.shape[0]
+        emb [B, C]: an explicit input vector instead of tok_emb[idx] (idx may be None); pos_extra [B, C]: added to
+        the position embedding (the vtokens_pos term).  Returns logits [B, vocab] (or None if want_logits is False)."""
+        B = (idx if idx is not None else emb).shape[0]
         if want_logits and logits is None:
-            logits = torch.empty(B, self.vocab_size, device=idx.device, dtype=torch.float32)
-        check(_lib.load().omnitok_lm_step(self._engine, ctypes.c_void_p(idx.data_ptr()),
-                                          ctypes.c_void_p(self._pos.data_ptr()), ctypes.c_void_p(self._len.data_ptr()),
-                                          B, None if not want_logits else ctypes.c_void_p(logits.data_ptr()),
-                                          int(advance), torch.cuda.current_stream().cuda_stream), "lm_step")
+            logits = torch.empty(B, self.vocab_size, device=self.device, dtype=torch.float32)
+        check(_lib.load().omnitok_lm_step_ex(self._engine, self._fp(idx), self._fp(emb), self._fp(pos_extra),
+                                             ctypes.c_void_p(self._pos.data_ptr()), ctypes.c_void_p(self._len.data_ptr()),
+                                             B, None if not want_logits else ctypes.c_void_p(logits.data_ptr()),
+                                             int(advance), torch.cuda.current_stream().cuda_stream), "lm_step")
         return logits if want_logits else None
 
-    def prefill(self, idx, want_logits=False):
-        """Feeds idx [B, T] into EMPTY streams in one batched pass (GEMMs + causal flash attention,
-        include/omnitok_lm.h omnitok_lm_prefill): same arithmetic as T steps.  Returns the
-        teacher-forced logits [B, T, vocab] if want_logits."""
+    def prefill(self, idx, want_logits=False, emb=None, pos_extra=None):
+        """Feeds emb [B, Te, C] (optional, prepended) then idx [B, T] into EMPTY streams in one batched pass
+        (GEMMs + causal flash attention, include/omnitok_lm.h omnitok_lm_prefill_ex): same arithmetic as Te + T
+        steps.  pos_extra [B, Te + T, C] (optional): the vtokens_pos term.  Returns the teacher-forced logits
+        [B, Te + T, vocab] if want_logits."""
         B, T = idx.shape
+        Te = 0 if emb is None else emb.shape[1]
         idx = idx.contiguous()
-        logits = torch.empty(B, T, self.vocab_size, device=idx.device, dtype=torch.float32) if want_logits else None
-        check(_lib.load().omnitok_lm_prefill(self._engine, ctypes.c_void_p(idx.data_ptr()),
-                                             ctypes.c_void_p(self._pos.data_ptr()), ctypes.c_void_p(self._len.data_ptr()),
-                                             B, T, None if logits is None else ctypes.c_void_p(logits.data_ptr()),
-                                             torch.cuda.current_stream().cuda_stream), "lm_prefill")
+        logits = torch.empty(B, Te + T, self.vocab_size, device=idx.device, dtype=torch.float32) if want_logits else None
+        check(_lib.load().omnitok_lm_prefill_ex(self._engine, self._fp(idx), T, self._fp(emb), Te, self._fp(pos_extra),
+                                                ctypes.c_void_p(self._pos.data_ptr()),
+                                                ctypes.c_void_p(self._len.data_ptr()), B, self._fp(logits),
+                                                torch.cuda.current_stream().cuda_stream), "lm_prefill")
         return logits
 
-    def _feed(self, idx):
+    def _feed(self, idx, pos_extra=None):
         """Conditioning tokens idx [B, T] into empty streams: batched prefill, or plain steps when
-        the prefix is short (or too large for one prefill launch)."""
+        the prefix is short (or too large for one prefill launch).  pos_extra [B, T, C] optional."""
         B, T = idx.shape
         if T == 0:
             return
         if T >= 8 and B * T <= 65535:
-            self.prefill(idx)
+            self.prefill(idx, pos_extra=None if pos_extra is None else pos_extra.contiguous())
         else:
             for t in range(T):
-                self.step(idx[:, t].contiguous(), want_logits=False)
+                self.step(idx[:, t].contiguous(), want_logits=False,
+                          pos_extra=None if pos_extra is None else pos_extra[:, t].contiguous())
+
+    def vtokens_position_embeddings(self, cbox, tbox=None):
+        """reference gpt.py:220-225: rows of vtokens_pos_emb selected by the per-sample boxes, [B, n, C]
+        (a gather on the parameter; the engine adds it to the position embeddings)."""
+        if not self.vtokens_pos:
+            return None
+        if cbox is None:
+            raise ValueError("this GPT was built with vtokens_pos: cbox is required (reference gpt.py:221-225)")
+        C = self.vtokens_pos_emb.shape[-1]
+        if tbox:
+            rows = [self.vtokens_pos_emb[:, tp[0]:tp[1], p[0]:p[1], p[2]:p[3], :].reshape(1, -1, C)
+                    for p, tp in zip(cbox, tbox)]
+        else:
+            rows = [self.vtokens_pos_emb[:, :, p[0]:p[1], p[2]:p[3], :].reshape(1, -1, C) for p in cbox]
+        return torch.cat(rows, 0).contiguous()
+
+    def graph_step_extra(self, B):
+        """graph_step with a position-extra input buffer (vtokens_pos): (idx, extra, logits, replay)."""
+        key = ("extra", B)
+        if key not in self._graphs:
+            idx = torch.zeros(B, dtype=torch.int64, device=self.device)
+            extra = torch.zeros(B, self.n_embd, device=self.device, dtype=torch.float32)
+            logits = torch.empty(B, self.vocab_size, device=self.device, dtype=torch.float32)
+            pos0, len0 = self._pos.clone(), self._len.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.step(idx, logits, pos_extra=extra)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step(idx, logits, pos_extra=extra)
+            self._pos.copy_(pos0)
+            self._len.copy_(len0)
+            self._graphs[key] = (idx, extra, logits, g)
+        idx, extra, logits, g = self._graphs[key]
+        return idx, extra, logits, g.replay
 
     def graph_step(self, B):
         """(idx_buffer, logits_buffer, replay) for a captured decode step of B streams: write the next
@@ -267,18 +309,25 @@ class GPT(nn.Module):
     def forward(self, idx, embeddings=None, targets=None, cbox=None, tbox=None):
         """reference gpt.py:207-234: logits [B, T, V] of a whole sequence (teacher-forced), computed by
         the batched prefill (same arithmetic as walking the KV-cached step over the T positions)."""
-        if embeddings is not None or cbox is not None or tbox is not None:
-            raise NotImplementedError("explicit embeddings / vtokens_pos boxes are not built")
-        B, T = idx.shape
+        B, Tt = idx.shape
+        Te = 0 if embeddings is None else embeddings.shape[1]
+        T = Te + Tt  # explicit embeddings are prepended (gpt.py:214-216)
         assert T <= self.block_size, "Cannot forward, model block size is exhausted."
+        self._sync_engine()
+        emb = None if embeddings is None else self._f32(embeddings, (B, Te, self.n_embd), "embeddings")
+        extra = self.vtokens_position_embeddings(cbox, tbox)
+        if extra is not None:
+            extra = self._f32(extra, (B, T, self.n_embd), "vtokens position embeddings (cbox / tbox)")
         self.reset_streams(B, T)
         idx = idx.to(self.device).long()
         if B * T <= 65535:
-            out = self.prefill(idx, want_logits=True)
+            out = self.prefill(idx, want_logits=True, emb=emb, pos_extra=extra)
         else:
             out = torch.empty(B, T, self.vocab_size, device=self.device, dtype=torch.float32)
             for t in range(T):
-                out[:, t] = self.step(idx[:, t].contiguous())
+                out[:, t] = self.step(None if t < Te else idx[:, t - Te].contiguous(),
+                                      emb=None if t >= Te else emb[:, t].contiguous(),
+                                      pos_extra=None if extra is None else extra[:, t].contiguous())
         loss = None
         if targets is not None:
             loss = F.cross_entropy(out.view(-1, out.size(-1)), targets.view(-1))
@@ -291,18 +340,29 @@ class GPT(nn.Module):
         Otherwise idx [B, 1] continues them; `past` is the list of handles returned so far and its
         total length must equal past_length like the reference asserts (:246-247).  The new token's
         position embedding is pos_emb[past_length] (+1 with forward_uncond, :248)."""
-        if embeddings is not None or cbox is not None:
-            raise NotImplementedError("explicit embeddings / vtokens_pos boxes are not built")
         idx = idx.to(self.device).long()
         B, T = idx.shape
+        self._sync_engine()
+        extra = self.vtokens_position_embeddings(cbox)  # [B, n, C] or None
         if past is None:
             self.reset_streams(B, self.block_size + 1)
-            self._feed(idx[:, :T - 1])
-            logits = self.step(idx[:, T - 1].contiguous())
+            if embeddings is not None:
+                # explicit embeddings prepended to the prefix (gpt.py:239-240): one batched pass, all logits
+                Te = embeddings.shape[1]
+                emb = self._f32(embeddings, (B, Te, self.n_embd), "embeddings")
+                ex = None if extra is None else extra[:, :Te + T].contiguous()
+                out = self.prefill(idx, want_logits=True, emb=emb, pos_extra=ex)
+                return out, None, _PastHandle(self, Te + T, self._generation)
+            self._feed(idx[:, :T - 1], None if extra is None else extra[:, :T - 1])
+            logits = self.step(idx[:, T - 1].contiguous(),
+                               pos_extra=None if extra is None else extra[:, T - 1].contiguous())
             out = torch.zeros(B, T, self.vocab_size, device=self.device) if T > 1 else None
             if out is not None:
                 out[:, -1] = logits  # callers read logits[:, -1, :] (gpt.py:347)
             return (out if out is not None else logits[:, None]), None, _PastHandle(self, T, self._generation)
+        if embeddings is not None:
+            raise NotImplementedError("embeddings together with a past: the reference broadcasts ONE position "
+                                      "embedding over the several new rows (gpt.py:248); no caller does this")
         assert past_length is not None
         for h in past:
             if not isinstance(h, _PastHandle) or h.model is not self or h.generation != self._generation:
@@ -315,36 +375,36 @@ class GPT(nn.Module):
         assert have == past_length, f"{have} =/= {past_length}"
         assert T == 1
         self._pos[:B] = past_length + (1 if forward_uncond else 0)
-        logits = self.step(idx[:, 0].contiguous())
+        logits = self.step(idx[:, 0].contiguous(),
+                           pos_extra=None if extra is None else extra[:, past_length].contiguous())
         return logits[:, None], None, _PastHandle(self, 1, self._generation)
 
 
-def _select(logits, sample_logits, top_k, top_p):
-    """Token selection of the reference's loops (gpt.py:347-357): top-k / top-p filtering, softmax,
-    then top-1 or a multinomial draw.  The stochastic branch draws from the same distribution with
-    ONE descending sort instead of topk + sort: in sorted order the top-k filter is `rank >= k` (ties
-    with the k-th value kept, like `logits < kth`), the nucleus filter is the shifted cumulative mass,
-    and the drawn rank is mapped back through the sort indices."""
-    if not sample_logits or top_k is None:
-        if top_k is not None:
-            logits = top_k_top_p_filtering(logits, top_k=top_k, top_p=1.0 if top_p is None else top_p)
-        probs = F.softmax(logits, dim=-1)
-        if not sample_logits:
-            return torch.topk(probs, k=1, dim=-1)[1]
-        return torch.multinomial(probs, num_samples=1)
-    V = logits.size(-1)
-    top_p = 1.0 if top_p is None else top_p
-    sl, si = torch.sort(logits, descending=True)
-    if top_k > 0:
-        k = min(max(top_k, 1), V)
-        sl = sl.masked_fill(sl < sl[..., k - 1, None], -float("inf"))
-    if top_p < 1.0:
-        cum = torch.cumsum(F.softmax(sl, dim=-1), dim=-1)
-        remove = cum > top_p
-        remove = torch.cat((torch.zeros_like(remove[..., :1]), remove[..., :-1]), dim=-1)
-        sl = sl.masked_fill(remove, -float("inf"))
-    rank = torch.multinomial(F.softmax(sl, dim=-1), num_samples=1)
-    return si.gather(-1, rank)
+def select_tokens(logits, sample_logits=True, top_k=None, top_p=None, temperature=1.0, logits_uncond=None,
+                  cfg_t=0.0, generator=None, return_logits=False):
+    """Token selection of the reference's loops (gpt.py:347-357, CFG blend :428-431) as ONE kernel
+    (include/omnitok_lm.h omnitok_lm_select): logits [B, V] (raw, this call divides by temperature) ->
+    ids [B] int64.  top_k None: no filtering (like the reference, top_p is then ignored).  Stochastic draws are
+    inverse-CDF lookups with one torch uniform per stream."""
+    if logits.device.type != "cuda" or logits.dtype != torch.float32:
+        raise RuntimeError("select_tokens: logits must be float32 on the GPU (no CPU path)")
+    logits = logits.contiguous()
+    B, V = logits.shape
+    out = torch.empty(B, dtype=torch.int64, device=logits.device)
+    u = torch.rand(B, device=logits.device, generator=generator) if sample_logits else None
+    blend = torch.empty(B, V, device=logits.device, dtype=torch.float32) if return_logits else None
+    err = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    lu = None if logits_uncond is None else logits_uncond.contiguous()
+    fp = GPT._fp
+    # (1 + t) and t enter as fp32 scalars like `(1 + t) * lc - t * lu` on fp32 tensors
+    check(_lib.load().omnitok_lm_select(fp(logits), fp(lu), B, V, float(temperature), float(1 + cfg_t), float(cfg_t),
+                                        -1 if top_k is None else int(top_k), 1.0 if top_p is None else float(top_p),
+                                        int(bool(sample_logits)), fp(u), fp(out), fp(blend), fp(err),
+                                        torch.cuda.current_stream().cuda_stream), "lm_select")
+    if sample_logits and top_k is not None and top_p is not None and top_p < 1.0 and (top_k == 0 or top_k > 16384):
+        if int(err.item()):  # only this corner can overflow the sort buffer: one readback there
+            raise NotImplementedError("nucleus sampling over more than 16384 surviving logits (set top_k)")
+    return (out, blend) if return_logits else out
 
 
 @torch.no_grad()
@@ -353,32 +413,40 @@ def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, t
     """reference gpt.py:327-359: x [B, cond_len] conditioning tokens -> [B, steps] sampled tokens.
     The conditioning is fed through the same KV-cached step; each sampling step is one replay of
     the captured HIP graph plus the token selection on the GPU, with no host synchronisation."""
-    if cbox is not None:
-        raise NotImplementedError("vtokens_pos boxes are not built")
     x = x.to(model.device).long()
     B, cond_len = x.shape
     if cond_len + steps - 1 > model.block_size:  # the reference fails at pos_emb[:, past_length] (gpt.py:248)
         raise ValueError(f"{cond_len} conditioning + {steps} sampled tokens exceed block_size {model.block_size}")
+    model._sync_engine()
+    extra = model.vtokens_position_embeddings(cbox)  # [B, n, C] or None (vtokens_pos models need cbox)
     model.reset_streams(B, cond_len + steps)
-    model._feed(x[:, :cond_len - 1])
+    model._feed(x[:, :cond_len - 1], None if extra is None else extra[:, :cond_len - 1])
     if use_graph:
-        idx_buf, logits_buf, replay = model.graph_step(B)
+        if extra is None:
+            idx_buf, logits_buf, replay = model.graph_step(B)
+        else:
+            idx_buf, extra_buf, logits_buf, replay = model.graph_step_extra(B)
     nxt = x[:, -1].contiguous()
     out = torch.empty(B, steps, dtype=torch.int64, device=model.device)
     all_logits = [] if return_logits else None
     for n in range(steps):
         if callback is not None:
             callback(n)
+        ex = None if extra is None else extra[:, cond_len - 1 + n].contiguous()  # position of the token entering
         if use_graph:
             idx_buf.copy_(nxt)
+            if ex is not None:
+                extra_buf.copy_(ex)
             replay()
             logits = logits_buf
         else:
-            logits = model.step(nxt)
-        logits = logits / temperature
+            logits = model.step(nxt, pos_extra=ex)
+        sel = select_tokens(logits, sample_logits, top_k, top_p, temperature, return_logits=return_logits)
         if return_logits:
-            all_logits.append(logits.clone())
-        nxt = _select(logits, sample_logits, top_k, top_p)[:, 0]
+            nxt, lg = sel
+            all_logits.append(lg)
+        else:
+            nxt = sel
         out[:, n] = nxt
     return (out, torch.stack(all_logits, 1)) if return_logits else out
 
@@ -391,8 +459,10 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
     [sos, class+1]) and the unconditional stream ([sos]) run as rows [0, B) and [B, 2B) of ONE batched
     step: both see the same new token and the same position (the reference's forward_uncond shift,
     gpt.py:248), only their cache lengths differ by one."""
-    if cbox is not None:
-        raise NotImplementedError("vtokens_pos boxes are not built")
+    if cbox is not None or model.vtokens_pos:
+        raise NotImplementedError("classifier-free guidance with vtokens_pos boxes: the reference's unconditional "
+                                  "pass indexes the box embeddings at past_length of a different stream "
+                                  "(gpt.py:250-252); no script combines the two")
     x = x.to(model.device).long() + 1
     B = x.shape[0]
     sos = torch.zeros_like(x)
@@ -425,12 +495,14 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
             logits = logits_buf
         else:
             logits = model.step(nxt)
-        lc, lu = logits[:B] / temperature, logits[B:] / temperature
         t = cfg_ratio * (n if scale_cfg else 1)
-        blend = (1 + t) * lc - t * lu
+        sel = select_tokens(logits[:B], sample_logits, top_k, top_p, temperature, logits_uncond=logits[B:], cfg_t=t,
+                            return_logits=return_logits)  # blend = (1 + t) * lc - t * lu inside the kernel
         if return_logits:
-            all_logits.append(blend.clone())
-        tok = _select(blend, sample_logits, top_k, top_p)[:, 0]
+            tok, lg = sel
+            all_logits.append(lg)
+        else:
+            tok = sel
         out[:, n] = tok
         nxt = torch.cat((tok, tok)).contiguous()
     return (out, torch.stack(all_logits, 1)) if return_logits else out

@@ -247,8 +247,9 @@ def state_checksum(sd) -> int:
     return c
 
 
-def synth_gpt_state(vocab_size, block_size, n_layer, n_head, n_embd, seed=0):
-    """Seeded numpy weights with the reference GPT's key names / shapes (gpt.py:172-193)."""
+def synth_gpt_state(vocab_size, block_size, n_layer, n_head, n_embd, seed=0, vtokens_pos_shape=None):
+    """Seeded numpy weights with the reference GPT's key names / shapes (gpt.py:172-193).
+    vtokens_pos_shape = (sequence_length, resolution): adds vtokens_pos_emb [1, T, R, R, C] (gpt.py:183-184)."""
     sd = OrderedDict()
 
     def put(name, shape, kind):
@@ -276,4 +277,7 @@ def synth_gpt_state(vocab_size, block_size, n_layer, n_head, n_embd, seed=0):
         put(f"{p}.mlp.2.weight", (C, 4 * C), "w"); put(f"{p}.mlp.2.bias", (C,), "b")
     put("ln_f.weight", (C,), "g"); put("ln_f.bias", (C,), "b")
     put("head.weight", (vocab_size, C), "w")
+    if vtokens_pos_shape is not None:
+        t, r = vtokens_pos_shape
+        put("vtokens_pos_emb", (1, t, r, r, C), "e")
     return sd

@@ -54,10 +54,28 @@ def n_layers(sd):
     return 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
 
 
-def forward(sd, idx, n_head):
-    """reference gpt.py:207-234 GPT.forward(idx) -> logits [B,T,V] (no embeddings / vtokens_pos)."""
-    T = idx.shape[1]
-    x = F.embedding(idx, sd["tok_emb.weight"]) + sd["pos_emb"][:, :T]
+def vtokens_position_embeddings(sd, cbox, tbox=None):
+    """reference gpt.py:220-225: [B, n, C] rows of vtokens_pos_emb [1, T, H, W, C] selected by the per-sample
+    spatial boxes cbox = (h0, h1, w0, w1) and optional temporal boxes tbox = (t0, t1)."""
+    e = sd["vtokens_pos_emb"]
+    C = e.shape[-1]
+    if tbox:
+        return torch.cat([e[:, tp[0]:tp[1], p[0]:p[1], p[2]:p[3], :].reshape(1, -1, C) for p, tp in zip(cbox, tbox)], 0)
+    return torch.cat([e[:, :, p[0]:p[1], p[2]:p[3], :].reshape(1, -1, C) for p in cbox], 0)
+
+
+def forward(sd, idx, n_head, embeddings=None, cbox=None, tbox=None):
+    """reference gpt.py:207-234 GPT.forward(idx, embeddings, cbox=, tbox=) -> logits [B,T,V]: explicit
+    embeddings are prepended (:214-216); with vtokens_pos (a 'vtokens_pos_emb' entry in sd) the box embeddings
+    are added to the position embeddings (:219-226)."""
+    tok = F.embedding(idx, sd["tok_emb.weight"])
+    if embeddings is not None:
+        tok = torch.cat((embeddings, tok), dim=1)
+    T = tok.shape[1]
+    pos = sd["pos_emb"][:, :T]
+    if "vtokens_pos_emb" in sd:
+        pos = pos + vtokens_position_embeddings(sd, cbox, tbox)
+    x = tok + pos
     for i in range(n_layers(sd)):
         x, _, _ = block(sd, f"blocks.{i}", x, n_head)
     C = x.shape[-1]
@@ -65,18 +83,29 @@ def forward(sd, idx, n_head):
     return F.linear(x, sd["head.weight"])
 
 
-def forward_with_past(sd, idx, n_head, cache, position=None):
+def forward_with_past(sd, idx, n_head, cache, position=None, embeddings=None, cbox=None, past_length=None):
     """reference gpt.py:236-275.  cache: None (first call, positions 0..T-1) or a list of (k, v)
     per layer [B,nh,len,hs]; then idx is one new token per row and its position embedding is
     pos_emb[:, position] (position = past_length, or past_length + 1 with forward_uncond, :248).
+    embeddings (first call only) are prepended (:239-240); with vtokens_pos the box embeddings of
+    positions [:T] (first call, :255-257) or of index past_length (:249-252) are added.
     Returns (logits [B,T,V], new cache)."""
-    T = idx.shape[1]
+    tok = F.embedding(idx, sd["tok_emb.weight"])
+    if embeddings is not None:
+        assert cache is None
+        tok = torch.cat((embeddings, tok), dim=1)
+    T = tok.shape[1]
     if cache is None:
         pos = sd["pos_emb"][:, :T]
+        if "vtokens_pos_emb" in sd:
+            pos = pos + vtokens_position_embeddings(sd, cbox)[:, :T]
     else:
         assert T == 1 and position is not None
         pos = sd["pos_emb"][:, position][:, None]
-    x = F.embedding(idx, sd["tok_emb.weight"]) + pos
+        if "vtokens_pos_emb" in sd:
+            pl = position if past_length is None else past_length
+            pos = pos + vtokens_position_embeddings(sd, cbox)[:, pl][:, None]
+    x = tok + pos
     new_cache = []
     for i in range(n_layers(sd)):
         pk, pv = (None, None) if cache is None else cache[i]
@@ -112,13 +141,30 @@ def _pick(logits, sample_logits, top_k, top_p, generator):
     return torch.multinomial(probs, num_samples=1, generator=generator)
 
 
+def select_inverse_cdf(values, top_k, top_p, u):
+    """What csrc/lm_select.hip computes for ONE row, restated in float64 on top of the reference's own filter:
+    the survivors of top_k_top_p_filtering(values) in descending value order (ties by ascending index) -- or, for
+    top_k None (no filtering), the whole vocabulary in INDEX order --, their softmax, and the token at which the
+    cumulative distribution first exceeds u.
+    Returns (token, order, cdf): order = survivor indices by rank, cdf = cumulative probabilities (float64)."""
+    v = values.clone().float()
+    if top_k is not None:
+        v = top_k_top_p_filtering(v[None], top_k=top_k, top_p=1.0 if top_p is None else top_p)[0]
+    keep = torch.nonzero(torch.isfinite(v))[:, 0]
+    order = keep if top_k is None else keep[torch.sort(-v[keep].double(), stable=True)[1]]
+    pr = torch.softmax(v[order].double(), 0)
+    cdf = torch.cumsum(pr, 0)
+    r = int(torch.searchsorted(cdf, torch.tensor(float(u), dtype=torch.float64), right=True))
+    return int(order[min(r, order.numel() - 1)]), order, cdf
+
+
 def sample_with_past(sd, x, n_head, steps, temperature=1.0, sample_logits=True, top_k=None, top_p=None,
-                     generator=None, return_logits=False):
+                     generator=None, return_logits=False, cbox=None):
     """reference gpt.py:327-359: x [B, cond_len] conditioning -> [B, steps] new tokens."""
     cond_len = x.shape[1]
     cache, out, all_logits = None, [], []
     for n in range(steps):
-        logits, cache = forward_with_past(sd, x, n_head, cache, position=n + cond_len - 1)
+        logits, cache = forward_with_past(sd, x, n_head, cache, position=n + cond_len - 1, cbox=cbox)
         logits = logits[:, -1, :] / temperature
         all_logits.append(logits)
         x = _pick(logits, sample_logits, top_k, top_p, generator)

@@ -344,6 +344,55 @@ def make_gpt_golden():
         print(f"{name}: logits {tuple(logits.shape)} absmax {logits.abs().max().item():.2f} greedy {greedy[0, :6].tolist()}")
 
 
+def make_gpt_vtok_golden(name="gpt_vtok"):
+    """The reference GPT's optional inputs (gpt.py:207-258): vtokens_pos boxes (cbox / tbox) and explicit
+    embeddings prepended -- full forward, the KV-cached first call + steps, and greedy sample_with_past(cbox)."""
+    import argparse
+    import importlib
+    from oracle import gpt_oracle as go
+    rh.install_stubs()
+    gpt = importlib.import_module("OmniTokenizer.modules.gpt")
+    V, BS, L, H, C, TT, RR = 300, 40, 2, 4, 256, 3, 6
+    sd = go.synth_gpt_state(V, BS, L, H, C, seed=4, vtokens_pos_shape=(TT, RR))
+    args = argparse.Namespace(sequence_length=TT, resolution=RR)
+    m = gpt.GPT(args, V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True).eval()
+    missing = m.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.endswith("attn.mask") for k in missing.missing_keys)
+    g = torch.Generator().manual_seed(11)
+    cbox = [(0, 3, 1, 5), (2, 5, 0, 4)]          # 3 x 4 spatial boxes: 3 frames x 12 = 36 positions
+    tbox = [(0, 2), (1, 3)]                      # with tbox: 2 frames x 12 = 24 positions
+    emb = torch.randn(2, 2, C, generator=g) * 0.5
+    idx36 = torch.randint(0, V, (2, 34), generator=g)   # 2 embeddings + 34 tokens = 36
+    idx24 = torch.randint(0, V, (2, 24), generator=g)
+    steps = 10
+    with torch.no_grad():
+        lg_emb, _ = m(idx36, embeddings=emb, cbox=cbox)
+        lg_tbox, _ = m(idx24, cbox=cbox, tbox=tbox)
+        # KV-cached: first call with embeddings + 3 tokens (positions 0..4), then 4 single-token steps.
+        # Batch 1 only: with a past the reference adds a [B, C] position term to [B, 1, C] token embeddings
+        # (gpt.py:248-253), which broadcasts to [B, B, C] for B > 1 -- the cached vtokens_pos path of the
+        # reference is only well-formed for one stream.
+        first, _, present = m.forward_with_past(idx36[:1, :3], embeddings=emb[:1], cbox=cbox[:1])
+        past, plen, step_logits = [present], 5, []
+        for t in range(4):
+            lgt, _, present = m.forward_with_past(idx36[:1, 3 + t:4 + t], past=past, past_length=plen, cbox=cbox[:1])
+            past.append(present)
+            plen += 1
+            step_logits.append(lgt[:, -1])
+        greedy = torch.cat([gpt.sample_with_past(idx36[b:b + 1, :3].clone(), m, steps, temperature=0.8,
+                                                 sample_logits=False, top_k=40, top_p=0.9, cbox=cbox[b:b + 1])
+                            for b in range(2)], 0)
+    crc = 0
+    for k in sd:
+        crc = __import__("zlib").crc32(sd[k].numpy().tobytes(), crc)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), vocab=V, block_size=BS, n_layer=L, n_head=H, n_embd=C,
+                        sequence_length=TT, resolution=RR, weight_seed=4, state_crc=np.uint32(crc),
+                        cbox=np.array(cbox), tbox=np.array(tbox), emb=emb.numpy(), idx36=idx36.numpy(),
+                        idx24=idx24.numpy(), steps=steps, logits_emb=lg_emb.numpy(), logits_tbox=lg_tbox.numpy(),
+                        first=first.numpy(), step_logits=torch.stack(step_logits, 1).numpy(), greedy=greedy.numpy())
+    print(f"{name}: logits_emb {tuple(lg_emb.shape)} logits_tbox {tuple(lg_tbox.shape)} greedy {greedy[0, :6].tolist()}")
+
+
 def run_b32_case(name="s2_sdpa_r256_vid17_b32", stride=8):
     args = make_args(2, resolution=256)
     cfg = OmniTokConfig.from_args(args, attention_mode="sdpa")
@@ -395,6 +444,8 @@ if __name__ == "__main__":
             run_ext_case(*c)
     if only in (None, "gpt"):
         make_gpt_golden()
+    if only in (None, "gpt", "gpt_vtok"):
+        make_gpt_vtok_golden()
     if only in (None, "vae"):
         for c in VAE_CASES:
             run_vae_case(*c)

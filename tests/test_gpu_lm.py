@@ -275,3 +275,192 @@ def test_tokens_to_pixels_chain():
     video = vq.decode(index, False)                 # flat video ids, omnitokenizer.py:283-286
     assert tuple(video.shape) == (1, 3, 5, 64, 64) and torch.isfinite(video).all()
     assert torch.equal(video, vq.decode(index.reshape(1, 2, 8, 8), False))
+
+
+# ---- token selection kernel (csrc/lm_select.hip) ---------------------------------------------------------------
+@pytest.mark.parametrize("V,top_k,top_p,temp", [(320, 50, 0.9, 0.9), (9193, 2048, 0.9, 1.0), (9193, 64, 1.0, 0.7),
+                                                (300, 300, 0.5, 1.0), (520, 1, 0.3, 1.0), (17385, None, None, 1.0),
+                                                (9193, 0, 0.7, 1.3), (8193, 8192, 0.95, 1.0)])
+def test_select_kernel_vs_reference_semantics(V, top_k, top_p, temp):
+    """greedy = argmax; stochastic = inverse CDF over the survivors of the reference's filter (gpt.py:19-51): for u
+    at the midpoints of the oracle's CDF intervals the kernel returns exactly the oracle's token, for random u the
+    token agrees unless u sits on an interval edge (fp32 vs fp64 prefix sums)."""
+    from omnitokenizer_amd import gpt as og
+    B = 6
+    lg = rnd(B, V, seed=V + (top_k or 0), scale=3.0)
+    lg[0, 10] = lg[0, 11]            # a tie
+    lg[1, 5] = lg[1].max() + 4.0     # a dominant token
+    d = lg.cuda()
+    greedy = og.select_tokens(d, sample_logits=False, top_k=top_k, top_p=top_p, temperature=temp)
+    vals = torch.div(lg, temp)
+    assert torch.equal(greedy.cpu(), vals.argmax(-1))
+    # hand-placed uniforms: patch torch.rand through a generator-free path -- call the C entry directly
+    lib = __import__("omnitokenizer_amd")._lib.load()
+    out = torch.empty(B, dtype=torch.int64, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+
+    def run(u):
+        ud = u.float().cuda()
+        from omnitokenizer_amd._lib import check
+        check(lib.omnitok_lm_select(_p(d), None, B, V, float(temp), 1.0, 0.0, -1 if top_k is None else top_k,
+                                    1.0 if top_p is None else float(top_p), 1, _p(ud), _p(out), None, _p(err),
+                                    torch.cuda.current_stream().cuda_stream), "lm_select")
+        return out.cpu()
+    oracles = [go.select_inverse_cdf(vals[b], top_k, top_p, 0.0) for b in range(B)]
+    for frac in (0.0, 0.3, 0.77, 0.999):
+        u, want = [], []
+        for b in range(B):
+            _, order, cdf = oracles[b]
+            r = min(int(frac * len(order)), len(order) - 1)
+            lo = 0.0 if r == 0 else float(cdf[r - 1])
+            u.append((lo + float(cdf[r])) / 2)
+            want.append(int(order[r]))
+        # skip intervals narrower than fp32 can resolve
+        got = run(torch.tensor(u, dtype=torch.float64))
+        for b in range(B):
+            _, order, cdf = oracles[b]
+            r = min(int(frac * len(order)), len(order) - 1)
+            width = float(cdf[r] - (cdf[r - 1] if r else 0.0))
+            if width > 1e-5:
+                assert int(got[b]) == want[b], (frac, b, int(got[b]), want[b])
+    g = torch.Generator().manual_seed(1)
+    agree = total = 0
+    for _ in range(20):
+        u = torch.rand(B, generator=g, dtype=torch.float64)
+        got = run(u)
+        for b in range(B):
+            tok, order, cdf = go.select_inverse_cdf(vals[b], top_k, top_p, float(u[b].float()))
+            edge = (cdf - float(u[b].float())).abs().min().item() < 2e-6
+            assert int(got[b]) in set(order.tolist())
+            if not edge:
+                total += 1
+                agree += int(got[b]) == tok
+    assert agree == total, f"{total - agree} of {total} draws differ from the inverse-CDF oracle"
+    assert int(err.item()) == 0
+
+
+def test_select_kernel_cfg_blend_and_errors():
+    from omnitokenizer_amd import gpt as og
+    B, V = 3, 1000
+    lc, lu = rnd(B, V, seed=1, scale=2.0), rnd(B, V, seed=2, scale=2.0)
+    t, temp = 1.5, 0.8
+    blend_ref = (1 + t) * (lc / temp) - t * (lu / temp)   # the reference's expression on fp32 tensors (gpt.py:428-431)
+    tok, blend = og.select_tokens(lc.cuda(), sample_logits=False, top_k=64, top_p=1.0, temperature=temp,
+                                  logits_uncond=lu.cuda(), cfg_t=t, return_logits=True)
+    assert torch.equal(blend.cpu(), blend_ref)
+    assert torch.equal(tok.cpu(), blend_ref.argmax(-1))
+    with pytest.raises(RuntimeError):
+        og.select_tokens(lc, sample_logits=False)                       # CPU tensor
+    with pytest.raises(NotImplementedError):                           # nucleus over > 16384 survivors
+        og.select_tokens(rnd(1, 17385, seed=3).cuda(), sample_logits=True, top_k=0, top_p=0.5)
+    torch.manual_seed(5)
+    a = og.select_tokens(lc.cuda(), True, 50, 0.9)
+    torch.manual_seed(5)
+    assert torch.equal(a, og.select_tokens(lc.cuda(), True, 50, 0.9))  # torch's generator governs the draw
+
+
+# ---- the reference GPT's optional inputs: explicit embeddings, vtokens_pos boxes ----------------------------------
+def test_gpt_embeddings_and_vtokens_pos_vs_reference_golden():
+    from omnitokenizer_amd import gpt as og
+    from omnitokenizer_amd.gpt import GPT
+    g, sd, (V, BS, L, H, C) = load_gpt_case("gpt_vtok")
+    args = argparse.Namespace(sequence_length=int(g["sequence_length"]), resolution=int(g["resolution"]))
+    m = GPT(args, V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True)
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.cuda().eval()
+    cbox = [tuple(r) for r in g["cbox"].tolist()]
+    tbox = [tuple(r) for r in g["tbox"].tolist()]
+    emb, idx36, idx24 = (torch.from_numpy(g[k]).cuda() for k in ("emb", "idx36", "idx24"))
+    lg, _ = m(idx36, embeddings=emb, cbox=cbox)
+    assert (lg.cpu() - torch.from_numpy(g["logits_emb"])).abs().max().item() < LOGIT_TOL
+    lg, _ = m(idx24, cbox=cbox, tbox=tbox)
+    assert (lg.cpu() - torch.from_numpy(g["logits_tbox"])).abs().max().item() < LOGIT_TOL
+    with pytest.raises(ValueError):
+        m(idx24)                                   # a vtokens_pos model needs its boxes (gpt.py:221-225)
+    # the reference's KV-cached calling pattern: first call with embeddings, then single-token steps
+    first, _, present = m.forward_with_past(idx36[:1, :3], embeddings=emb[:1], cbox=cbox[:1])
+    assert (first.cpu() - torch.from_numpy(g["first"])).abs().max().item() < LOGIT_TOL
+    past, plen = [present], 5
+    for t in range(4):
+        lgt, _, present = m.forward_with_past(idx36[:1, 3 + t:4 + t], past=past, past_length=plen, cbox=cbox[:1])
+        past.append(present)
+        plen += 1
+        assert (lgt[:, -1].cpu() - torch.from_numpy(g["step_logits"])[:, t]).abs().max().item() < LOGIT_TOL
+    # greedy sampling with boxes: per stream like the reference (its cached path is single-stream), and as one batch
+    for use_graph in (False, True):
+        one = torch.cat([og.sample_with_past(idx36[b:b + 1, :3].clone(), m, int(g["steps"]), temperature=0.8,
+                                             sample_logits=False, top_k=40, top_p=0.9, cbox=cbox[b:b + 1],
+                                             use_graph=use_graph) for b in range(2)], 0)
+        assert np.array_equal(one.cpu().numpy(), g["greedy"])
+        both = og.sample_with_past(idx36[:, :3].clone(), m, int(g["steps"]), temperature=0.8, sample_logits=False,
+                                   top_k=40, top_p=0.9, cbox=cbox, use_graph=use_graph)
+        assert np.array_equal(both.cpu().numpy(), g["greedy"])
+    # explicit embeddings on a model without vtokens_pos: oracle parity
+    g2, sd2, (V2, BS2, L2, H2, C2) = load_gpt_case("gpt_hd64")
+    m2 = GPT(argparse.Namespace(), V2, BS2, n_layer=L2, n_head=H2, n_embd=C2)
+    m2.load_state_dict(sd2, strict=True)
+    m2 = m2.cuda().eval()
+    e2 = rnd(2, 3, C2, seed=8, scale=0.5)
+    idx = torch.from_numpy(g2["idx"])[:, :9]
+    ref = go.forward(sd2, idx, H2, embeddings=e2)
+    out, _ = m2(idx.cuda(), embeddings=e2.cuda())
+    assert (out.cpu() - ref).abs().max().item() < LOGIT_TOL
+
+
+# ---- Net2NetTransformer mirror (reference lm_transformer.py:19-275) ------------------------------------------------
+@pytest.mark.parametrize("starts_with_sos,class_first", [(False, False), (True, False), (True, True)])
+def test_net2net_transformer_forward_and_sample(starts_with_sos, class_first):
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    from omnitokenizer_amd.lm_transformer import Net2NetTransformer
+    from oracle import omnitok_oracle as orc
+    targs = make_args(2, resolution=64)
+    cfg = OmniTokConfig.from_args(targs)
+    tsd = synth.synth_state_dict(cfg, seed=0)
+    tok = OmniTokenizer_VQGAN(targs)
+    tok.load_state_dict(tsd, strict=True)
+    n_cls, L, H, C = 10, 2, 4, 256
+    args = argparse.Namespace(class_cond_dim=n_cls, unconditional=False, vtokens=False, block_size=80, n_layer=L,
+                              n_head=H, n_embd=C, vtokens_pos=False, n_unmasked=0, starts_with_sos=starts_with_sos,
+                              class_first=class_first)
+    net = Net2NetTransformer(args, first_stage_model=tok)
+    V = cfg.n_codes + n_cls + (1 if starts_with_sos else 0)
+    assert net.transformer.vocab_size == V and net.first_stage_vocab_size == cfg.n_codes
+    gsd = go.synth_gpt_state(V, 80, L, H, C, seed=6)
+    # the Lightning checkpoint layout: prefixed keys, the tokenizer's off-path keys ride along
+    full = {f"transformer.{k}": v for k, v in gsd.items()}
+    full.update({f"first_stage_model.{k}": v for k, v in tsd.items()})
+    net.load_state_dict(full, strict=True)
+    net = net.cuda().eval()
+    x = synth.synth_image(2, 64, seed=21)                      # 8 x 8 = 64 latent tokens
+    c = torch.tensor([3, 7])
+    logits, target = net(x.cuda(), c.cuda())
+    # oracle composition of the same pipeline (reference lm_transformer.py:136-192)
+    with torch.no_grad():
+        z = orc.encode(tsd, x, True, cfg).reshape(2, -1)
+    ci = c[:, None]
+    if starts_with_sos:
+        sos = torch.zeros_like(ci)
+        ci, zi = ci + 1, z + n_cls + 1
+        cz = torch.cat((ci, sos, zi), 1) if class_first else torch.cat((sos, ci, zi), 1)
+        prefix = 1
+    else:
+        zi = z + n_cls
+        cz = torch.cat((ci, zi), 1)
+        prefix = 0
+    assert torch.equal(target.cpu(), zi)
+    ref = go.forward(gsd, cz[:, :-1], H)[:, prefix:]
+    assert (logits.cpu() - ref).abs().max().item() < LOGIT_TOL
+    # sample(): the reference recomputes the full sequence per token (lm_transformer.py:231-247); greedy is token-equal
+    steps = 6
+    got = net.sample(zi[:, :0].cuda(), cz[:, :prefix + 1].cuda(), steps, temperature=1.0, sample=False, top_k=20)
+    seq = cz[:, :prefix + 1]
+    for _ in range(steps):
+        nxt = go.forward(gsd, seq, H)[:, -1].argmax(-1, keepdim=True)
+        seq = torch.cat((seq, nxt), 1)
+    assert torch.equal(got.cpu(), seq[:, prefix + 1:])
+    # and the sampled ids decode through the tokenizer like transformer_eval.py:68-69
+    index = torch.clamp(got - n_cls - (1 if starts_with_sos else 0), min=0, max=net.first_stage_model.n_codes - 1)
+    pix = net.first_stage_model.decode(torch.cat((index, index[:, :2].repeat(1, 29)), 1)[:, :64], is_image=True)
+    assert tuple(pix.shape) == (2, 3, 64, 64) and torch.isfinite(pix).all()

@@ -17,7 +17,8 @@ GPT_CASES = ["gpt_hd64", "gpt_hd96", "gpt_hd128"]
 def load_gpt_case(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     V, BS, L, H, C = (int(g[k]) for k in ("vocab", "block_size", "n_layer", "n_head", "n_embd"))
-    sd = go.synth_gpt_state(V, BS, L, H, C, seed=int(g["weight_seed"]))
+    vt = (int(g["sequence_length"]), int(g["resolution"])) if "sequence_length" in g.files else None
+    sd = go.synth_gpt_state(V, BS, L, H, C, seed=int(g["weight_seed"]), vtokens_pos_shape=vt)
     crc = 0
     for k in sd:
         crc = zlib.crc32(sd[k].numpy().tobytes(), crc)
@@ -43,6 +44,26 @@ def test_gpt_oracle_matches_reference_golden(name):
         b = go.sample_with_past_cfg(sd, cls, H, steps, sample_logits=False, top_k=64, top_p=0.95, cfg_ratio=0.5,
                                     class_first=False, scale_cfg=True)
         assert np.array_equal(a.numpy(), g["cfg_a"]) and np.array_equal(b.numpy(), g["cfg_b"])
+
+
+def test_gpt_oracle_optional_inputs_match_reference_golden():
+    """explicit embeddings prepended + vtokens_pos boxes (reference gpt.py:207-258), pinned by gpt_vtok.npz."""
+    g, sd, (V, BS, L, H, C) = load_gpt_case("gpt_vtok")
+    cbox = [tuple(r) for r in g["cbox"].tolist()]
+    tbox = [tuple(r) for r in g["tbox"].tolist()]
+    emb, idx36, idx24 = (torch.from_numpy(g[k]) for k in ("emb", "idx36", "idx24"))
+    with torch.no_grad():
+        assert (go.forward(sd, idx36, H, embeddings=emb, cbox=cbox) - torch.from_numpy(g["logits_emb"])).abs().max() < 2e-5
+        assert (go.forward(sd, idx24, H, cbox=cbox, tbox=tbox) - torch.from_numpy(g["logits_tbox"])).abs().max() < 2e-5
+        first, cache = go.forward_with_past(sd, idx36[:1, :3], H, None, embeddings=emb[:1], cbox=cbox[:1])
+        assert (first - torch.from_numpy(g["first"])).abs().max() < 2e-5
+        for t in range(4):
+            lg, cache = go.forward_with_past(sd, idx36[:1, 3 + t:4 + t], H, cache, position=5 + t, cbox=cbox[:1])
+            assert (lg[:, 0] - torch.from_numpy(g["step_logits"])[:, t]).abs().max() < 2e-5
+        greedy = torch.cat([go.sample_with_past(sd, idx36[b:b + 1, :3], H, int(g["steps"]), temperature=0.8,
+                                                sample_logits=False, top_k=40, top_p=0.9, cbox=cbox[b:b + 1])
+                            for b in range(2)], 0)
+        assert np.array_equal(greedy.numpy(), g["greedy"])
 
 
 @pytest.mark.skipif(not rh.reference_available(), reason="needs /root/reference (build container only)")
@@ -76,28 +97,32 @@ def test_product_gpt_state_dict_and_cpu_refusal():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 4, dtype=torch.long))
     with pytest.raises(NotImplementedError):
-        GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True)
+        GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C, n_unmasked=2)
+    # vtokens_pos: the reference's extra parameter, same key and shape (gpt.py:183-184)
+    mv = GPT(argparse.Namespace(sequence_length=3, resolution=6), V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True)
+    assert tuple(mv.state_dict()["vtokens_pos_emb"].shape) == (1, 3, 6, 6, C)
+    assert set(mv.state_dict()) == set(sd) | {"vtokens_pos_emb"}
 
 
-@pytest.mark.parametrize("top_k,top_p", [(50, 0.9), (2048, 0.9), (64, 1.0), (300, 0.5), (1, 0.3)])
-def test_product_token_selection_matches_reference_semantics(top_k, top_p):
-    """omnitokenizer_amd.gpt's filtering (pure torch, CPU-runnable) == the oracle's restatement of
-    reference gpt.py:19-51, and its single-sort sampling branch draws from exactly that distribution."""
+@pytest.mark.parametrize("top_k,top_p", [(50, 0.9), (2048, 0.9), (64, 1.0), (300, 0.5), (1, 0.3), (None, None), (0, 0.7)])
+def test_select_inverse_cdf_draws_from_the_reference_distribution(top_k, top_p):
+    """The inverse-CDF restatement the selection kernel is tested against (oracle select_inverse_cdf) assigns every
+    survivor of the reference's filter (gpt.py:19-51) an interval of u of exactly its softmax probability."""
     import torch.nn.functional as F
-    from omnitokenizer_amd import gpt as og
-    g = torch.Generator().manual_seed(top_k)
-    lg = torch.randn(4, 300, generator=g) * 3
-    lg[0, 10] = lg[0, 11]
-    ref = go.top_k_top_p_filtering(lg, top_k, top_p)
-    assert torch.equal(og.top_k_top_p_filtering(lg.clone(), top_k=top_k, top_p=top_p), ref)
-    # greedy branch: same token as the reference's topk(softmax(filtered))
-    assert torch.equal(og._select(lg.clone(), False, top_k, top_p), torch.topk(F.softmax(ref, -1), 1)[1])
-    # stochastic branch: empirical support is inside the reference's support, frequencies follow its probs
-    probs = F.softmax(ref, -1)
-    torch.manual_seed(0)
-    draws = torch.cat([og._select(lg.clone(), True, top_k, top_p) for _ in range(400)], 1)  # [4, 400]
-    assert (probs.gather(1, draws) > 0).all()
-    if top_k > 1:
-        top = probs.argmax(-1)
-        freq = (draws == top[:, None]).float().mean(1)
-        assert (freq - probs.gather(1, top[:, None])[:, 0]).abs().max().item() < 0.12
+    g = torch.Generator().manual_seed(7 if top_k is None else top_k)
+    lg = torch.randn(300, generator=g) * 3
+    lg[10] = lg[11]
+    ref = lg.clone()[None]
+    if top_k is not None:
+        ref = go.top_k_top_p_filtering(ref, top_k, 1.0 if top_p is None else top_p)
+    probs = F.softmax(ref.double(), -1)[0]
+    tok, order, cdf = go.select_inverse_cdf(lg, top_k, top_p, 0.0)
+    assert tok == int(order[0])
+    if top_k is not None:
+        assert tok == int(probs.argmax())
+    assert set(order.tolist()) == set(torch.nonzero(probs > 0)[:, 0].tolist())
+    widths = torch.diff(cdf, prepend=torch.zeros(1, dtype=torch.float64))
+    assert (widths - probs[order]).abs().max().item() < 1e-12
+    for r in (0, len(order) // 2, len(order) - 1):   # the midpoint of an interval selects its token
+        mid = float(cdf[r] - widths[r] / 2)
+        assert go.select_inverse_cdf(lg, top_k, top_p, mid)[0] == int(order[r])

@@ -28,7 +28,9 @@ def test_vq_torch_oracle_matches_reference_kat(n_codes):
     assert np.array_equal(ids, g["ids"].astype(np.int64))
 
 
-@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"] + FULL_CASES + VARIANT_CASES)
+# (the 17-frame legacy-mode fixture costs ~100 s of einsum attention on the CPU: it is checked against the HIP path
+# by tests/test_gpu_e2e.py and by the oracle only in its sdpa twin, keeping this suite at a few minutes)
+@pytest.mark.parametrize("name", FAST + ["s2_sdpa_r256_img"] + [c for c in FULL_CASES if "legacy" not in c] + VARIANT_CASES)
 def test_oracle_end_to_end_matches_reference(name):
     c = GoldenCase(name)
     with torch.no_grad():
