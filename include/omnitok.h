@@ -412,6 +412,15 @@ int omnitok_engine_check_ids(omnitok_engine *e, omnitok_stream_t stream);
 
 int64_t omnitok_engine_workspace_bytes(omnitok_engine *e);
 
+/* Caller-owned workspace (e.g. a tensor of PyTorch's caching allocator) instead of the engine's own grow-only
+ * hipMalloc buffers: omnitok_engine_workspace_need_encode / _decode return the bytes a call of that shape needs
+ * (-1: invalid shape); omnitok_engine_set_workspace hands over a 256-byte-aligned device block that must stay
+ * alive until it is replaced (NULL, 0: back to internal allocation).  encode / decode fail with OMNITOK_ERR_STATE
+ * if the block is too small. */
+int64_t omnitok_engine_workspace_need_encode(omnitok_engine *e, int B, int F, int H, int W);
+int64_t omnitok_engine_workspace_need_decode(omnitok_engine *e, int B, int T, int h, int w);
+int omnitok_engine_set_workspace(omnitok_engine *e, void *dev_ptr, int64_t bytes);
+
 /* Per-kernel timing: when enabled, every launch made by encode/decode is bracketed with HIP
  * events on its stream; omnitok_engine_timing_report fills a '\n'-separated
  * "name calls total_ms" list (synchronises). */

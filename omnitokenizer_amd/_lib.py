@@ -90,6 +90,9 @@ _PROTOS = {
     "omnitok_engine_decode_shape": [P, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int)],
     "omnitok_engine_check_ids": [P, P],
     "omnitok_engine_workspace_bytes": [P],
+    "omnitok_engine_workspace_need_encode": [P, c_int, c_int, c_int, c_int],
+    "omnitok_engine_workspace_need_decode": [P, c_int, c_int, c_int, c_int],
+    "omnitok_engine_set_workspace": [P, P, I64],
     "omnitok_engine_set_timing": [P, c_int],
     "omnitok_engine_timing_report": [P, c_char_p, c_int],
     # include/omnitok_lm.h
@@ -115,6 +118,7 @@ _PROTOS = {
 }
 _RESTYPES = {"omnitok_last_error": c_char_p, "omnitok_version": c_char_p,
              "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64,
+             "omnitok_engine_workspace_need_encode": c_int64, "omnitok_engine_workspace_need_decode": c_int64,
              "omnitok_lm_destroy": None, "omnitok_lm_cache_bytes": c_int64}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

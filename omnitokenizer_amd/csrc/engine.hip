@@ -114,8 +114,11 @@ struct omnitok_engine {
     float *dq_table = nullptr;  // [n_codes, dim] = E . post_vq^T + b (decode = row gather)
     std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
     std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
-    // workspace
+    // workspace: grow-only hipMalloc buffers, or slices of a caller-supplied block (omnitok_engine_set_workspace:
+    // the Python mirror hands over memory of PyTorch's caching allocator)
     Buf X, X2, Y, QKV, AO, HD, Z, ST;
+    float *ext_ws = nullptr;
+    int64_t ext_ws_bytes = 0;
     // fp16-split GEMM (gemm_mode 2): packed weights by fp32 weight pointer, device-side range slots
     std::map<const float *, H2W> h2w;
     float pe_bound[2] = {0.0f, 0.0f};
@@ -900,7 +903,8 @@ static int reset_bounds(omnitok_engine *e, int B, hipStream_t stream) {
     return OMNITOK_OK;
 }
 
-static int ensure_workspace(omnitok_engine *e, int64_t L) {
+// floats per token of the eight workspace buffers, in the order X, X2, Y, QKV, AO, HD, Z, ST
+static void workspace_widths(const omnitok_engine *e, int64_t (&wd)[8]) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim;
     const Geo g = geometry(c);
@@ -910,15 +914,38 @@ static int ensure_workspace(omnitok_engine *e, int64_t L) {
     int64_t hdw = e->inner_pad;
     if (kmax > hdw) hdw = kmax;
     if (2 * D > hdw) hdw = 2 * D;  // packed K | V of the fp16-split attention
-    if (int rc = ensure(e->X, L * D)) return rc;
-    if (int rc = ensure(e->X2, L * D)) return rc;
-    if (int rc = ensure(e->Y, L * D)) return rc;
-    if (int rc = ensure(e->QKV, L * 3 * D)) return rc;
-    if (int rc = ensure(e->AO, L * D)) return rc;
-    if (int rc = ensure(e->HD, L * hdw)) return rc;
-    if (int rc = ensure(e->Z, L * 8)) return rc;
-    if (int rc = ensure(e->ST, L * 2)) return rc;
+    const int64_t w[8] = {D, D, D, 3 * (int64_t)D, D, hdw, 8, 2};
+    for (int i = 0; i < 8; ++i) wd[i] = w[i];
+}
 
+static int64_t workspace_bytes_for(const omnitok_engine *e, int64_t L) {
+    int64_t wd[8], total = 0;
+    workspace_widths(e, wd);
+    for (int i = 0; i < 8; ++i) total += ((L * wd[i] * 4 + 255) / 256) * 256;
+    return total;
+}
+
+static int ensure_workspace(omnitok_engine *e, int64_t L) {
+    int64_t wd[8];
+    workspace_widths(e, wd);
+    Buf *bufs[8] = {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST};
+    if (e->ext_ws) {  // slices of the caller's block, 256-byte aligned
+        const int64_t need = workspace_bytes_for(e, L);
+        if (need > e->ext_ws_bytes) {
+            set_error("workspace of %lld bytes is too small: %lld tokens need %lld (omnitok_engine_workspace_need_*)",
+                      (long long)e->ext_ws_bytes, (long long)L, (long long)need);
+            return OMNITOK_ERR_STATE;
+        }
+        char *p = reinterpret_cast<char *>(e->ext_ws);
+        for (int i = 0; i < 8; ++i) {
+            bufs[i]->p = reinterpret_cast<float *>(p);
+            bufs[i]->cap = L * wd[i];
+            p += ((L * wd[i] * 4 + 255) / 256) * 256;
+        }
+        return OMNITOK_OK;
+    }
+    for (int i = 0; i < 8; ++i)
+        if (int rc = ensure(*bufs[i], L * wd[i])) return rc;
     return OMNITOK_OK;
 }
 
@@ -1056,8 +1083,9 @@ extern "C" void omnitok_engine_destroy(omnitok_engine *e) {
     for (auto &kv : e->w)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (void *p : e->owned) (void)hipFree(p);
-    for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST})
-        if (b->p) (void)hipFree(b->p);
+    if (!e->ext_ws)
+        for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST})
+            if (b->p) (void)hipFree(b->p);
     if (e->err_flag) (void)hipFree(e->err_flag);
     if (e->bounds) (void)hipFree(e->bounds);
     if (e->range_scratch) (void)hipFree(e->range_scratch);
@@ -1500,6 +1528,46 @@ extern "C" int omnitok_decode_vae(omnitok_engine *e, const float *z, int channel
     }
     return decode_latent(e, channel_first ? LatentKind::ChannelFirst : LatentKind::ChannelLast, z, B, T, gh, gw,
                          pixels_out, static_cast<hipStream_t>(stream_));
+}
+
+// tokens the workspace must hold for an encode of [B, C, F, H, W] / a decode of [B, T, h, w] latents
+static int64_t encode_peak_tokens(omnitok_engine *e, int B, int F, int H, int W_) {
+    const Geo g = geometry(e->cfg);
+    if (F < 1 || H % g.p_enc || W_ % g.p_enc || (F - 1) % g.pt_enc) return -1;
+    int gh = H / g.p_enc, gw = W_ / g.p_enc;
+    int64_t peak = (int64_t)gh * gw;
+    (void)walk_enc_grid(e->cfg.enc_block, &gh, &gw, &peak);
+    return (int64_t)B * (1 + (F - 1) / g.pt_enc) * peak;
+}
+
+extern "C" int64_t omnitok_engine_workspace_need_encode(omnitok_engine *e, int B, int F, int H, int W_) {
+    if (!e) return -1;
+    const int64_t L = encode_peak_tokens(e, B, F, H, W_);
+    return L < 0 ? -1 : workspace_bytes_for(e, L);
+}
+
+extern "C" int64_t omnitok_engine_workspace_need_decode(omnitok_engine *e, int B, int T, int gh, int gw) {
+    if (!e || T < 1 || gh < 1 || gw < 1) return -1;
+    const Geo g = geometry(e->cfg);
+    const int T2 = g.defer_t ? 1 + (T - 1) * 2 : T, up = g.defer_s ? 2 : 1;
+    return workspace_bytes_for(e, (int64_t)B * T2 * gh * up * gw * up);
+}
+
+extern "C" int omnitok_engine_set_workspace(omnitok_engine *e, void *dev_ptr, int64_t bytes) {
+    OT_CHECK_ARG(e, "set_workspace: null engine");
+    OT_CHECK_ARG((dev_ptr == nullptr) == (bytes == 0) && bytes >= 0, "set_workspace: pointer / size mismatch");
+    OT_CHECK_ARG((reinterpret_cast<uintptr_t>(dev_ptr) & 255) == 0, "set_workspace: the block must be 256-byte aligned");
+    Buf *bufs[8] = {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST};
+    if (!e->ext_ws)  // leaving the internal allocation: release it
+        for (Buf *b : bufs)
+            if (b->p) (void)hipFree(b->p);
+    for (Buf *b : bufs) {
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    e->ext_ws = static_cast<float *>(dev_ptr);
+    e->ext_ws_bytes = bytes;
+    return OMNITOK_OK;
 }
 
 extern "C" int64_t omnitok_engine_workspace_bytes(omnitok_engine *e) {

@@ -399,6 +399,10 @@ static int launch_h2(H2Params hp, hipStream_t stream) {
     if ((t == 1 || t == 5) && rpc % 256) t = 3;
     if (t == 6 && rpc % 128) t = 4;
     if (t == 3 && rpc % 128) t = 4;
+    // short-K GEMMs with a residual epilogue (to_out: K = 512, 1 GB of traffic for 86 GFLOP): two independent
+    // 128x256 workgroups per CU let one tile's residual loads / stores overlap the other's K loop
+    // (measured at C3: 0.429 -> 0.380 ms; profiles/r02_h2_tile_experiment.txt)
+    if (g_h2_tile == 0 && t == 1 && (FLAGS & OMNITOK_GEMM_RESIDUAL) && !LN && p.K <= 512 && rpc % 128 == 0) t = 6;
     constexpr bool GEGLU = (FLAGS & OMNITOK_GEMM_GEGLU) != 0;
     if constexpr (FLAGS == 0 && !LN) {
         if (t == 1 && g_h2_dbg) {

@@ -526,6 +526,71 @@ def _register():
     def _(q, k, v, q_scale, k_scale, T, heads, causal):
         return torch.empty_like(q)
 
+    @custom_op("omnitok::linear_geglu", mutates_args=(), device_types="cuda")
+    def _linear_geglu(x: torch.Tensor, w1_packed: torch.Tensor) -> torch.Tensor:
+        return linear_geglu(x.contiguous(), w1_packed.contiguous())
+
+    @_linear_geglu.register_fake
+    def _(x, w1_packed):
+        return x.new_empty(*x.shape[:-1], w1_packed.shape[0] // 2)
+
+    @custom_op("omnitok::patchify_ln", mutates_args=(), device_types="cuda")
+    def _patchify_ln(video: torch.Tensor, f0: int, t: int, pt: int, p: int, gamma: Optional[torch.Tensor] = None,
+                     beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return patchify_ln(video.contiguous(), f0, t, pt, p, gamma, beta)
+
+    @_patchify_ln.register_fake
+    def _(video, f0, t, pt, p, gamma=None, beta=None):
+        B, C, F, H, W = video.shape
+        return video.new_empty(B * t * (H // p) * (W // p), C * pt * p * p)
+
+    @custom_op("omnitok::unpatchify", mutates_args=("video",), device_types="cuda")
+    def _unpatchify(tok: torch.Tensor, video: torch.Tensor, f0: int, t: int, pt: int, p: int) -> None:
+        unpatchify(tok.contiguous(), video, f0, t, pt, p)
+
+    @custom_op("omnitok::qk_prep", mutates_args=("q", "k"), device_types="cuda")
+    def _qk_prep(q: torch.Tensor, k: torch.Tensor, n_tokens: int, heads: int, q_scale: torch.Tensor,
+                 k_scale: torch.Tensor, cos: Optional[torch.Tensor] = None, sin: Optional[torch.Tensor] = None,
+                 scale: float = 8.0) -> None:
+        qk_prep_(q, k, n_tokens, heads, q_scale, k_scale, cos, sin, scale)
+
+    @custom_op("omnitok::attn_spatial_h2", mutates_args=(), device_types="cuda")
+    def _attn_spatial_h2(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, n_tokens: int, heads: int,
+                         q_scale: torch.Tensor, k_scale: torch.Tensor, cos: Optional[torch.Tensor] = None,
+                         sin: Optional[torch.Tensor] = None, scale: float = 8.0) -> torch.Tensor:
+        """RoPE + l2norm + scales + softmax(q k^T) v on the fp16 matrix cores from RAW q, k, v (attn_pack +
+        attn_spatial_h2 of csrc/attn_h2.hip): the engine's spatial attention as one functional operator."""
+        packed, bounds = attn_pack(q, k, v, n_tokens, heads, q_scale, k_scale, cos, sin, scale)
+        return attn_spatial_h2(packed, bounds, q.shape[0] // n_tokens, n_tokens, heads)
+
+    @_attn_spatial_h2.register_fake
+    def _(q, k, v, n_tokens, heads, q_scale, k_scale, cos=None, sin=None, scale=8.0):
+        return q.new_empty(q.shape[0], heads * 64)
+
+    @custom_op("omnitok::pre_vq", mutates_args=(), device_types="cuda")
+    def _pre_vq(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, l2: bool = True) -> torch.Tensor:
+        return pre_vq(x.contiguous(), w.contiguous(), b, l2)
+
+    @_pre_vq.register_fake
+    def _(x, w, b, l2=True):
+        return x.new_empty(*x.shape[:-1], w.shape[0])
+
+    @custom_op("omnitok::dequant_post_vq", mutates_args=(), device_types="cuda")
+    def _dequant(ids: torch.Tensor, codebook: torch.Tensor, w: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return dequant_post_vq(ids.contiguous(), codebook.contiguous(), w.contiguous(), b)
+
+    @_dequant.register_fake
+    def _(ids, codebook, w, b):
+        return w.new_empty(*ids.shape, w.shape[0])
+
+    @custom_op("omnitok::gather_rows", mutates_args=(), device_types="cuda")
+    def _gather_rows(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        return gather_rows(ids.contiguous(), table.contiguous())
+
+    @_gather_rows.register_fake
+    def _(ids, table):
+        return table.new_empty(*ids.shape, table.shape[1])
+
     @custom_op("omnitok::peg3d", mutates_args=(), device_types="cuda")
     def _peg3d(x: torch.Tensor, w27: torch.Tensor, bias: torch.Tensor, B: int, T: int, H: int, W: int,
                causal: bool) -> torch.Tensor:
@@ -536,9 +601,6 @@ def _register():
         return torch.empty_like(x)
 
 
-try:
-    _register()
-    CUSTOM_OPS_REGISTERED = True
-except Exception as _e:  # registration is a convenience layer; the C ABI wrappers above are the API
-    CUSTOM_OPS_REGISTERED = False
-    _CUSTOM_OPS_ERROR = repr(_e)
+# the operators are part of the boundary: a registration failure is an import error
+_register()
+CUSTOM_OPS_REGISTERED = True

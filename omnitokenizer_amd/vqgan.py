@@ -11,8 +11,10 @@ hands device pointers to the native engine.  Inference only; there is no CPU fal
 from __future__ import annotations
 
 import ctypes
+import itertools
 import math
-from typing import Dict, Optional
+import weakref
+from typing import Dict, Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -62,6 +64,18 @@ def _on_own_device(fn):
     return wrapper
 
 
+# modules by handle: the omnitok::vqgan_encode / vqgan_decode custom ops take tensors and an integer handle
+_MODELS: "weakref.WeakValueDictionary[int, OmniTokenizer_VQGAN]" = weakref.WeakValueDictionary()
+_HANDLES = itertools.count(1)
+
+
+def _model(handle: int) -> "OmniTokenizer_VQGAN":
+    m = _MODELS.get(handle)
+    if m is None:
+        raise RuntimeError(f"omnitok::vqgan_*: no live OmniTokenizer_VQGAN with handle {handle}")
+    return m
+
+
 class OmniTokenizer_VQGAN(nn.Module):
     def __init__(self, args, attention_mode: Optional[str] = None):
         """args: the same Namespace the reference takes.  attention_mode: "sdpa" (what the
@@ -109,6 +123,9 @@ class OmniTokenizer_VQGAN(nn.Module):
         self._engine_dev = None
         self._version = getattr(self, "_version", 0)
         self._timing = False
+        self._workspace = None  # uint8 tensor of PyTorch's caching allocator lent to the engine (grow-only)
+        self._handle = next(_HANDLES)  # how the omnitok::vqgan_* custom ops find this module
+        _MODELS[self._handle] = self
 
     # ---- nn.Module plumbing -------------------------------------------------------------------
     @property
@@ -238,6 +255,44 @@ class OmniTokenizer_VQGAN(nn.Module):
         torch.cuda.current_stream().synchronize()
         self._engine_sig = sig
 
+    def _lend_workspace(self, need):
+        """The engine's activations live in a tensor of PyTorch's caching allocator (visible to
+        torch.cuda.memory_allocated, released with the module), grown when a larger call arrives."""
+        if need < 0:
+            return  # invalid shape: the native call reports it
+        if self._workspace is None or self._workspace.numel() < need:
+            torch.cuda.current_stream().synchronize()  # kernels of earlier calls may still read the old block
+            self._workspace = None
+            self._workspace = torch.empty(int(need * 1.02) + 256, dtype=torch.uint8, device=self.device)
+            ptr = (self._workspace.data_ptr() + 255) // 256 * 256
+            check(_lib.load().omnitok_engine_set_workspace(self._engine, ctypes.c_void_p(ptr),
+                                                           self._workspace.numel() - (ptr - self._workspace.data_ptr())),
+                  "set_workspace")
+
+    def latent_dims(self, F, H, W):
+        """(T', h, w) of encode() for [.., F, H, W] pixels from the configuration alone (no engine): what the
+        omnitok::vqgan_encode fake implementation and shape checks use."""
+        c = self.cfg
+        t = 1 + (F - 1) // c.enc_temporal_patch_size
+        h, w = H // c.enc_patch_size, W // c.enc_patch_size
+        for ch in c.enc_block:
+            if ch in "aml":
+                h, w = h // 2, w // 2
+            elif ch in "nr":
+                h, w = h * 2, w * 2
+        if c._defer_s:
+            h, w = h // 2, w // 2
+        if c._defer_t:
+            t = 1 + (t - 1) // 2
+        return t, h, w
+
+    def pixel_dims(self, T, h, w):
+        """(F, H, W) of decode() for [.., T', h, w] latents from the configuration alone."""
+        c = self.cfg
+        t = 1 + (T - 1) * 2 if c._defer_t else T
+        up = 2 if c._defer_s else 1
+        return 1 + (t - 1) * c.dec_temporal_patch_size, h * up * c.dec_patch_size, w * up * c.dec_patch_size
+
     # ---- the path -------------------------------------------------------------------------------
     @torch.no_grad()
     @_on_own_device
@@ -276,26 +331,42 @@ class OmniTokenizer_VQGAN(nn.Module):
                                  f"patch size ({pt})")  # reference omnitokenizer.py:931-932
         T, h, w = self._shape("encode", F, H, W)
         if self.use_vae:
+            self._lend_workspace(_lib.load().omnitok_engine_workspace_need_encode(self._engine, B, F, H, W))
             return self._encode_vae(x, is_image, (B, F, H, W, T, h, w), noise, sample_posterior, return_moments)
-        ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
+        # through the registered operator (omnitok::vqgan_encode): torch.compile / export see an op with a
+        # shape function instead of opaque Python
+        x5 = x if x.dim() == 5 else x[:, :, None]
+        ids, emb, z = torch.ops.omnitok.vqgan_encode(x5, self._handle, bool(include_embeddings), bool(return_latents))
         if not include_embeddings:
             emb = None
-        elif self.use_external_codebook:  # project_out(embed[ids]), token-major from the engine
-            emb = torch.empty(B, T, h, w, self.cfg.dim, device=x.device)
-        else:
-            emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device)
-        z = torch.empty(B, T, h, w, self.cfg.codebook_dim, device=x.device) if return_latents else None
-        lib = _lib.load()
-        check(lib.omnitok_encode(self._engine, ctypes.c_void_p(x.data_ptr()), B, F, H, W,
-                                 ctypes.c_void_p(ids.data_ptr()),
-                                 None if emb is None else ctypes.c_void_p(emb.data_ptr()),
-                                 None if z is None else ctypes.c_void_p(z.data_ptr()),
-                                 torch.cuda.current_stream().cuda_stream), "encode")
-        if emb is not None and self.use_external_codebook:
+        elif self.use_external_codebook:
             emb = emb.permute(0, 4, 1, 2, 3)  # 'b (t h w) c -> b c t h w', vector_quantize_pytorch.py:1077
         if return_latents:
             return (emb, ids, z) if include_embeddings else (ids, z)
         return (emb, ids) if include_embeddings else ids
+
+    def _encode_native(self, x, want_emb, want_z):
+        """omnitok::vqgan_encode on CUDA tensors: x [B, C, F, H, W] fp32 contiguous -> (ids, emb, z); emb / z are
+        empty tensors when not requested."""
+        self._sync_engine()
+        B, C, F, H, W = x.shape
+        T, h, w = self._shape("encode", F, H, W)
+        lib = _lib.load()
+        self._lend_workspace(lib.omnitok_engine_workspace_need_encode(self._engine, B, F, H, W))
+        ids = torch.empty(B, T, h, w, device=x.device, dtype=torch.int64)
+        if not want_emb:
+            emb = x.new_empty(0)
+        elif self.use_external_codebook:  # project_out(embed[ids]), token-major from the engine
+            emb = torch.empty(B, T, h, w, self.cfg.dim, device=x.device)
+        else:
+            emb = torch.empty(B, self.cfg.codebook_dim, T, h, w, device=x.device)
+        z = torch.empty(B, T, h, w, self.cfg.codebook_dim, device=x.device) if want_z else x.new_empty(0)
+        check(lib.omnitok_encode(self._engine, ctypes.c_void_p(x.data_ptr()), B, F, H, W,
+                                 ctypes.c_void_p(ids.data_ptr()),
+                                 ctypes.c_void_p(emb.data_ptr()) if want_emb else None,
+                                 ctypes.c_void_p(z.data_ptr()) if want_z else None,
+                                 torch.cuda.current_stream().cuda_stream), "encode")
+        return ids, emb, z
 
     def _shape(self, which, a, b, c):
         """latent <-> pixel shapes from the engine (pooling blocks, deferred pools and gen_upscale
@@ -363,6 +434,7 @@ class OmniTokenizer_VQGAN(nn.Module):
                              f"({'channel-first' if channel_first else 'channel-last'} layout)")
         c = self.cfg
         F, Ho, Wo = self._shape("decode", T, h, w)
+        self._lend_workspace(_lib.load().omnitok_engine_workspace_need_decode(self._engine, B, T, h, w))
         out = torch.empty(B, c.image_channels, F, Ho, Wo, device=z.device, dtype=torch.float32)
         check(_lib.load().omnitok_decode_vae(self._engine, ctypes.c_void_p(z.data_ptr()), channel_first, B, T, h, w,
                                              ctypes.c_void_p(out.data_ptr()),
@@ -398,13 +470,9 @@ class OmniTokenizer_VQGAN(nn.Module):
         B, T, h, w = ids.shape
         if is_image and T != 1:
             raise ValueError("is_image=True expects a single latent frame")
-        c = self.cfg
-        F, Ho, Wo = self._shape("decode", T, h, w)
-        out = torch.empty(B, c.image_channels, F, Ho, Wo, device=ids.device, dtype=torch.float32)
+        out = torch.ops.omnitok.vqgan_decode(ids, self._handle)
         lib = _lib.load()
         stream = torch.cuda.current_stream().cuda_stream
-        check(lib.omnitok_decode(self._engine, ctypes.c_void_p(ids.data_ptr()), B, T, h, w,
-                                 ctypes.c_void_p(out.data_ptr()), stream), "decode")
         if check_ids is None:
             # like the reference's F.embedding, out-of-range ids raise; the check is one int read-back (a
             # host synchronisation), so it is skipped by default only while a HIP graph is being captured
@@ -415,6 +483,18 @@ class OmniTokenizer_VQGAN(nn.Module):
                 raise IndexError(lib.omnitok_last_error().decode())
             check(rc, "check_ids")
         return out[:, :, 0] if is_image else out
+
+    def _decode_native(self, ids):
+        """omnitok::vqgan_decode on CUDA tensors: ids [B, T', h, w] int64 contiguous -> pixels [B, C, F, H, W]."""
+        self._sync_engine()
+        B, T, h, w = ids.shape
+        F, Ho, Wo = self._shape("decode", T, h, w)
+        lib = _lib.load()
+        self._lend_workspace(lib.omnitok_engine_workspace_need_decode(self._engine, B, T, h, w))
+        out = torch.empty(B, self.cfg.image_channels, F, Ho, Wo, device=ids.device, dtype=torch.float32)
+        check(lib.omnitok_decode(self._engine, ctypes.c_void_p(ids.data_ptr()), B, T, h, w,
+                                 ctypes.c_void_p(out.data_ptr()), torch.cuda.current_stream().cuda_stream), "decode")
+        return out
 
     def forward(self, x, optimizer_idx=None, log_image=False):
         """The inference use of reference VQGAN.forward (omnitokenizer.py:330-413,
@@ -496,3 +576,45 @@ def load_vqgan(tokenizer, vqgan_ckpt, device=torch.device("cpu"), **kw):
     vqgan = OmniTokenizer_VQGAN.load_from_checkpoint(vqgan_ckpt, strict=False, **kw).to(device)
     vqgan.eval()
     return vqgan
+
+
+# ------------------------------------------------------------------------------------------------
+# encode / decode as PyTorch operators (omnitok::vqgan_encode, omnitok::vqgan_decode): the module's methods go
+# through them, and the fake (meta) implementations give torch.compile / torch.export the output shapes.
+# Registration failure is an import error: the operators ARE the encode/decode path.
+# ------------------------------------------------------------------------------------------------
+def _register_ops():
+    from torch.library import custom_op
+
+    @custom_op("omnitok::vqgan_encode", mutates_args=(), device_types="cuda")
+    def _enc(x: torch.Tensor, handle: int, want_emb: bool, want_z: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        return _model(handle)._encode_native(x.contiguous(), want_emb, want_z)
+
+    @_enc.register_fake
+    def _(x, handle, want_emb, want_z):
+        m = _model(handle)
+        B, C, F, H, W = x.shape
+        T, h, w = m.latent_dims(F, H, W)
+        ids = x.new_empty((B, T, h, w), dtype=torch.int64)
+        if not want_emb:
+            emb = x.new_empty(0)
+        elif m.use_external_codebook:
+            emb = x.new_empty((B, T, h, w, m.cfg.dim))
+        else:
+            emb = x.new_empty((B, m.cfg.codebook_dim, T, h, w))
+        z = x.new_empty((B, T, h, w, m.cfg.codebook_dim)) if want_z else x.new_empty(0)
+        return ids, emb, z
+
+    @custom_op("omnitok::vqgan_decode", mutates_args=(), device_types="cuda")
+    def _dec(ids: torch.Tensor, handle: int) -> torch.Tensor:
+        return _model(handle)._decode_native(ids.contiguous())
+
+    @_dec.register_fake
+    def _(ids, handle):
+        m = _model(handle)
+        B, T, h, w = ids.shape
+        F, H, W = m.pixel_dims(T, h, w)
+        return ids.new_empty((B, m.cfg.image_channels, F, H, W), dtype=torch.float32)
+
+
+_register_ops()

@@ -163,6 +163,48 @@ def test_torch_custom_ops_registered_with_schemas(lib):
         assert tuple(y.shape) == (7, 192)
         q = torch.empty(2048, 512, device="cuda")
         assert tuple(torch.ops.omnitok.attn_spatial(q, q, q, 1024, 8).shape) == (2048, 512)
+        # the rest of the operator set
+        s64 = torch.empty(64, device="cuda")
+        assert tuple(torch.ops.omnitok.attn_spatial_h2(q, q, q, 1024, 8, s64, s64).shape) == (2048, 512)
+        assert tuple(torch.ops.omnitok.linear_geglu(q, torch.empty(2816, 512, device="cuda")).shape) == (2048, 1408)
+        vid = torch.empty(2, 3, 17, 256, 256, device="cuda")
+        assert tuple(torch.ops.omnitok.patchify_ln(vid, 1, 4, 4, 8).shape) == (2 * 4 * 1024, 3 * 4 * 64)
+        assert tuple(torch.ops.omnitok.pre_vq(q, torch.empty(8, 512, device="cuda"), torch.empty(8, device="cuda")).shape) \
+            == (2048, 8)
+        idl = torch.empty(2, 5, 32, 32, dtype=torch.int64, device="cuda")
+        w, b = torch.empty(512, 8, device="cuda"), torch.empty(512, device="cuda")
+        assert tuple(torch.ops.omnitok.dequant_post_vq(idl, torch.empty(8192, 8, device="cuda"), w, b).shape) == (2, 5, 32, 32, 512)
+        assert tuple(torch.ops.omnitok.gather_rows(idl, torch.empty(8192, 512, device="cuda")).shape) == (2, 5, 32, 32, 512)
+    for name in ("unpatchify", "qk_prep"):   # in-place operators: schema carries the mutation
+        assert "!)" in str(getattr(torch.ops.omnitok, name).default._schema)
+
+
+def test_vqgan_encode_decode_are_registered_operators():
+    """OmniTokenizer_VQGAN.encode / decode run through omnitok::vqgan_encode / vqgan_decode; their fake
+    implementations infer the shapes of every configuration family without a GPU."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args
+    cases = [(dict(), (2, 3, 17, 256, 256), (2, 5, 32, 32)),
+             (dict(enc_block="tawl", resolution=128), (1, 3, 5, 128, 128), (1, 2, 4, 4)),
+             (dict(enc_block="ttnw", resolution=64), (1, 3, 5, 64, 64), (1, 2, 16, 16)),
+             (dict(defer_spatial_pool=True, defer_temporal_pool=True, resolution=128), (1, 3, 9, 128, 128), (1, 3, 16, 16)),
+             (dict(gen_upscale=2, resolution=64), (1, 3, 5, 64, 64), (1, 2, 8, 8))]
+    for over, xs, ids_shape in cases:
+        m = OmniTokenizer_VQGAN(make_args(2, **over))
+        with FakeTensorMode():
+            x = torch.empty(*xs, device="cuda")
+            ids, emb, z = torch.ops.omnitok.vqgan_encode(x, m._handle, True, True)
+            assert tuple(ids.shape) == ids_shape and ids.dtype == torch.int64
+            assert tuple(emb.shape) == (ids_shape[0], 8) + ids_shape[1:] and tuple(z.shape) == ids_shape + (8,)
+            pix = torch.ops.omnitok.vqgan_decode(ids, m._handle)
+            # the decoder works from the latent grid: pooling / Up blocks of the encoder are not undone
+            side = ids_shape[2] * m.cfg.dec_patch_size * (2 if over.get("defer_spatial_pool") else 1)
+            assert tuple(pix.shape) == (xs[0], 3, xs[2], side, side), (over, pix.shape)
+    with FakeTensorMode(), pytest.raises(RuntimeError, match="handle"):
+        torch.ops.omnitok.vqgan_decode(torch.empty(1, 1, 8, 8, dtype=torch.int64, device="cuda"), 10 ** 9)
+    with pytest.raises(NotImplementedError):   # CPU tensors: the operator exists for the GPU only (no fallback)
+        torch.ops.omnitok.vqgan_decode(torch.empty(1, 1, 8, 8, dtype=torch.int64), 10 ** 9)
 
 
 def test_lm_argument_errors_without_gpu(lib):

@@ -465,3 +465,43 @@ def test_external_codebook_vs_reference_golden(models, name):
     if flips == 0:
         assert abs(float(out["perplexity"]) - c.perplexity) < 1e-3 * c.perplexity
     print(f"{name}: id flips {flips}, z err {zerr:.1e}, pixel err {err:.1e}")
+
+
+def test_workspace_is_torch_memory_and_the_c_abi_still_owns_one():
+    """The Python mirror lends the engine a block of PyTorch's caching allocator (sized by
+    omnitok_engine_workspace_need_*); the bare C ABI keeps its own grow-only buffers.  Same results either way,
+    and encode / decode run through the registered operators."""
+    import ctypes
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib
+    c = GoldenCase("s2_sdpa_r64_vid")
+    m = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
+    m.load_state_dict(c.sd, strict=True)
+    m = m.cuda().eval()
+    x = c.x.cuda()
+    before = torch.cuda.memory_allocated()
+    ids = m.encode(x, False)
+    assert torch.equal(ids.cpu(), c.ids)
+    lib = _lib.load()
+    need = lib.omnitok_engine_workspace_need_encode(m._engine, *[x.shape[i] for i in (0, 2, 3, 4)])
+    assert need > 0 and m._workspace is not None and m._workspace.numel() >= need
+    assert torch.cuda.memory_allocated() - before >= need             # visible to torch's accounting
+    assert lib.omnitok_engine_workspace_bytes(m._engine) <= m._workspace.numel()
+    ids_op, _, _ = torch.ops.omnitok.vqgan_encode(x, m._handle, False, False)
+    assert torch.equal(ids_op, ids)
+    rec = m.decode(ids, False)
+    assert torch.equal(torch.ops.omnitok.vqgan_decode(ids, m._handle), rec)
+    # a too-small caller block is an error, not an overrun
+    small = torch.empty(4096, dtype=torch.uint8, device="cuda")
+    assert lib.omnitok_engine_set_workspace(m._engine, ctypes.c_void_p(small.data_ptr()), small.numel()) == 0
+    out = torch.empty_like(ids)
+    rc = lib.omnitok_encode(m._engine, ctypes.c_void_p(x.data_ptr()), *[x.shape[i] for i in (0, 2, 3, 4)],
+                            ctypes.c_void_p(out.data_ptr()), None, None, torch.cuda.current_stream().cuda_stream)
+    assert rc != 0 and b"too small" in lib.omnitok_last_error()
+    # back to the engine's own allocation (what a C caller gets by default)
+    assert lib.omnitok_engine_set_workspace(m._engine, None, 0) == 0
+    m._workspace = None
+    rc = lib.omnitok_encode(m._engine, ctypes.c_void_p(x.data_ptr()), *[x.shape[i] for i in (0, 2, 3, 4)],
+                            ctypes.c_void_p(out.data_ptr()), None, None, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(out, ids)
+    assert lib.omnitok_engine_workspace_bytes(m._engine) > 0

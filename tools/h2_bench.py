@@ -20,6 +20,9 @@ def main():
     ap.add_argument("--clips", type=int, default=32)
     ap.add_argument("--tiles", default="1")
     ap.add_argument("--skip-check", action="store_true")
+    ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const"],
+                    help="operand values of the speed section: the DVFS check of MI355X_MICROARCH.md (same binary, "
+                         "zero-filled inputs toggle fewer bits -> higher clocks if the kernel is power-bound)")
     a = ap.parse_args()
     g = torch.Generator(device="cuda").manual_seed(0)
     r = lambda *s: torch.randn(*s, device="cuda", generator=g)  # noqa: E731
@@ -77,6 +80,12 @@ def main():
     _lib.set_option("h2_tile", 0)
     print("tiling independence (bitwise):", bool(torch.equal(big[:100], small)))
 
+    if a.data != "randn":
+        r0 = r
+        if a.data == "zeros":
+            r = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+        else:
+            r = lambda *s: torch.full(s, 0.5, device="cuda")  # noqa: E731
     L = a.clips * 5120
     D = 512
     x = r(L, D)
