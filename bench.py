@@ -151,8 +151,13 @@ def main():
         # HBM traffic per launch of the dominant kernel, from the committed PMC passes (rocprofv3
         # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied; bench.py cannot
         # collect counters itself).  null if no PMC run covers this kernel / workload.
+        pmc = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"gemm_mode_{a.gemm_mode}", {})
+            if is_gemm and "dvfs_check" in pmc:
+                # the same binary on constant operands: what the kernel reaches when the chip is not clocking down
+                # under the data-dependent power of random operands (MI355X_MICROARCH.md "DVFS give-back")
+                roofline["power_limit_evidence"] = pmc["dvfs_check"]
             if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
                 roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
                 roofline["traffic_source"] = pmc[dom]["source"]
@@ -170,6 +175,12 @@ def main():
             vq_bytes = L * 40 + cfg.n_codes * 32
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3)
                                                            / 1e9, 2)
+            if "vq_argmin" in pmc and B == 32 and a.frames == 17 and a.resolution == 256 and cfg.n_codes == 8192:
+                # counted memory-side bytes of the sweep (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)
+                kernels["vq_argmin"]["traffic"] = pmc["vq_argmin"]["read_bytes"] + pmc["vq_argmin"]["write_bytes"]
+                kernels["vq_argmin"]["traffic_gbs"] = round(kernels["vq_argmin"]["traffic"]
+                                                            / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 1)
+                kernels["vq_argmin"]["traffic_source"] = pmc["vq_argmin"]["source"]
 
         if is_image:
             wl_name = "C2" if (B, a.resolution) == (64, 256) else "images"
@@ -192,7 +203,8 @@ def main():
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
                        "parallelism": f"clip-sharded x{world}"},
             "rccl_world_size": res.world_seen, "ids_crc32": res.ids_crc, "allgather_ms": res.allgather_ms,
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
+            "kernels": kernels,
             "workspace_gb": round(model.workspace_bytes() / 2**30, 2),
         }
 

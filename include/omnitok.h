@@ -69,6 +69,11 @@ int omnitok_layernorm(const float *x, const float *gamma, const float *beta, flo
                       int64_t rows, int dim, float eps,
                       int64_t rows_per_group, int64_t group_stride, int64_t group_offset,
                       omnitok_stream_t stream);
+/* The same LayerNorm with the token transpose '(n a c) d -> (n c a) d' fused into the store (y != x): the final
+ * norm_out of a Transformer followed by the rearrange to the other stage's token order
+ * (reference omnitokenizer.py:894-903, 1072-1084). */
+int omnitok_layernorm_transposed(const float *x, const float *gamma, const float *beta, float *y, int64_t n, int a,
+                                 int c, int dim, float eps, omnitok_stream_t stream);
 
 /* Epilogue flags of omnitok_gemm */
 #define OMNITOK_GEMM_BIAS 1      /* + bias[n]                                               */
@@ -284,6 +289,10 @@ int omnitok_dequant_table(const float *codebook, int n_codes, int cdim, const fl
                           float *table, int D, int64_t *scratch_ids, omnitok_stream_t stream);
 int omnitok_gather_rows(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n, int D,
                         int *err_flag, omnitok_stream_t stream);
+/* ... with the token transpose '(b a c) d -> (b c a) d' fused into the store (n = b*a*c rows; a = c = 0: none):
+ * the reference's rearranges between its spatial and temporal stages (omnitokenizer.py:1072, 1081). */
+int omnitok_gather_rows_transposed(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n,
+                                   int a, int c, int D, int *err_flag, omnitok_stream_t stream);
 
 /* --use_vae posterior sample (reference modules/vae.py:4-17 on top of pre_vq_conv with 2*cdim
  * outputs): h = x[n,:] . w[2*cdim, D]^T + b, n = B*thw rows in (b, thw) order;

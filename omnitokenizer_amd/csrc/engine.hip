@@ -684,8 +684,10 @@ static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *
 
 // One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
 // Pooling blocks shrink the token grid (attention.py:683-684): *ghp / *gwp are updated.
+// transpose_out: the final LayerNorm stores its rows in the OTHER stage's token order ('(b t)(h w)' <-> '(b h w) t'),
+// i.e. the rearrange that follows every Transformer on the path is fused into the norm_out store.
 static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
-                           hipStream_t stream) {
+                           hipStream_t stream, bool transpose_out = false) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim, heads = c.heads;
     int gh = *ghp, gw = *gwp;
@@ -881,8 +883,13 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                            e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
         }
     }
-    OT_RUN("layernorm", 2.0 * L * D * 4.0,
-           omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
+    if (transpose_out && T > 1)  // rows (b, t, s) -> (b, s, t) after a spatial stage, (b, s, t) -> (b, t, s) after a temporal one
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm_transposed(e->X.p, tw.og, tw.ob, e->X2.p, B, spatial ? T : S, spatial ? S : T, D, 1e-5f,
+                                            stream));
+    else
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
     std::swap(e->X, e->X2);
     *ghp = gh;
     *gwp = gw;
@@ -1321,18 +1328,11 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
                                  goff, stream));
     }
     // ---- spatial then temporal transformer (reference omnitokenizer.py:891-903) -------------
-    if (int rc = run_transformer(e, e->enc_s, B, T, &gh, &gw, true, stream)) return rc;
+    // the rearranges '(b t)(h w) d -> (b h w) t d' and back (omnitokenizer.py:900, 906) ride on the norm_out stores
+    if (int rc = run_transformer(e, e->enc_s, B, T, &gh, &gw, true, stream, true)) return rc;
     const int S2 = gh * gw;  // pooling blocks shrink the grid, omnitokenizer.py:898-899
     const int64_t L2 = (int64_t)B * T * S2;
-    if (T > 1) {
-        OT_RUN("transpose", 2.0 * L2 * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T, S2, D, stream));
-        std::swap(e->X, e->X2);
-    }
-    if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream)) return rc;
-    if (T > 1) {
-        OT_RUN("transpose", 2.0 * L2 * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S2, T, D, stream));
-        std::swap(e->X, e->X2);
-    }
+    if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream, true)) return rc;
     // ---- deferred pools (reference omnitokenizer.py:907-914) ---------------------------------
     if (g.defer_s) {
         OT_RUN("pool", 1.25 * L2 * D * 4.0,
@@ -1425,10 +1425,13 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
         // the out-of-range flag reports on THIS decode only (omnitok_engine_check_ids)
         OT_HIP(hipMemsetAsync(e->err_flag, 0, sizeof(int), stream));
     }
+    // ids straight into the temporal stage's '(b h w) t' order when nothing sits between (no deferred up-sampling)
+    const bool fuse_first_transpose = kind == LatentKind::Ids && !g.defer_t && !g.defer_s && T > 1;
     if (kind == LatentKind::Ids)
         OT_RUN("dequant_post_vq", (double)L0 * D * 4.0,
-               omnitok_gather_rows(static_cast<const int64_t *>(latent), e->dq_table, c.n_codes, e->X.p, L0, D,
-                                   e->err_flag, stream));
+               omnitok_gather_rows_transposed(static_cast<const int64_t *>(latent), e->dq_table, c.n_codes, e->X.p, L0,
+                                              fuse_first_transpose ? T : 0, fuse_first_transpose ? gh * gw : 0, D,
+                                              e->err_flag, stream));
     else
         OT_RUN("post_vq", (double)L0 * D * 4.0,
                omnitok_post_vq(static_cast<const float *>(latent), kind == LatentKind::ChannelFirst, B,
@@ -1447,15 +1450,11 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     }
     int ghc = gh2, gwc = gw2;
     // temporal first on decode (reference omnitokenizer.py:1072-1084)
-    if (T2 > 1) {
+    if (T2 > 1 && !fuse_first_transpose) {
         OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, T2, S, D, stream));
         std::swap(e->X, e->X2);
     }
-    if (int rc = run_transformer(e, e->dec_t, B, T2, &ghc, &gwc, false, stream)) return rc;
-    if (T2 > 1) {
-        OT_RUN("transpose", 2.0 * L * D * 4.0, omnitok_transpose_tokens(e->X.p, e->X2.p, B, S, T2, D, stream));
-        std::swap(e->X, e->X2);
-    }
+    if (int rc = run_transformer(e, e->dec_t, B, T2, &ghc, &gwc, false, stream, true)) return rc;
     if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream)) return rc;
     // ---- to_pixels (reference omnitokenizer.py:1006-1033, 1089-1096) -------------------------
     OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,

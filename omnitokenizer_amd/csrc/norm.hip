@@ -29,7 +29,7 @@ __device__ __forceinline__ void row_stats(const f32x4 *v, int nv, int lane, int 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ y,
                                                         int64_t rows, int dim, float eps, int64_t rpg,
-                                                        int64_t gstride, int64_t goff) {
+                                                        int64_t gstride, int64_t goff, int tr_a, int tr_c) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -43,6 +43,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     row_stats(v, nv, lane, dim, eps, mean, rstd);
     int64_t orow = row;
     if (rpg > 0) orow = (row / rpg) * gstride + goff + (row % rpg);
+    if (tr_a > 0) {  // token transpose fused into the store: row (b, a, c) -> (b, c, a)
+        const int64_t c = row % tr_c, ba = row / tr_c;
+        orow = ((ba / tr_a) * tr_c + c) * tr_a + ba % tr_a;
+    }
     f32x4 *yr = reinterpret_cast<f32x4 *>(y + orow * dim);
     const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
@@ -254,8 +258,23 @@ extern "C" int omnitok_layernorm(const float *x, const float *gamma, const float
                  "layernorm: pointers must be 16-byte aligned");
     if (rows == 0) return OMNITOK_OK;
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y,
-                       rows, dim, eps, rows_per_group, group_stride, group_offset);
+                       rows, dim, eps, rows_per_group, group_stride, group_offset, 0, 0);
     OT_LAUNCH_CHECK("layernorm");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_layernorm_transposed(const float *x, const float *gamma, const float *beta, float *y, int64_t n,
+                                            int a, int c, int dim, float eps, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && gamma && y && x != y, "layernorm_transposed: null pointer / in-place");
+    OT_CHECK_ARG(dim > 0 && dim % 4 == 0 && dim <= 256 * LN_MAX_V4 && a > 0 && c > 0, "layernorm_transposed: bad shape");
+    OT_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && (!beta || aligned16(beta)),
+                 "layernorm_transposed: pointers must be 16-byte aligned");
+    const int64_t rows = n * a * c;
+    if (rows == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y,
+                       rows, dim, eps, (int64_t)0, (int64_t)0, (int64_t)0, a, c);
+    OT_LAUNCH_CHECK("layernorm_transposed");
     return OMNITOK_OK;
 }
 

@@ -114,12 +114,10 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
 
     // Sweep: per 32-code tile only the lane's minimum distance (v_min3 tree, ~2.5 VALU per element instead of
     // the 5 of a running (value, index) pair) and the tile that holds it; strict '<' keeps the FIRST tile of a tie.
+    // Software pipeline: the 8 MFMAs of tile t + 1 are issued with the epilogue of tile t (two accumulator sets),
+    // so a wave's VALU work sits beside its own matrix instructions instead of after them.
     const f32x4 *pk = reinterpret_cast<const f32x4 *>(packed) + lane;
-    f32x4 a_next = pk[(int64_t)t0 * 64];
-    for (int t = t0; t < t1; ++t) {
-        const f32x4 a = a_next;
-        if (t + 1 < t1) a_next = pk[(int64_t)(t + 1) * 64];
-        f32x16 acc[2];
+    auto dots = [&](const f32x4 &a, f32x16 (&acc)[2]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -128,26 +126,81 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
             for (int s = 0; s < 4; ++s)
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xb[g][s], acc[g], 0, 0, 0);
         }
+    };
+    // one quarter (q) of a tile's epilogue: the lane's 4 codes cbase + 8 q + (0..3) of both row groups
+    auto epi_quarter = [&](int t, int q, const f32x16 (&acc)[2], float (&tmin)[2]) {
         const int cbase = t * 32 + 4 * hi;
-        float tmin[2] = {INFINITY, INFINITY};
+        const f32x4 e4 = MODE == VQ_COS ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
+                             : *reinterpret_cast<const f32x4 *>(ee_s + cbase - c0 + 8 * q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 e4 = MODE == VQ_COS ? f32x4{0.0f, 0.0f, 0.0f, 0.0f}
-                                 : *reinterpret_cast<const f32x4 *>(ee_s + cbase - c0 + 8 * q);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const float d0 = dist(xx[g], acc[g][q * 4 + 0], e4[0]), d1 = dist(xx[g], acc[g][q * 4 + 1], e4[1]);
-                const float d2 = dist(xx[g], acc[g][q * 4 + 2], e4[2]), d3 = dist(xx[g], acc[g][q * 4 + 3], e4[3]);
-                tmin[g] = fminf(fminf(tmin[g], d0), d1);
-                tmin[g] = fminf(fminf(tmin[g], d2), d3);
+        for (int g = 0; g < 2; ++g) {
+            float d0, d1, d2, d3;
+            if constexpr (MODE == VQ_EUCLID) {
+                d0 = dist(xx[g], acc[g][q * 4 + 0], e4[0]); d1 = dist(xx[g], acc[g][q * 4 + 1], e4[1]);
+                d2 = dist(xx[g], acc[g][q * 4 + 2], e4[2]); d3 = dist(xx[g], acc[g][q * 4 + 3], e4[3]);
+            } else {
+                // (xx - dot) + ee on register pairs: v_pk_add_f32 rounds each half like the scalar add
+                // (IEEE, no contraction), so the distances are bit-identical at half the issue slots
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                const f32x2 x2 = {xx[g], xx[g]};
+                const f32x2 a01 = {acc[g][q * 4 + 0], acc[g][q * 4 + 1]}, a23 = {acc[g][q * 4 + 2], acc[g][q * 4 + 3]};
+                const f32x2 e01 = {e4[0], e4[1]}, e23 = {e4[2], e4[3]};
+                const f32x2 r01 = (x2 - a01) + e01, r23 = (x2 - a23) + e23;
+                d0 = r01[0]; d1 = r01[1]; d2 = r23[0]; d3 = r23[1];
             }
+            tmin[g] = fminf(fminf(tmin[g], d0), d1);
+            tmin[g] = fminf(fminf(tmin[g], d2), d3);
         }
+    };
+    auto commit = [&](int t, const float (&tmin)[2]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
             if (tmin[g] < best[g]) {
                 best[g] = tmin[g];
                 btile[g] = t;
             }
+    };
+    auto epilogue = [&](int t, const f32x16 (&acc)[2]) {
+        float tmin[2] = {INFINITY, INFINITY};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) epi_quarter(t, q, acc, tmin);
+        commit(t, tmin);
+    };
+    // MFMA step s of the NEXT tile (both row groups) followed by quarter s of the CURRENT tile's epilogue; the
+    // scheduling barriers pin that issue order (the wave issues in order: eight MFMAs back to back would hold the
+    // VALU work behind the matrix pipe, and the compiler otherwise groups them)
+    auto fused = [&](const f32x4 &a, f32x16 (&nxt)[2], int t, const f32x16 (&cur)[2]) {
+        float tmin[2] = {INFINITY, INFINITY};
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nxt[g][r] = 0.0f;
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            nxt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sq], xb[0][sq], nxt[0], 0, 0, 0);
+            nxt[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sq], xb[1][sq], nxt[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            epi_quarter(t, sq, cur, tmin);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        commit(t, tmin);
+    };
+    f32x16 accA[2], accB[2];
+    f32x4 a_cur = pk[(int64_t)t0 * 64];
+    dots(a_cur, accA);
+    int t = t0;
+    for (; t + 2 < t1; t += 2) {   // tiles t, t + 1 complete here; t + 2 is in flight at the end
+        const f32x4 a1 = pk[(int64_t)(t + 1) * 64];
+        const f32x4 a2 = pk[(int64_t)(t + 2) * 64];
+        fused(a1, accB, t, accA);
+        fused(a2, accA, t + 1, accB);
+    }
+    if (t + 1 < t1) {              // two tiles left: t (in flight) and t + 1
+        const f32x4 a1 = pk[(int64_t)(t + 1) * 64];
+        fused(a1, accB, t, accA);
+        epilogue(t + 1, accB);
+    } else {
+        epilogue(t, accA);
     }
     // Resolve the index: redo the lane's 16 codes of its winning tile with the same arithmetic -- the fp32 MFMA is
     // bitwise the k-ordered fmaf chain from 0 (oracle/vq_argmin.c), so the scalar chain reproduces the distances --
@@ -277,7 +330,8 @@ __global__ __launch_bounds__(256) void dequant_post_vq_kernel(const int64_t *__r
 // L2 / Infinity-Cache resident table (16 MiB at 8192 x 512): one 16-byte load + store per thread.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t *__restrict__ ids,
                                                           const f32x4 *__restrict__ table, int n_codes,
-                                                          f32x4 *__restrict__ tok, int64_t n, int d4n, int *err_flag) {
+                                                          f32x4 *__restrict__ tok, int64_t n, int d4n, int *err_flag,
+                                                          int tr_a, int tr_c) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= n * d4n) return;
     const int64_t row = gid / d4n;
@@ -287,7 +341,12 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t *__restr
         if (err_flag) atomicOr(err_flag, 1);
         id = 0;
     }
-    __builtin_nontemporal_store(table[id * d4n + c4], tok + gid);
+    int64_t orow = row;
+    if (tr_a > 0) {  // token transpose fused into the store: row (b, a, c) -> (b, c, a)
+        const int64_t c = row % tr_c, ba = row / tr_c;
+        orow = ((ba / tr_a) * tr_c + c) * tr_a + ba % tr_a;
+    }
+    __builtin_nontemporal_store(table[id * d4n + c4], tok + orow * d4n + c4);
 }
 
 __global__ void iota_i64_kernel(int64_t *__restrict__ out, int n) {
@@ -563,14 +622,21 @@ extern "C" int omnitok_dequant_table(const float *codebook, int n_codes, int cdi
 
 extern "C" int omnitok_gather_rows(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n, int D,
                                    int *err_flag, omnitok_stream_t stream_) {
+    return omnitok_gather_rows_transposed(ids, table, n_codes, tok, n, 0, 0, D, err_flag, stream_);
+}
+
+extern "C" int omnitok_gather_rows_transposed(const int64_t *ids, const float *table, int n_codes, float *tok, int64_t n,
+                                              int a, int c, int D, int *err_flag, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(ids && table && tok, "gather_rows: null pointer");
     OT_CHECK_ARG(D % 4 == 0 && aligned16(table) && aligned16(tok), "gather_rows: need D %% 4 == 0 and 16-byte alignment");
+    OT_CHECK_ARG((a == 0 && c == 0) || (a > 0 && c > 0 && n % ((int64_t)a * c) == 0),
+                 "gather_rows: %lld rows are not whole [a=%d, c=%d] groups", (long long)n, a, c);
     if (n == 0) return OMNITOK_OK;
     const int64_t total = n * (D / 4);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ids,
                        reinterpret_cast<const f32x4 *>(table), n_codes, reinterpret_cast<f32x4 *>(tok), n, D / 4,
-                       err_flag);
+                       err_flag, a, c);
     OT_LAUNCH_CHECK("gather_rows");
     return OMNITOK_OK;
 }

@@ -67,6 +67,18 @@ def layernorm(x, gamma, beta=None, eps=1e-5):
     return y
 
 
+def layernorm_transposed(x, gamma, beta, n, a, c, eps=1e-5):
+    """LayerNorm of rows ordered (n, a, c) stored in (n, c, a) order (the token transpose fused into the store)."""
+    x = _req(x, "x")
+    dim = x.shape[-1]
+    assert x.numel() == n * a * c * dim
+    y = torch.empty_like(x)
+    _opt(beta, "beta", dim)
+    check(_lib.load().omnitok_layernorm_transposed(_p(x), _p(_req(gamma, "gamma")), _p(beta), _p(y), n, a, c, dim, eps,
+                                                   _stream()), "layernorm_transposed")
+    return y
+
+
 def linear(x, weight, bias=None, residual=None, leaky=False):
     """y = x @ weight.T (+bias) (+leaky_relu 0.1) (+residual); weight [N, K], K % 32 == 0."""
     x = _req(x, "x")
@@ -395,14 +407,16 @@ def dequant_table(codebook, w, b):
     return table
 
 
-def gather_rows(ids, table):
-    """tok[..., :] = table[ids[...], :]; out-of-range ids raise IndexError like F.embedding."""
+def gather_rows(ids, table, transpose=None):
+    """tok[..., :] = table[ids[...], :]; out-of-range ids raise IndexError like F.embedding.
+    transpose=(a, c): ids are ordered (n, a, c), the rows are stored in (n, c, a) order."""
     ids, table = _req(ids, "ids", torch.int64), _req(table, "table")
     D = table.shape[1]
     tok = torch.empty(*ids.shape, D, device=ids.device, dtype=torch.float32)
     err = torch.zeros(1, device=ids.device, dtype=torch.int32)
-    check(_lib.load().omnitok_gather_rows(_p(ids), _p(table), table.shape[0], _p(tok), ids.numel(), D, _p(err),
-                                          _stream()), "gather_rows")
+    a, c = transpose if transpose else (0, 0)
+    check(_lib.load().omnitok_gather_rows_transposed(_p(ids), _p(table), table.shape[0], _p(tok), ids.numel(), a, c, D,
+                                                     _p(err), _stream()), "gather_rows")
     if int(err.item()):
         raise IndexError("token id out of range")
     return tok

@@ -159,6 +159,20 @@ def test_peg3d(ops, shape, causal, variant):
     assert maxerr(out_t, ref_t) < 1e-5
 
 
+def test_fused_token_transposes(ops):
+    """LayerNorm / row gather with the '(n a c) d -> (n c a) d' rearrange fused into the store == the plain kernel
+    followed by transpose_tokens, bit for bit."""
+    n, a, c, D = 3, 5, 64, 512
+    x = dev(rnd(n * a * c, D, seed=141))
+    g, b = dev(rnd(D, seed=142) * 0.1 + 1), dev(rnd(D, seed=143) * 0.1)
+    want = ops.transpose_tokens(ops.layernorm(x, g, b), n, a, c)
+    assert torch.equal(ops.layernorm_transposed(x, g, b, n, a, c), want)
+    table = dev(rnd(300, D, seed=144))
+    ids = dev(torch.randint(0, 300, (n, a, c), generator=torch.Generator().manual_seed(145)))
+    want = ops.transpose_tokens(ops.gather_rows(ids, table).reshape(-1, D), n, a, c)
+    assert torch.equal(ops.gather_rows(ids, table, transpose=(a, c)).reshape(-1, D), want)
+
+
 def test_transpose_tokens(ops):
     B, A, C, D = 2, 5, 64, 512
     x = rnd(B, A, C, D, seed=41)
