@@ -39,6 +39,11 @@ enum omnitok_status {
     OMNITOK_ERR_UNSUPPORTED = -4  /* configuration outside the built path  */
 };
 
+/* Measurement kernel (csrc/gemm_pp.hip): c[M, N] = a . w^T with BOTH operands as packed fp16 hi|lo planes
+ * (omnitok_h2_pack_weight layout and row scales), staged by LDS-DMA only.  M % 128 == 0, N % 256 == 0, K % 32 == 0. */
+int omnitok_gemm_pp(const void *a_planes, const float *a_scale, const void *w_planes, const float *w_scale,
+                    float *c, int64_t ldc, int64_t M, int N, int K, omnitok_stream_t stream);
+
 const char *omnitok_last_error(void);
 /* "omnitok <version> gfx950 ..." */
 const char *omnitok_version(void);

@@ -112,6 +112,7 @@ _PROTOS = {
     "omnitok_lm_select": [P, P, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, P, P, P, P, P],
     "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "omnitok_lm_attn_decode": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
+    "omnitok_gemm_pp": [P, P, P, P, P, I64, I64, c_int, c_int, P],
     "omnitok_set_option": [c_char_p, c_int],
     "omnitok_debug_set_gemm_trace": [P],
     "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
