@@ -57,6 +57,9 @@ def main():
 
     from omnitokenizer_amd import launch
 
+    if a.gpus > 1 and "LOCAL_RANK" not in os.environ and torch.cuda.device_count() < a.gpus:
+        sys.exit(f"bench.py --gpus {a.gpus}: this node exposes {torch.cuda.device_count()} GPU(s) "
+                 "(one rank per GPU; no oversubscription)")
     # `python bench.py --gpus N` with no launcher around it: start the N ranks ourselves
     rc = launch.maybe_respawn(os.path.abspath(__file__), sys.argv[1:], a.gpus)
     if rc is not None:

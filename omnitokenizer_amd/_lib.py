@@ -139,6 +139,11 @@ def load():
         raise OmnitokError(
             f"{LIB_PATH} not found: the HIP library is required (no CPU fallback). "
             "Build it with `python omnitokenizer_amd/build.py`.")
+    # PyTorch-ROCm ships its own HIP runtime; it must be the one in the process before libomnitok.so is mapped,
+    # otherwise the library binds a second runtime (/opt/rocm) that sees no device once torch has initialised its
+    # own ("no ROCm-capable device is detected" at the first hipMalloc).  Importing torch first pins the order no
+    # matter what the caller imported before.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
