@@ -63,6 +63,10 @@ def test_encode_decode_vs_reference_golden(models, name):
     x = c.x.cuda()
     ids, z = m.encode(x, c.is_image, return_latents=True)
     assert ids.dtype == torch.int64 and tuple(ids.shape) == tuple(c.ids.shape)
+    # the shape functions behind the operators' fake implementations agree with the engine
+    F_, H_, W_ = (1 if c.is_image else x.shape[2]), x.shape[-2], x.shape[-1]
+    assert m.latent_dims(F_, H_, W_) == tuple(ids.shape[1:]) == m._shape("encode", F_, H_, W_)
+    assert m.pixel_dims(*ids.shape[1:]) == m._shape("decode", *ids.shape[1:])
     # tier (i): the quantiser alone on the reference's z -> bit-exact
     ids_on_ref_z = ops.vq_argmin(c.z.cuda(), m.codebook.embeddings.data)
     assert torch.equal(ids_on_ref_z.cpu(), c.ids), "VQ kernel not bit-exact on the reference's z"
