@@ -124,6 +124,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         self._version = getattr(self, "_version", 0)
         self._timing = False
         self._workspace = None  # uint8 tensor of PyTorch's caching allocator lent to the engine (grow-only)
+        self._workspace_stream = None
         self._handle = next(_HANDLES)  # how the omnitok::vqgan_* custom ops find this module
         _MODELS[self._handle] = self
 
@@ -260,14 +261,24 @@ class OmniTokenizer_VQGAN(nn.Module):
         torch.cuda.memory_allocated, released with the module), grown when a larger call arrives."""
         if need < 0:
             return  # invalid shape: the native call reports it
-        if self._workspace is None or self._workspace.numel() < need:
-            torch.cuda.current_stream().synchronize()  # kernels of earlier calls may still read the old block
-            self._workspace = None
-            self._workspace = torch.empty(int(need * 1.02) + 256, dtype=torch.uint8, device=self.device)
-            ptr = (self._workspace.data_ptr() + 255) // 256 * 256
-            check(_lib.load().omnitok_engine_set_workspace(self._engine, ctypes.c_void_p(ptr),
-                                                           self._workspace.numel() - (ptr - self._workspace.data_ptr())),
-                  "set_workspace")
+        cur = torch.cuda.current_stream()
+        if self._workspace is not None and self._workspace.numel() >= need:
+            # used from a stream other than the one it was allocated on: tell the caching allocator, so that it
+            # does not recycle the block under a running kernel once the module is gone
+            if cur != self._workspace_stream and not torch.cuda.is_current_stream_capturing():
+                self._workspace.record_stream(cur)
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the engine workspace has to grow for this shape, which needs a synchronisation: run "
+                               "one eager encode/decode of the same shape before capturing a HIP graph")
+        cur.synchronize()  # kernels of earlier calls may still read the old block
+        self._workspace = None
+        self._workspace = torch.empty(int(need * 1.02) + 256, dtype=torch.uint8, device=self.device)
+        self._workspace_stream = cur
+        ptr = (self._workspace.data_ptr() + 255) // 256 * 256
+        check(_lib.load().omnitok_engine_set_workspace(self._engine, ctypes.c_void_p(ptr),
+                                                       self._workspace.numel() - (ptr - self._workspace.data_ptr())),
+              "set_workspace")
 
     def latent_dims(self, F, H, W):
         """(T', h, w) of encode() for [.., F, H, W] pixels from the configuration alone (no engine): what the
