@@ -44,10 +44,11 @@ class GPT(nn.Module):
                  resid_pdrop=0., attn_pdrop=0., n_unmasked=0, vtokens_pos=False):
         """Same signature as the reference (gpt.py:172).  Dropouts are inference no-ops; vtokens_pos adds the
         reference's vtokens_pos_emb parameter [1, sequence_length, resolution, resolution, n_embd] (gpt.py:183-184).
-        n_unmasked (a bidirectional prefix in the causal mask, gpt.py:98-100; no script sets it) is not built."""
+        n_unmasked is accepted and has no effect, exactly as in the reference under torch >= 2.1: it only edits the
+        `mask` buffer (gpt.py:98-100), which the scaled_dot_product_attention branch the reference then takes never
+        reads (gpt.py:122-126, is_causal = layer_past is None)."""
         super().__init__()
-        if n_unmasked:
-            raise NotImplementedError("n_unmasked is not built (no released config uses it)")
+        self.n_unmasked = n_unmasked
         self.vtokens_pos = bool(vtokens_pos)
         if self.vtokens_pos:
             self.vtokens_pos_emb = nn.Parameter(

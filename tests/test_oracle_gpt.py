@@ -96,8 +96,8 @@ def test_product_gpt_state_dict_and_cpu_refusal():
     assert set(m.state_dict()) == set(sd)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 4, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
-        GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C, n_unmasked=2)
+    # n_unmasked only edits the reference's unused mask buffer (gpt.py:98-100 vs the SDPA branch :122-126): accepted
+    assert GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C, n_unmasked=2).n_unmasked == 2
     # vtokens_pos: the reference's extra parameter, same key and shape (gpt.py:183-184)
     mv = GPT(argparse.Namespace(sequence_length=3, resolution=6), V, BS, n_layer=L, n_head=H, n_embd=C, vtokens_pos=True)
     assert tuple(mv.state_dict()["vtokens_pos_emb"].shape) == (1, 3, 6, 6, C)
