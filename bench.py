@@ -161,6 +161,11 @@ def main():
                 # the same binary on constant operands: what the kernel reaches when the chip is not clocking down
                 # under the data-dependent power of random operands (MI355X_MICROARCH.md "DVFS give-back")
                 roofline["power_limit_evidence"] = pmc["dvfs_check"]
+                if pmc["dvfs_check"].get("mfma_stream_only_tflops"):
+                    # what a bare MFMA + fragment-read stream of this kernel sustains on random operands (ablation
+                    # build): the practical ceiling under the chip's power-limited clock
+                    roofline["frac_of_measured_mfma_stream"] = round(
+                        roofline["achieved"] / pmc["dvfs_check"]["mfma_stream_only_tflops"], 4)
             if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
                 roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
                 roofline["traffic_source"] = pmc[dom]["source"]
