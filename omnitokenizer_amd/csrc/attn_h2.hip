@@ -389,7 +389,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2p_kernel(AttnH2Params p
 
     const int ntiles = p.N / 64;
     dma(0, 0);
-    __syncthreads();  // (the compiler drains vmcnt before the barrier)
+    // the LDS-DMA loads are tracked by vmcnt only: drain them explicitly before the barrier that publishes the tile
+    // (hipcc adds this wait itself when it knows a global_load_lds is outstanding; stated here so that the
+    // ordering does not depend on that analysis)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -487,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2p_kernel(AttnH2Params p
         const float alpha_b = softmax(sb, phb, plb);   // ... beside the softmax of b
         rescale(alpha_b);
         pv(1, phb, plb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile t + 1 has landed (see the prologue)
         __syncthreads();
     }
 
