@@ -82,6 +82,63 @@ __global__ __launch_bounds__(256) void attn_temporal_reg(TAttnParams p) {
     }
 }
 
+// register-resident K / V with the queries streamed (one load in flight ahead of the one being used): the form for
+// 9 < T <= TMAX (17 tokens = the 65-frame clips of BASELINE config C5), where holding q as well would not fit and
+// the streaming variant below re-normalises every key for every query (1.4 TB/s at T = 17).
+template <int TMAX, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_temporal_kv_reg(TAttnParams p) {
+    const int l16 = threadIdx.x & 15;
+    const int64_t grp = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (grp >= p.cols * p.heads) return;
+    const int64_t col = grp / p.heads;
+    const int head = (int)(grp % p.heads);
+    const int T = p.T;
+    const int64_t row0 = col * T;
+    const int choff = head * 64 + l16 * 4;
+    f32x4 k[TMAX], v[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        const int tt = t < T ? t : T - 1;  // clamped loads keep the code branch-free
+        k[t] = *reinterpret_cast<const f32x4 *>(p.k + (row0 + tt) * p.ldkv + choff);
+        v[t] = *reinterpret_cast<const f32x4 *>(p.v + (row0 + tt) * p.ldkv + choff);
+    }
+    f32x4 q_next = *reinterpret_cast<const f32x4 *>(p.q + row0 * p.ldq + choff);
+    const f32x4 qs = *reinterpret_cast<const f32x4 *>(p.q_scale + l16 * 4);
+    const f32x4 ks = *reinterpret_cast<const f32x4 *>(p.k_scale + l16 * 4);
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) k[t] = l2scale(k[t], ks, 1.0f);
+    const float slope = p.alibi ? p.alibi[head] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        const f32x4 qi = l2scale(q_next, qs, p.scale);
+        if (i + 1 < TMAX) {
+            const int tn = i + 1 < T ? i + 1 : T - 1;
+            q_next = *reinterpret_cast<const f32x4 *>(p.q + (row0 + tn) * p.ldq + choff);
+        }
+        float s[TMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            if (CAUSAL && j > i) continue;
+            float d = row16_allsum(dot4(qi, k[j]));
+            d -= slope * (float)(i > j ? i - j : j - i);  // ALiBi (legacy), attention.py:474
+            d = j < T ? d : -INFINITY;                    // keys beyond T never contribute
+            s[j] = d;
+            mx = fmaxf(mx, d);
+        }
+        float l = 0.0f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            if (CAUSAL && j > i) continue;
+            const float e = expf(s[j] - mx);  // exp(-inf) = 0 for j >= T
+            l += e;
+            o += v[j] * e;
+        }
+        if (i < T) *reinterpret_cast<f32x4 *>(p.out + (row0 + i) * p.ldo + choff) = o * (1.0f / l);
+    }
+}
+
 // streaming variant for any T: per query an online-softmax sweep over the keys (K/V re-read from
 // L1/L2; the column's working set is T * 12 KiB)
 __global__ __launch_bounds__(256) void attn_temporal_stream(TAttnParams p) {
@@ -150,7 +207,12 @@ extern "C" int omnitok_attn_temporal(const float *q, int64_t ldq, const float *k
         OT_TREG(5);
     else if (T <= 9)
         OT_TREG(9);
-    else
+    else if (T <= 17) {
+        if (causal)
+            hipLaunchKernelGGL((attn_temporal_kv_reg<17, true>), grid, dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL((attn_temporal_kv_reg<17, false>), grid, dim3(256), 0, stream, p);
+    } else
         hipLaunchKernelGGL(attn_temporal_stream, grid, dim3(256), 0, stream, p);
 #undef OT_TREG
     OT_LAUNCH_CHECK("attn_temporal");

@@ -288,7 +288,7 @@ def test_attn_window(ops, Bn, g):
     assert maxerr(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("T", [1, 2, 3, 5, 9, 17])
+@pytest.mark.parametrize("T", [1, 2, 3, 5, 9, 11, 13, 17, 21])
 @pytest.mark.parametrize("causal,alibi", [(True, False), (False, False), (True, True)])
 def test_attn_temporal(ops, T, causal, alibi):
     cols, h, d = 70, 8, 64
