@@ -238,3 +238,31 @@ def test_missing_library_fails_loudly(lib, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libomnitok.so")
     with pytest.raises(_lib.OmnitokError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_new_entry_points_validate_arguments_without_gpu(lib):
+    """Argument validation of the round-2 entry points happens before any HIP call (status -1 + a message)."""
+    import ctypes as C
+    one = C.c_void_p(256)  # any non-null, 16-byte aligned value: the checks fire before it is dereferenced
+    f = C.c_float
+    # attn_pack: n_tokens not a multiple of 32; non-positive bounds
+    assert lib.omnitok_attn_pack(one, 512, one, one, 1024, 48, 48, 8, None, None, one, one, f(8.0), f(8.0), f(1.0), f(1.0),
+                                 None, 0, 0, one, one, one, None) == -1
+    assert b"attn_pack" in lib.omnitok_last_error()
+    assert lib.omnitok_attn_pack(one, 512, one, one, 1024, 64, 64, 8, None, None, one, one, f(8.0), f(0.0), f(1.0), f(1.0),
+                                 None, 0, 0, one, one, one, None) == -1
+    assert b"bounds" in lib.omnitok_last_error()
+    # attn_spatial_h2: N not a multiple of 64
+    assert lib.omnitok_attn_spatial_h2(one, one, one, one, 512, 1, 96, 8, f(8.0), f(1.0), f(1.0), None, 0, 0, None, 0, 0,
+                                       None) == -1
+    # lm_select: non-positive temperature, sampling without uniforms, top_p <= 0
+    assert lib.omnitok_lm_select(one, None, 1, 100, f(0.0), f(1.0), f(0.0), -1, f(1.0), 0, None, one, None, None, None) == -1
+    assert b"temperature" in lib.omnitok_last_error()
+    assert lib.omnitok_lm_select(one, None, 1, 100, f(1.0), f(1.0), f(0.0), 10, f(0.9), 1, None, one, None, None, None) == -1
+    assert lib.omnitok_lm_select(one, None, 1, 100, f(1.0), f(1.0), f(0.0), 10, f(0.0), 0, None, one, None, None, None) == -1
+    # gather_rows / layernorm with the fused transpose: rows must be whole (a, c) groups; in-place is refused
+    assert lib.omnitok_gather_rows_transposed(one, one, 10, one, 100, 3, 7, 512, None, None) == -1
+    assert lib.omnitok_layernorm_transposed(one, one, None, one, 2, 3, 4, 512, f(1e-5), None) == -1
+    # set_workspace: pointer / size mismatch and alignment are rejected on a null engine too
+    assert lib.omnitok_engine_set_workspace(None, None, 0) == -1
+    assert lib.omnitok_gemm_pp(one, one, one, one, one, 256, 100, 256, 64, None) == -1
