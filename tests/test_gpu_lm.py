@@ -464,3 +464,77 @@ def test_net2net_transformer_forward_and_sample(starts_with_sos, class_first):
     index = torch.clamp(got - n_cls - (1 if starts_with_sos else 0), min=0, max=net.first_stage_model.n_codes - 1)
     pix = net.first_stage_model.decode(torch.cat((index, index[:, :2].repeat(1, 29)), 1)[:, :64], is_image=True)
     assert tuple(pix.shape) == (2, 3, 64, 64) and torch.isfinite(pix).all()
+
+
+def test_transformer_eval_call_patterns():
+    """The bodies of transformer_eval.py::class_condition_generation (its three branches, :41-69) and
+    ::frame_prediction (:106-121) run against the mirrors (Net2NetTransformer + GPT + OmniTokenizer_VQGAN) with the
+    reference's own statements; greedy variants are checked token by token against the oracle."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    from omnitokenizer_amd.gpt import sample_with_past, sample_with_past_cfg
+    from omnitokenizer_amd.lm_transformer import Net2NetTransformer
+    targs = make_args(2, resolution=64)
+    cfg = OmniTokConfig.from_args(targs)
+    tsd = synth.synth_state_dict(cfg, seed=0)
+    tok = OmniTokenizer_VQGAN(targs)
+    tok.load_state_dict(tsd, strict=True)
+    n_cls, L, H, C, BS = 10, 2, 4, 256, 140
+    latent_shape = [2, 8, 8]                      # (5 - 1) // 4 + 1 latent frames of 64 // 8 squared
+    for starts_with_sos in (False, True):
+        args = argparse.Namespace(class_cond_dim=n_cls, unconditional=False, vtokens=False, block_size=BS, n_layer=L,
+                                  n_head=H, n_embd=C, vtokens_pos=False, n_unmasked=0, starts_with_sos=starts_with_sos,
+                                  class_first=False)
+        gpt = Net2NetTransformer(args, first_stage_model=tok)
+        V = cfg.n_codes + n_cls + (1 if starts_with_sos else 0)
+        gsd = go.synth_gpt_state(V, BS, L, H, C, seed=6)
+        gpt.load_state_dict({f"transformer.{k}": v for k, v in gsd.items()}, strict=True)
+        gpt = gpt.cuda().eval()
+        n_cond = n_cls + (1 if starts_with_sos else 0)
+        steps = int(np.prod(latent_shape[1:]))    # image generation: 64 tokens
+        batch_size, class_label = 2, 3
+        # ---- class_condition_generation ----
+        c_indices = torch.tensor([class_label]).repeat(batch_size, 1).to(gpt.device)
+        if not starts_with_sos:
+            index_sample = sample_with_past(c_indices, gpt.transformer, steps=steps, sample_logits=True, top_k=100,
+                                            callback=None, temperature=1.0, top_p=0.9)
+            greedy = sample_with_past(c_indices, gpt.transformer, steps=8, sample_logits=False, top_k=100, top_p=0.9)
+            assert torch.equal(greedy.cpu(), go.sample_with_past(gsd, c_indices.cpu(), H, 8, sample_logits=False,
+                                                                 top_k=100, top_p=0.9))
+        else:
+            sos = torch.zeros_like(c_indices)
+            ci = torch.cat((sos, c_indices + 1), dim=1)
+            index_sample = sample_with_past(ci, gpt.transformer, steps=steps, sample_logits=True, top_k=100,
+                                            callback=None, temperature=1.0, top_p=0.9)
+            cfg_sample = sample_with_past_cfg(c_indices.clone(), gpt.transformer, steps=steps, sample_logits=True,
+                                              top_k=100, callback=None, temperature=1.0, top_p=0.9, cfg_ratio=1.5,
+                                              class_first=False, scale_cfg=False)
+            assert tuple(cfg_sample.shape) == (batch_size, steps)
+            greedy = sample_with_past_cfg(c_indices.clone(), gpt.transformer, steps=8, sample_logits=False, top_k=100,
+                                          top_p=0.9, cfg_ratio=1.5)
+            assert torch.equal(greedy.cpu(), go.sample_with_past_cfg(gsd, c_indices.cpu(), H, 8, sample_logits=False,
+                                                                     top_k=100, top_p=0.9, cfg_ratio=1.5))
+        index = torch.clamp(index_sample - n_cond, min=0, max=gpt.first_stage_model.n_codes - 1)
+        x_sample = gpt.first_stage_model.decode(index, is_image=True)
+        samples = torch.clamp(x_sample + 0.5, 0, 1)
+        assert tuple(samples.shape) == (batch_size, 3, 64, 64) and torch.isfinite(samples).all()
+    # ---- frame_prediction (unconditional LM over the tokenizer's vocabulary) ----
+    uargs = argparse.Namespace(class_cond_dim=None, unconditional=True, vtokens=False, block_size=BS, n_layer=L, n_head=H,
+                               n_embd=C, vtokens_pos=False, n_unmasked=0)
+    gpt = Net2NetTransformer(uargs, first_stage_model=tok)
+    assert gpt.cond_stage_vocab_size == 0 and gpt.transformer.vocab_size == cfg.n_codes
+    gpt.load_state_dict({f"transformer.{k}": v for k, v in go.synth_gpt_state(cfg.n_codes, BS, L, H, C, seed=7).items()},
+                        strict=True)
+    gpt = gpt.cuda().eval()
+    input_videos = synth.synth_video(2, 5, 64, seed=33).cuda()
+    _, prefix_encodings = gpt.first_stage_model.encode(input_videos, is_image=False, include_embeddings=True)
+    prefix_encodings = prefix_encodings[:, :1]                      # (the reference conditions on its first latent frames)
+    B, _, Hh, Ww = prefix_encodings.shape
+    prefix_encodings = prefix_encodings.view(B, -1)
+    steps = int(np.prod(latent_shape))
+    index_sample = sample_with_past(prefix_encodings, gpt.transformer, steps=int(steps - 1 * Hh * Ww), sample_logits=True,
+                                    top_k=2048, temperature=1.0, top_p=0.9)
+    index = torch.clamp(index_sample, min=0, max=gpt.first_stage_model.n_codes - 1)
+    index = torch.cat((prefix_encodings, index), dim=1).reshape(B, -1, Hh, Ww)    # "b (t h w) -> b t h w"
+    x_sample = gpt.first_stage_model.decode(index, is_image=False)
+    assert tuple(x_sample.shape) == (2, 3, 5, 64, 64) and torch.isfinite(x_sample).all()
