@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--n-codes", type=int, default=0, help="codebook size (default: the stage-2 8192; C5: 16384)")
     ap.add_argument("--gemm-mode", type=int, default=2, choices=[0, 1, 2],
                     help="engine GEMM arithmetic: 2 fp16x2 split (default), 1 bf16x3 split, 0 fp32-input MFMA")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
+                    help="omnitok_set_option switch for A/B measurements (e.g. attn_vpack=0); recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
@@ -72,6 +74,9 @@ def main():
     from omnitokenizer_amd.config import OmniTokConfig
 
     _lib.set_option("gemm_mode", a.gemm_mode)
+    for kv in a.option:
+        name, _, val = kv.partition("=")
+        _lib.set_option(name, int(val))
     over = dict(resolution=a.resolution)
     if a.n_codes:
         over["n_codes"] = a.n_codes
@@ -202,14 +207,16 @@ def main():
             "metric": "patches/sec encode+decode", "value": round(value, 1), "unit": "patches/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.gemm_mode == 0 else f"f32 ({gm_name}, fp32 accumulate; attention / VQ on fp32 MFMA)",
+            "dtype": "f32" if a.gemm_mode == 0 else (f"f32 ({gm_name}, fp32 accumulate; "
+                                                           + ("spatial attention likewise; " if a.gemm_mode == 2 else "attention and ")
+                                                           + "VQ on fp32 MFMA)"),
             "gemm_mode": a.gemm_mode, "data": "synthetic",
             "config": {"workload": wl_name + f": B={B}/GPU " + (f"{a.resolution}x{a.resolution} images" if is_image
                                     else f"{a.frames}x{a.resolution}x{a.resolution} clips")
                                    + f", stage-2 (imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes={cfg.n_codes}), encode + "
                                    f"{'RCCL id all-gather + ' if world > 1 else ''}decode; {B} distinct clips per rank",
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
-                       "parallelism": f"clip-sharded x{world}"},
+                       "parallelism": f"clip-sharded x{world}", **({"options": a.option} if a.option else {})},
             "rccl_world_size": res.world_seen, "ids_crc32": res.ids_crc, "allgather_ms": res.allgather_ms,
             "roofline": roofline, "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
             "kernels": kernels,

@@ -140,6 +140,21 @@ int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes, const flo
                     float a_bound, const float *a_bound_dev, int a_bound_stride, int64_t a_rows_per_clip,
                     const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
                     float ln_bound, float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream);
+/* omnitok_gemm_h2 whose columns [v_col0, N) -- the V projection of a merged to_q | to_kv launch (reference
+ * attention.py:404-412) -- are not stored as fp32 but written straight into the packed fp16 hi|lo V planes of
+ * omnitok_attn_spatial_h2 (the 32x32 MFMA accumulator layout is that layout), bit-identical to storing them and
+ * running omnitok_attn_pack on the result.  v_planes NULL: plain omnitok_gemm_h2.  Needs flags == 0, the fused
+ * LayerNorm, v_col0 % 256 == 0, N - v_col0 == heads * 64, M a whole number of n_tokens-row sequences
+ * (n_tokens % 32 == 0) and a_rows_per_clip % 128 == 0; v_bound (times v_bound_dev[v_bound_stride * clip]) >= max|v|. */
+int omnitok_gemm_h2_vpack(const float *a, int64_t lda, const void *w_planes, const float *w_scale,
+                          const float *bias, const float *residual, int64_t ldr, float *c, int64_t ldc,
+                          int64_t M, int N, int K, int flags,
+                          int64_t a_rows_per_group, int64_t a_group_stride, int64_t a_group_offset,
+                          float a_bound, const float *a_bound_dev, int a_bound_stride, int64_t a_rows_per_clip,
+                          const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
+                          float ln_bound, float *c2, int64_t ldc2, int split_col, void *v_planes, int v_col0,
+                          int n_tokens, int heads, float v_bound, const float *v_bound_dev, int v_bound_stride,
+                          omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of
@@ -222,7 +237,7 @@ int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k, const floa
  *     hi|lo planes in MFMA-fragment order: qp / kp / vp are rows*heads*64*4 bytes each (blocks of 32 tokens of
  *     one head, 8 KiB).  q_bound >= max|q| (= scale * max|q_scale|), k_bound >= max|k| (= max|k_scale|);
  *     v_bound (times v_bound_dev[v_bound_stride * clip] if given, clip = row / rows_per_clip) >= max|v| of the
- *     rows of a clip.  n_tokens % 32 == 0.
+ *     rows of a clip.  n_tokens % 32 == 0.  v == vp == NULL: only q and k (V written by omnitok_gemm_h2_vpack).
  *   omnitok_attn_spatial_h2: out[Bn*N, heads*64] = softmax(q k^T [+ bias]) v from the packed operands; the same
  *     bounds must be passed (they define the power-of-two operand scales); seq_per_clip = sequences per clip
  *     for v_bound_dev.  N % 64 == 0. */

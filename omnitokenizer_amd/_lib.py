@@ -47,6 +47,8 @@ _PROTOS = {
     "omnitok_h2_pack_weight": [P, I64, c_int, c_int, P, P, P],
     "omnitok_gemm_h2": [P, I64, P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, c_float, P, c_int,
                         I64, P, P, P, c_int, c_float, P, I64, c_int, P],
+    "omnitok_gemm_h2_vpack": [P, I64, P, P, P, P, I64, P, I64, I64, c_int, c_int, c_int, I64, I64, I64, c_float, P, c_int,
+                              I64, P, P, P, c_int, c_float, P, I64, c_int, P, c_int, c_int, c_int, c_float, P, c_int, P],
     "omnitok_row_stats": [P, I64, c_int, c_float, P, P, I64, P],
     "omnitok_weight_range": [P, I64, c_int, c_int, P, P],
     "omnitok_pack_geglu_weight": [P, c_int, c_int, c_int, P, P],

@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackParams p) {
         }
     }
     // ---- V: lane = channel d, each wave takes two key quads (j, ii, h): four keys 16 j + 8 ii + 4 h + r --------
-    {
+    //      (skipped when the q|k|v GEMM already wrote the V planes from its epilogue: omnitok_gemm_h2_vpack)
+    if (p.vp) {
         const int lane = tid & 63, wave = tid >> 6;
         const int mt = lane >> 5, dd = lane & 31;
         float bound = p.v_bound;
@@ -124,13 +125,15 @@ __global__ __launch_bounds__(256) void attn_pack_kernel(PackParams p) {
     // ---- linear 8 KiB stores of the three blocks --------------------------------------------------------
     unsigned char *outs[3] = {p.qp, p.kp, p.vp};
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t) {
+        if (t == 2 && !p.vp) break;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int s = tid + 256 * i;  // 16-byte slot 0..511
             const u32x4 w = *reinterpret_cast<const u32x4 *>(lds + (t * 16 + (s >> 5)) * PK_CHUNK + (s & 31) * 16);
             *reinterpret_cast<u32x4 *>(outs[t] + unit * 8192 + (int64_t)s * 16) = w;
         }
+    }
 }
 
 // -------------------------------------------------------------------------------------------
@@ -526,13 +529,14 @@ extern "C" int omnitok_attn_pack(const float *q, int64_t ldq, const float *k, co
                                  float v_bound, const float *v_bound_dev, int v_bound_stride, int64_t rows_per_clip,
                                  void *qp, void *kp, void *vp, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(q && k && v && q_scale && k_scale && qp && kp && vp, "attn_pack: null pointer");
+    OT_CHECK_ARG(q && k && q_scale && k_scale && qp && kp, "attn_pack: null pointer");
+    OT_CHECK_ARG((v == nullptr) == (vp == nullptr), "attn_pack: v and vp must both be given or both null (V packed elsewhere)");
     OT_CHECK_ARG((cos == nullptr) == (sin == nullptr), "attn_pack: cos/sin must both be given or both null");
-    OT_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(qp) &&
-                     aligned16(kp) && aligned16(vp), "attn_pack: unaligned");
+    OT_CHECK_ARG(ldq % 4 == 0 && ldkv % 4 == 0 && aligned16(q) && aligned16(k) && (!v || aligned16(v)) && aligned16(qp) &&
+                     aligned16(kp) && (!vp || aligned16(vp)), "attn_pack: unaligned");
     OT_CHECK_ARG(n_tokens > 0 && n_tokens % 32 == 0 && rows % n_tokens == 0, "attn_pack: %lld rows of %d-token sequences",
                  (long long)rows, n_tokens);
-    OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && v_bound > 0.0f, "attn_pack: operand bounds must be positive");
+    OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && (!v || v_bound > 0.0f), "attn_pack: operand bounds must be positive");
     OT_CHECK_ARG(!v_bound_dev || (rows_per_clip > 0 && rows_per_clip % n_tokens == 0),
                  "attn_pack: rows_per_clip must be a whole number of sequences");
     if (rows == 0) return OMNITOK_OK;

@@ -648,6 +648,8 @@ int g_gemm_mode = 2;
 //      statistics pass exist (the split-operand GEMM path) and the q/k scales are usable;
 //   0: the fp32-input MFMA kernel of attn_spatial.hip.
 int g_attn_mode = 1;
+// "attn_vpack" 1 (default): the merged q|k|v launch writes V straight into the attention kernel's fp16 planes
+int g_attn_vpack = 1;
 
 static bool x3_ok(int N, int K, int flags) {
     return g_gemm_mode >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
@@ -659,18 +661,31 @@ static float *next_bounds(omnitok_engine *e) {  // [n_clips][2] slots of one row
     return e->bounds + (int64_t)2 * e->bound_clips * (e->bound_next++);
 }
 
+struct VPack {  // packed-V output of the merged q|k|v launch (gemm_h2.hip): planes, first V column, sequence shape, |v| bound
+    void *planes; int col0, n_tokens, heads; float bound; const float *bound_dev;
+};
+
 static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
                    const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags,
                    int64_t rpg, int64_t gstride, int64_t goff, hipStream_t stream, ABound ab = ABound(),
                    const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
-                   int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0) {
+                   int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0,
+                   const VPack *vpk = nullptr, bool *vpacked = nullptr) {
     if (g_gemm_mode == 2 && ab.stat > 0.0f && x3_ok(N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
         (!ab.dev || (ab.rpc > 0 && ab.rpc % 64 == 0 && rpg == 0))) {
         auto it = e->h2w.find(w);
-        if (it != e->h2w.end() && ldw == K)
+        if (it != e->h2w.end() && ldw == K) {
+            if (vpk && ab.dev && ab.rpc % 128 == 0) {  // V columns straight into the attention kernel's fp16 planes
+                *vpacked = true;
+                return omnitok_gemm_h2_vpack(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K,
+                                             flags, rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b,
+                                             ln_cols, ln_bound, c2, ldc2, split_col, vpk->planes, vpk->col0, vpk->n_tokens,
+                                             vpk->heads, vpk->bound, vpk->bound_dev, 2, stream);
+            }
             return omnitok_gemm_h2(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K, flags,
                                    rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b, ln_cols,
                                    ln_bound, c2, ldc2, split_col, stream);
+        }
     }
     if (x3_ok(N, K, flags))
         return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
@@ -777,6 +792,16 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             }
             float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
             int64_t ldq = D, ldkv = 2 * D;
+            // fp16-split spatial attention (attn_h2.hip): Q, K (RoPE + l2norm + scales applied) and V as hi|lo planes
+            // in MFMA fragment order (Y, HD are free here); |V| <= ||x_row|| ||Wv_j|| per clip from the row statistics
+            const float qb = 1.01f * 8.0f * ly.t.q_amax, kb = 1.01f * ly.t.k_amax;
+            const bool attn_h2 = spatial && g_attn_mode == 1 && bs && S % 64 == 0 && qb > 0.0f && kb > 0.0f &&
+                                 ly.t.vnorm > 0.0f && qb < 1e30f && kb < 1e30f;
+            unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
+            unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
+            unsigned char *vp = kp + (size_t)L * D * 4;
+            const VPack vpk{vp, 2 * D, S, heads, ab_ao.stat, ab_ao.dev};
+            bool vpacked = false;  // the q|k|v launch wrote the V planes itself (no fp32 V round trip)
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
             if (fused && D % 256 == 0) {
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
@@ -786,7 +811,8 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 // kernels read rows of D / 2D floats (with a [L, 3D] row pitch spatial attention ran 15 % slower)
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
                        eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, Q, D, L, 3 * D, D, 0, 0, 0, 0, stream, ab_x,
-                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D));
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D, attn_h2 && g_attn_vpack ? &vpk : nullptr,
+                               &vpacked));
             } else if (fused) {
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
@@ -811,16 +837,11 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 const float *bias = nullptr;
                 if (!ly.t.bias_prefix.empty())
                     if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
-                const float qb = 1.01f * 8.0f * ly.t.q_amax, kb = 1.01f * ly.t.k_amax;
-                if (g_attn_mode == 1 && bs && qb > 0.0f && kb > 0.0f && ly.t.vnorm > 0.0f && qb < 1e30f && kb < 1e30f) {
-                    // fp16-split attention: Q, K (RoPE + l2norm + scales applied) and V as hi|lo planes in MFMA
-                    // fragment order (Y, HD are free here); |V| <= ||x_row|| ||Wv_j|| per clip from the row statistics
-                    unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
-                    unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
-                    unsigned char *vp = kp + (size_t)L * D * 4;
-                    OT_RUN("qk_prep", 6.0 * L * D * 4.0,
-                           omnitok_attn_pack(Q, ldq, KV, KV + D, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale,
-                                             8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp, vp, stream));
+                if (attn_h2) {
+                    OT_RUN("qk_prep", (vpacked ? 4.0 : 6.0) * L * D * 4.0,
+                           omnitok_attn_pack(Q, ldq, KV, vpacked ? nullptr : KV + D, ldkv, L, S, heads, cosp, sinp,
+                                             ly.t.q_scale, ly.t.k_scale, 8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp,
+                                             vpacked ? nullptr : vp, stream));
                     OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
                            omnitok_attn_spatial_h2(qp, kp, vp, e->AO.p, D, B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev,
                                                    2, T, bias, gh, gw, stream));

@@ -50,6 +50,16 @@ struct H2Params {
     float *c2;               // output columns [split_col, N) go to c2 (row stride ldc2) instead of c
     int64_t ldc2;
     int split_col;           // 0: everything to c
+    // V columns of a merged q|k|v launch straight into the fp16 hi|lo planes of the attention kernel (attn_h2.hip):
+    // the 32x32 accumulator layout IS the packed V layout (a lane's registers 8 j .. 8 j + 7 are one 16-byte fragment
+    // of 16-key step j), so these tiles are never written as fp32
+    unsigned char *vp = nullptr;   // packed V ([rows * heads * 64] x 4 bytes), or null
+    int v_col0 = 0;                // first V column of the merged output (a multiple of the tile width)
+    int v_ntok = 0, v_heads = 0;   // tokens per sequence (% 32 == 0), heads
+    float v_bound = 0.0f;          // upper bound of |v| (times v_bound_dev[stride * clip] when set)
+    const float *v_bound_dev = nullptr;
+    int v_bound_stride = 1;
+    int64_t v_rpc = 0;             // rows per clip
 };
 
 template <int WGM_, int WGN_, int MI_, int NI_>
@@ -303,7 +313,48 @@ __global__ __launch_bounds__(C::NT, 2) void gemm_h2_kernel(H2Params hp) {
             const int col = col0 + ni * 32 + r32;
             cs[ni] = ainv * hp.wscale[col < p.N ? col : p.N - 1];
         }
-        if (hp.split_col > 0 && col0 >= hp.split_col) {  // wave-uniform: split_col is a multiple of the tile width
+        bool v_done = false;
+        if constexpr (FLAGS == 0 && LN && NI % 2 == 0) {
+            if (hp.vp && col0 >= hp.v_col0) {  // wave-uniform
+                v_done = true;
+                float vb = hp.v_bound;
+                if (hp.v_bound_dev) vb *= hp.v_bound_dev[(hp.v_rpc > 0 ? (ebm * TM) / hp.v_rpc : 0) * hp.v_bound_stride];
+                const float sv = h2_scale_of_bound(vb);
+                const int nblk = hp.v_ntok >> 5;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int64_t row = ebm * TM + (wm * MI + mi) * 32;  // first token of this 32-token block
+                    if (row < p.M) {
+                        const int64_t seq = row / hp.v_ntok;
+                        const int blk = (int)(row - seq * hp.v_ntok) >> 5;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int vcol = col0 - hp.v_col0 + ni * 32;  // column inside V: head vcol / 64, d-half (vcol / 32) & 1
+                            unsigned char *dst = hp.vp + ((seq * hp.v_heads + (vcol >> 6)) * nblk + blk) * 8192 +
+                                                 ((((vcol >> 5) & 1) * 2 + hi) * 32 + r32) * 16;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                f32x4 pa, pb;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    pa[e] = (acc[mi][ni][8 * j + e] * cs[ni]) * sv;  // the fp32 value the plain epilogue stores,
+                                    pb[e] = (acc[mi][ni][8 * j + 4 + e] * cs[ni]) * sv;  // then attn_pack's scaling
+                                }
+                                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                                const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                                const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                                *reinterpret_cast<u32x4 *>(dst + j * 2048) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                *reinterpret_cast<u32x4 *>(dst + 4096 + j * 2048) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (v_done) {
+        } else if (hp.split_col > 0 && col0 >= hp.split_col) {  // wave-uniform: split_col is a multiple of the tile width
             GemmParams q = p;
             q.c = hp.c2;
             q.ldc = hp.ldc2;
@@ -399,6 +450,13 @@ static int launch_h2(H2Params hp, hipStream_t stream) {
     if ((t == 1 || t == 5) && rpc % 256) t = 3;
     if (t == 6 && rpc % 128) t = 4;
     if (t == 3 && rpc % 128) t = 4;
+    if (hp.vp && t == 4) {  // the V-plane epilogue needs whole heads per wave (NI even): 128x128 tiles at least
+        if (rpc % 128) {
+            set_error("gemm_h2: packed-V output needs rows per clip %% 128 == 0 (got %lld)", (long long)rpc);
+            return OMNITOK_ERR_INVALID;
+        }
+        t = 3;
+    }
     // short-K GEMMs with a residual epilogue (to_out: K = 512, 1 GB of traffic for 86 GFLOP): two independent
     // 128x256 workgroups per CU let one tile's residual loads / stores overlap the other's K loop
     // (measured at C3: 0.429 -> 0.380 ms; profiles/r02_h2_tile_experiment.txt)
@@ -450,7 +508,27 @@ extern "C" int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes
                                int64_t a_group_offset, float a_bound, const float *a_bound_dev, int a_bound_stride,
                                int64_t a_rows_per_clip, const float *ln_stats, const float *ln_gamma, const float *ln_beta, int ln_cols,
                                float ln_bound, float *c2, int64_t ldc2, int split_col, omnitok_stream_t stream_) {
+    return omnitok_gemm_h2_vpack(a, lda, w_planes, w_scale, bias, residual, ldr, c, ldc, M, N, K, flags, a_rows_per_group,
+                                 a_group_stride, a_group_offset, a_bound, a_bound_dev, a_bound_stride, a_rows_per_clip,
+                                 ln_stats, ln_gamma, ln_beta, ln_cols, ln_bound, c2, ldc2, split_col, nullptr, 0, 0, 0, 0.0f,
+                                 nullptr, 1, stream_);
+}
+
+extern "C" int omnitok_gemm_h2_vpack(const float *a, int64_t lda, const void *w_planes, const float *w_scale,
+                                     const float *bias, const float *residual, int64_t ldr, float *c, int64_t ldc,
+                                     int64_t M, int N, int K, int flags, int64_t a_rows_per_group, int64_t a_group_stride,
+                                     int64_t a_group_offset, float a_bound, const float *a_bound_dev, int a_bound_stride,
+                                     int64_t a_rows_per_clip, const float *ln_stats, const float *ln_gamma,
+                                     const float *ln_beta, int ln_cols, float ln_bound, float *c2, int64_t ldc2,
+                                     int split_col, void *v_planes, int v_col0, int n_tokens, int heads, float v_bound,
+                                     const float *v_bound_dev, int v_bound_stride, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(!v_planes || (flags == 0 && ln_stats && v_col0 > 0 && v_col0 % 256 == 0 && v_col0 < N &&
+                               (N - v_col0) == heads * 64 && n_tokens > 0 && n_tokens % 32 == 0 && M % n_tokens == 0 &&
+                               v_bound > 0.0f && aligned16(v_planes) && a_rows_per_group == 0 &&
+                               (!v_bound_dev || a_rows_per_clip > 0)),
+                 "gemm_h2: packed-V output needs the fused-LN plain epilogue, v_col0 %% 256 == 0, N - v_col0 == heads * 64, "
+                 "whole sequences of n_tokens %% 32 == 0 rows and a positive bound");
     OT_CHECK_ARG(a && w_planes && w_scale && c, "gemm_h2: null pointer");
     OT_CHECK_ARG(split_col == 0 || (c2 && split_col % 256 == 0 && split_col < N && !(flags & (OMNITOK_GEMM_GEGLU | OMNITOK_GEMM_RESIDUAL))),
                  "gemm_h2: split output needs c2, split_col %% 256 == 0 and no GEGLU / residual epilogue");
@@ -480,6 +558,9 @@ extern "C" int omnitok_gemm_h2(const float *a, int64_t lda, const void *w_planes
     hp.ln_stats = ln_stats; hp.ln_gamma = ln_gamma; hp.ln_beta = ln_beta; hp.ln_cols = ln ? ln_cols : 0;
     hp.ln_bound = ln_bound;
     hp.c2 = c2; hp.ldc2 = ldc2; hp.split_col = split_col;
+    hp.vp = static_cast<unsigned char *>(v_planes); hp.v_col0 = v_col0; hp.v_ntok = n_tokens; hp.v_heads = heads;
+    hp.v_bound = v_bound; hp.v_bound_dev = v_bound_dev; hp.v_bound_stride = v_bound_stride > 0 ? v_bound_stride : 1;
+    hp.v_rpc = a_rows_per_clip;
 #define H2_CASE(F)                                                    \
     case F:                                                           \
         return ln ? launch_h2<F, true>(hp, stream) : launch_h2<F, false>(hp, stream);

@@ -190,6 +190,31 @@ def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound
     return out
 
 
+def linear_h2_vpack(x, packed, a_bound, ln, ln_cols, ln_bound, v_col0, n_tokens, heads, v_bound, a_bound_dev=None,
+                    a_bound_stride=1, rows_per_clip=0, v_bound_dev=None, v_bound_stride=1):
+    """linear_h2 (fused LayerNorm on the first ln_cols columns) whose columns [v_col0, N) go straight into the packed
+    fp16 hi|lo V planes of attn_spatial_h2 (omnitok_gemm_h2_vpack).  Returns (out[M, v_col0], v_planes)."""
+    x = _req(x, "x")
+    planes, scale = packed
+    K = x.shape[-1]
+    M = x.numel() // K
+    N = scale.shape[0]
+    out = torch.empty(M, v_col0, device=x.device, dtype=torch.float32)
+    vp = torch.empty(M * heads * 64, device=x.device, dtype=torch.int32)
+    st, g, b = ln
+    _req(st, "ln stats")
+    _req(g, "ln gamma")
+    _opt(b, "ln beta", K)
+    _opt(a_bound_dev, "a_bound_dev")
+    _opt(v_bound_dev, "v_bound_dev")
+    check(_lib.load().omnitok_gemm_h2_vpack(_p(x), K, _p(planes), _p(scale), None, None, 0, _p(out), v_col0, M, N, K, 0, 0,
+                                            0, 0, float(a_bound), _p(a_bound_dev), int(a_bound_stride),
+                                            int(rows_per_clip), _p(st), _p(g), _p(b), int(ln_cols), float(ln_bound), None,
+                                            0, 0, _p(vp), int(v_col0), int(n_tokens), int(heads), float(v_bound),
+                                            _p(v_bound_dev), int(v_bound_stride), _stream()), "gemm_h2_vpack")
+    return out, vp
+
+
 def pack_geglu_weight(w1, inner_pad):
     w1 = _req(w1, "w1")
     inner, K = w1.shape[0] // 2, w1.shape[1]

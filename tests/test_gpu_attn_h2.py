@@ -215,3 +215,34 @@ def test_engine_attn_modes_vs_golden(mode, name):
         assert (c.strided(rec.cpu()) - c.recon).abs().max().item() < 1e-4
     finally:
         _lib.set_option("attn_mode", 1)
+
+
+@pytest.mark.parametrize("M,N_tok,rpc", [(256, 64, 0), (1024, 256, 256), (49152, 1024, 12288), (640, 64, 128)])
+def test_qkv_gemm_writes_v_planes(ops, M, N_tok, rpc):
+    """omnitok_gemm_h2_vpack: the V columns of the merged to_q | to_kv launch land in the packed fp16 planes bit for bit
+    as if they had been stored as fp32 and packed by omnitok_attn_pack; the q | k columns are those of the plain launch."""
+    D, h = 256, 4
+    x = rnd(M, D, seed=171, scale=2.0)
+    w = rnd(3 * D, D, seed=172, scale=D ** -0.5)
+    gam, bet = rnd(D, seed=173) * 0.1 + 1, rnd(D, seed=174) * 0.1
+    xd, pk = dev(x), ops.h2_pack_weight(dev(w))
+    lnb = float(D ** 0.5 * gam.abs().max() + bet.abs().max())
+    kw, vkw, vdev = {}, {}, None
+    if rpc:
+        bounds = torch.zeros(M // rpc, 2, device="cuda")
+        st = ops.row_stats(xd, bounds=bounds, rows_per_clip=rpc)
+        vdev = bounds.view(-1)[1:]  # slot 1 of every clip: max ||x_row||
+        kw = dict(a_bound_dev=bounds, a_bound_stride=2, rows_per_clip=rpc)
+        vkw = dict(v_bound_dev=vdev, v_bound_stride=2)
+        a_bound, v_bound = 1.01, 1.01 * float(w[2 * D:].norm(dim=1).max())
+    else:
+        st = ops.row_stats(xd)
+        a_bound, v_bound = float(x.abs().max()), 1.01 * float((x @ w[2 * D:].T).abs().max())
+    plain = ops.linear_h2(xd, pk, a_bound, ln=(st, dev(gam), dev(bet)), ln_cols=D, ln_bound=lnb, **kw)
+    qk, vp = ops.linear_h2_vpack(xd, pk, a_bound, (st, dev(gam), dev(bet)), D, lnb, 2 * D, N_tok, h, v_bound, **kw, **vkw)
+    assert torch.equal(qk, plain[:, : 2 * D])
+    qs = torch.ones(64, device="cuda")
+    v32 = plain[:, 2 * D:]
+    packed, _ = ops.attn_pack(plain[:, :D], plain[:, D: 2 * D], v32, N_tok, h, qs, qs, v_bound=v_bound,
+                              v_bound_dev=vdev, v_bound_stride=2, rows_per_clip=rpc)
+    assert torch.equal(vp, packed[2])
