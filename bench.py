@@ -223,6 +223,50 @@ def main():
             "workspace_gb": round(model.workspace_bytes() / 2**30, 2),
         }
 
+        # ---- shader clock / board power during the same step (host thread reading the amdgpu hwmon files) ------
+        # The dominant kernels run at the board's power cap with the clock well under 2400 MHz on real data
+        # (profiles/r02_clock_power_probe.txt); this puts the live reading next to the roofline fractions.
+        out["clock_power"] = None
+        if world == 1:
+            try:
+                from tools import gpu_power
+                torch.cuda.synchronize()
+                time.sleep(0.5)
+                idle = gpu_power.snapshot()
+                n_pw = max(2, int(1.5 / max(dt / a.steps, 1e-3)))
+                snaps, watching = [], [True]
+
+                def watch():   # decode() synchronises (id check), so the load is only visible from another thread
+                    while watching[0]:
+                        snaps.append(gpu_power.snapshot())
+                        time.sleep(0.05)
+                import threading
+                th = threading.Thread(target=watch, daemon=True)
+                th.start()
+                for _ in range(n_pw):
+                    model.decode(model.encode(x, is_image), is_image)
+                torch.cuda.synchronize()
+                watching[0] = False
+                th.join()
+                busy = {d: max(sn.get(d, 0) for sn in snaps) for d in idle}
+                files, hw = gpu_power.pick_hwmon(idle, busy)
+                if files:
+                    smp = gpu_power.Sampler(files)
+                    smp.start()
+                    for _ in range(n_pw):
+                        model.decode(model.encode(x, is_image), is_image)
+                        torch.cuda.synchronize()
+                    smp.stop()
+                    cp = smp.summary(drop_first=0.1)
+                    cp.update(hw)
+                    cp["note"] = ("amdgpu hwmon freq1_input / power1_input sampled every 10 ms over %d more steps; the fp16 "
+                                  "MFMA peak scales with sclk / 2400 MHz" % n_pw)
+                    if "sclk_mhz" in cp and roofline.get("bound") == "mfma":
+                        roofline["frac_at_step_avg_clock"] = round(roofline["frac"] * 2400.0 / cp["sclk_mhz"]["avg"], 4)
+                    out["clock_power"] = cp
+            except Exception as e:  # noqa: BLE001  (measurement extra: never fails the bench)
+                out["clock_power"] = {"error": repr(e)}
+
         # ---- CPU baseline + parity on a bounded sample ---------------------------------------------
         if world == 1 and not a.no_cpu_baseline:
             from oracle import omnitok_oracle as orc
