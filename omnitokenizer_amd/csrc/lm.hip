@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void lm_embed_kernel(const int64_t *__restrict
 // attention-merge staging (XM): x is not a tensor but the flash-decode chunk partials of
 // lm_attn_decode_kernel; the workgroup merges them while it stages its activations, so the chunked
 // attention needs neither a merge launch nor cross-workgroup fences.
-constexpr int LM_KP = 2048;        // K panel staged in LDS (BQ * LM_KP * 4 B <= 64 KiB)
+int g_lm_wide_u = 2;  // "lm_wide_u": chunks per register buffer of the wide GEMVs (4 measured slower: 1.134 vs 1.114 ms / token)
+constexpr int LM_KP = 2048;        // K panel staged in LDS (BQ * LM_KP * 4 B <= 64 KiB; one 6144-float panel for the
+                                   // FC2 input at B = 1 measured the same: 1.114 ms / token)
 constexpr int LM_MAX_CHUNKS = 32;  // attention chunks per sequence: max_len <= 8192
 constexpr int LM_MAX_HEADS = 32;   // (bounds the merge-weight table in LDS: B * heads * chunks floats)
 
@@ -87,10 +89,11 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     auto load_w = [&](f32x4 (&dst)[ROWS][U], int c0) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int c = c0 + u < nch ? c0 + u : nch - 1;  // tail chunks re-read the last one, masked below
+            if (c0 + u < nch) {  // uniform; chunks past the row are neither loaded nor consumed
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-                dst[r][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wr[r] + c * 256));
+                for (int r = 0; r < ROWS; ++r)
+                    dst[r][u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(wr[r] + (c0 + u) * 256));
+            }
         }
     };
     f32x4 wa[ROWS][U], wb[ROWS][U];
@@ -109,7 +112,63 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
                 s_f[(b * mg.n_head + h) * mg.nchunk + c] = expf(pp[c * (2 + mg.hd)] - M) / L;
         }
     }
-    if (LN) {
+    // LayerNorm with the whole row in one LDS panel (K <= LM_KP, every GPT block): x, gamma and beta are requested
+    // together at kernel start (one memory round trip instead of three dependent ones), the two-pass statistics are
+    // block-wide reductions over registers, and the normalised row goes straight to LDS.
+    const bool ln_fast = LN && K <= LM_KP;
+    if (ln_fast) {
+        __shared__ float s_part[2][BQ][4];
+        const int k4n = K >> 2;  // float4 per row (<= 512: two per thread)
+        const bool has0 = tid < k4n, has1 = tid + 256 < k4n;
+        f32x4 xv[BQ][2], g4[2], b4[2];
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool has = j == 0 ? has0 : has1;
+            g4[j] = has ? *reinterpret_cast<const f32x4 *>(g + (tid + 256 * j) * 4) : zero4;
+            b4[j] = has ? *reinterpret_cast<const f32x4 *>(beta + (tid + 256 * j) * 4) : zero4;
+#pragma unroll
+            for (int b = 0; b < BQ; ++b)
+                xv[b][j] = has ? *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + (tid + 256 * j) * 4) : zero4;
+        }
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            const f32x4 t = xv[b][0] + xv[b][1];
+            const float sum = wave_allsum((t[0] + t[1]) + (t[2] + t[3]));
+            if (lane == 0) s_part[0][b][wave] = sum;
+        }
+        __syncthreads();
+        float mean[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            mean[b] = ((s_part[0][b][0] + s_part[0][b][1]) + (s_part[0][b][2] + s_part[0][b][3])) / (float)K;
+            float q = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 0 ? has0 : has1) {
+                    const f32x4 a = xv[b][j] - mean[b];
+                    q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+                }
+            }
+            q = wave_allsum(q);
+            if (lane == 0) s_part[1][b][wave] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            const float var = ((s_part[1][b][0] + s_part[1][b][1]) + (s_part[1][b][2] + s_part[1][b][3])) / (float)K;
+            const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j == 0 ? has0 : has1) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (xv[b][j][e] - mean[b]) * rstd * g4[j][e] + b4[j][e];
+                    *reinterpret_cast<f32x4 *>(xs + b * kp + (tid + 256 * j) * 4) = v;
+                }
+            }
+        }
+    } else if (LN) {
         // nn.LayerNorm statistics (two-pass, like ATen): wave w owns activation rows w and w + 4
         for (int b = wave; b < BQ; b += 4) {
             float sum = 0.0f;
@@ -161,7 +220,7 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     for (int p0 = 0; p0 < nch; p0 += CPP) {
         __syncthreads();  // previous panel fully consumed (and s_mean / s_rstd / s_f visible)
         const int pk = (nch - p0 < CPP ? nch - p0 : CPP) * 256;  // floats in this panel
-        for (int i = tid * 4; i < BQ * pk; i += 1024) {
+        for (int i = tid * 4; i < BQ * pk && !ln_fast; i += 1024) {
             const int b = i / pk, k = i - b * pk;
             f32x4 v;
             if (XM) {
@@ -492,8 +551,11 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
     // launch still covers every CU.  (Measured at C = 1536: 4 rows per wave for 4-8 batch rows, or a
     // side-stream weight prefetch into the Infinity Cache, did not help: the step is bound by the ~4.5 us
     // fixed cost of each of its 122 dependent launches, after which the kernels stream at 5-7 TB/s.)
+    // Wide outputs: 2 rows x 4 chunks x 2 buffers = 16 KiB per wave, i.e. a whole K = 1536 row pair is requested
+    // before the LayerNorm prologue finishes (the matrix streams from HBM while x is normalised).
     if (N <= 2048) launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-    else launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    else if (g_lm_wide_u == 2) launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    else launch_gemv_cfg<BQ, 2, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
 }
 
 template <int BQ>

@@ -31,10 +31,14 @@ def main():
     ap.add_argument("--layers", type=int, default=24)
     ap.add_argument("--heads", type=int, default=16)
     ap.add_argument("--embd", type=int, default=1536)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="omnitok_set_option switch (A/B)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     V, BS, L, H, C = a.vocab, a.block, a.layers, a.heads, a.embd
+    for kv in a.option:
+        from omnitokenizer_amd import _lib
+        _lib.set_option(kv.partition("=")[0], int(kv.partition("=")[2]))
     sd = synth_gpt_state(V, BS, L, H, C, seed=0)
     m = og.GPT(argparse.Namespace(), V, BS, n_layer=L, n_head=H, n_embd=C)
     m.load_state_dict(sd, strict=True)
