@@ -82,7 +82,6 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     const int row0 = (blockIdx.x * 4 + wave) * ROWS;
     const int kp = K < LM_KP ? K : LM_KP;
     const int nch = K >> 8;  // 256-float chunks
-    float *s_f = xs + BQ * kp;  // XM: [b][h][c] merge weights e^(M_c - M) / L
     const float *wr[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) wr[r] = w + (int64_t)(row0 + r < N ? row0 + r : N - 1) * K + lane * 4;
@@ -98,20 +97,6 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     };
     f32x4 wa[ROWS][U], wb[ROWS][U];
     load_w(wa, 0);  // in flight while the LayerNorm statistics / merge weights are computed
-    if (XM) {
-        // per (b, h): global max over the chunks that hold keys, then f_c = e^(M_c - M) / sum_c L_c e^(M_c - M)
-        for (int i = tid; i < BQ * mg.n_head; i += 256) {
-            const int b = i / mg.n_head, h = i - b * mg.n_head;
-            const int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
-            const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * (2 + mg.hd);
-            float M = -INFINITY;
-            for (int c = 0; c < used; ++c) M = fmaxf(M, pp[c * (2 + mg.hd)]);
-            float L = 0.0f;
-            for (int c = 0; c < used; ++c) L += pp[c * (2 + mg.hd) + 1] * expf(pp[c * (2 + mg.hd)] - M);
-            for (int c = 0; c < used; ++c)
-                s_f[(b * mg.n_head + h) * mg.nchunk + c] = expf(pp[c * (2 + mg.hd)] - M) / L;
-        }
-    }
     // LayerNorm with the whole row in one LDS panel (K <= LM_KP, every GPT block): x, gamma and beta are requested
     // together at kernel start (one memory round trip instead of three dependent ones), the two-pass statistics are
     // block-wide reductions over registers, and the normalised row goes straight to LDS.
@@ -224,14 +209,30 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
             const int b = i / pk, k = i - b * pk;
             f32x4 v;
             if (XM) {
+                // every staging thread merges its own head: global max over the chunks that hold keys, then
+                // f_c = e^(M_c - M) / sum_c L_c e^(M_c - M).  Chunk 0 always holds keys, so its partial is requested
+                // together with cache_len: up to 256 cached tokens the whole merge is one memory round trip (the
+                // per-head weight table in LDS, its three dependent passes and its barrier are gone).
                 const int col = p0 * 256 + k, h = col / mg.hd, d = col - h * mg.hd;  // hd % 4 == 0: one head per float4
+                const int S = 2 + mg.hd;
+                const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * S;
+                const float M0 = pp[0], L0 = pp[1];
+                const float q00 = pp[2 + d], q01 = pp[3 + d], q02 = pp[4 + d], q03 = pp[5 + d];
                 const int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
-                const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * (2 + mg.hd) + 2 + d;
-                const float *fw = s_f + (b * mg.n_head + h) * mg.nchunk;
+                float M = M0;
+                for (int c = 1; c < used; ++c) M = fmaxf(M, pp[c * S]);
+                float L = 0.0f;
+                L += L0 * expf(M0 - M);
+                for (int c = 1; c < used; ++c) L += pp[c * S + 1] * expf(pp[c * S] - M);
+                const float f0 = expf(M0 - M) / L;
                 v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                for (int c = 0; c < used; ++c) {
-                    const float f = fw[c];
-                    const float *q = pp + c * (2 + mg.hd);
+                v[0] += q00 * f0;
+                v[1] += q01 * f0;
+                v[2] += q02 * f0;
+                v[3] += q03 * f0;
+                for (int c = 1; c < used; ++c) {
+                    const float f = expf(pp[c * S] - M) / L;
+                    const float *q = pp + c * S + 2 + d;
                     v[0] += q[0] * f;
                     v[1] += q[1] * f;
                     v[2] += q[2] * f;
@@ -303,6 +304,13 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     // lm_kv_scatter_kernel), key t is the row's own K/V
     const int c = blockIdx.x, h = blockIdx.y, row = blockIdx.z;
     const int b = prefill_T > 0 ? row / prefill_T : row;
+    const int C = n_head * HD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slot = lane >> 3, ds = lane & 7;  // key slot 0..7, dim slot 0..7
+    const float *qn = qkv + (int64_t)row * 3 * C + h * HD;
+    f32x4 q[F4];  // requested before cache_len is known (one round trip for both)
+#pragma unroll
+    for (int i = 0; i < F4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(qn + (ds + 8 * i) * 4);
     int len = prefill_T > 0 ? row - b * prefill_T : cache_len[row];
     if (len >= max_len) {
         // a caller stepped past the cache it allocated: flag it (omnitok_lm_overflowed) and stay inside
@@ -312,10 +320,6 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     }
     const int total = len + 1;
     if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
-    const int C = n_head * HD;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slot = lane >> 3, ds = lane & 7;  // key slot 0..7, dim slot 0..7
-    const float *qn = qkv + (int64_t)row * 3 * C + h * HD;
     const float *kn = qn + C, *vn = qn + 2 * C;
     float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
     float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
@@ -326,45 +330,53 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
             vrow[(int64_t)len * HD + d] = vn[d];
         }
     }
-    f32x4 q[F4];
-#pragma unroll
-    for (int i = 0; i < F4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(qn + (ds + 8 * i) * 4);
     const float scale = 1.0f / sqrtf((float)HD);
     float m = -INFINITY, l = 0.0f;
     f32x4 o[F4];
 #pragma unroll
     for (int i = 0; i < F4; ++i) o[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const int kbase = c * LM_CHUNK + wave * 64;
-#pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        if (kbase + it * 8 >= total) break;  // wave-uniform: no keys left in this chunk
-        const int key = kbase + it * 8 + slot;
-        const bool valid = key < total;
-        // the new token's row is read from qkv (its cache copy is being written by this kernel)
-        const float *kp = key == len ? kn : krow + (int64_t)(valid ? key : 0) * HD;
-        const float *vp = key == len ? vn : vrow + (int64_t)(valid ? key : 0) * HD;
-        float s = 0.0f;
-        f32x4 vv[F4];
+    // 8 keys per iteration; four iterations' K and V rows are requested together (two memory round trips per 64 keys
+    // instead of one per pair).  Rows past the sequence are read from row 0 (a safe address) and masked.
+    for (int it0 = 0; it0 < 8; it0 += 4) {
+        if (kbase + it0 * 8 >= total) break;  // wave-uniform: no keys left in this chunk
+        f32x4 kk[4][F4], vv[4][F4];
+        bool valid[4];
 #pragma unroll
-        for (int i = 0; i < F4; ++i) {
-            const f32x4 kv = *reinterpret_cast<const f32x4 *>(kp + (ds + 8 * i) * 4);
-            vv[i] = *reinterpret_cast<const f32x4 *>(vp + (ds + 8 * i) * 4);
-            s = fmaf(q[i][0], kv[0], s);
-            s = fmaf(q[i][1], kv[1], s);
-            s = fmaf(q[i][2], kv[2], s);
-            s = fmaf(q[i][3], kv[3], s);
+        for (int j = 0; j < 4; ++j) {
+            const int key = kbase + (it0 + j) * 8 + slot;
+            valid[j] = key < total;
+            // the new token's row is read from qkv (its cache copy is being written by this kernel)
+            const float *kp = key == len ? kn : krow + (int64_t)(valid[j] ? key : 0) * HD;
+            const float *vp = key == len ? vn : vrow + (int64_t)(valid[j] ? key : 0) * HD;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                kk[j][i] = *reinterpret_cast<const f32x4 *>(kp + (ds + 8 * i) * 4);
+                vv[j][i] = *reinterpret_cast<const f32x4 *>(vp + (ds + 8 * i) * 4);
+            }
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        s += __shfl_xor(s, 4);
-        s = valid ? s * scale : -INFINITY;
-        const float mn = fmaxf(m, s);
-        if (mn > -INFINITY) {
-            const float corr = expf(m - mn), p = expf(s - mn);
-            l = l * corr + p;
 #pragma unroll
-            for (int i = 0; i < F4; ++i) o[i] = o[i] * corr + vv[i] * p;
-            m = mn;
+        for (int j = 0; j < 4; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                s = fmaf(q[i][0], kk[j][i][0], s);
+                s = fmaf(q[i][1], kk[j][i][1], s);
+                s = fmaf(q[i][2], kk[j][i][2], s);
+                s = fmaf(q[i][3], kk[j][i][3], s);
+            }
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            s = valid[j] ? s * scale : -INFINITY;
+            const float mn = fmaxf(m, s);
+            if (valid[j] && mn > -INFINITY) {   // a masked key changes nothing (and its V row may be uninitialised)
+                const float corr = expf(m - mn), p = expf(s - mn);
+                l = l * corr + p;
+#pragma unroll
+                for (int i = 0; i < F4; ++i) o[i] = o[i] * corr + vv[j][i] * p;
+                m = mn;
+            }
         }
     }
     // merge the 8 key slots of the wave (lanes with equal dim slot: xor 8, 16, 32)
@@ -536,7 +548,7 @@ template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
 static void launch_gemv_cfg(const float *x, const float *w, const float *bias, const float *residual, const float *g,
                             const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
     const int kp = K < LM_KP ? K : LM_KP;
-    const int lds = (BQ * kp + (XM ? BQ * mg.n_head * mg.nchunk : 0)) * 4;
+    const int lds = BQ * kp * 4;
     const int rows_per_wg = 4 * ROWS;
     if (lds > 65536) (void)set_max_dynamic_lds(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), lds);
     hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256),
