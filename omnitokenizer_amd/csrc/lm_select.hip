@@ -19,6 +19,7 @@ namespace omnitok {
 
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_SORT_MAX = 16384;  // survivors the LDS sort buffer holds (128 KiB)
+constexpr int SEL_VPT = 16;          // REG build: a thread keeps its V / 1024 values in registers (V <= 16384)
 
 struct SelParams {
     const float *logits;    // [B, V]
@@ -73,6 +74,8 @@ __device__ __forceinline__ float block_exclusive_scan(float v, float *scratch, f
     return base + x - v;
 }
 
+// REG: the row is read (and the CFG blend / temperature division done) once; every later pass runs on registers.
+template <bool REG>
 __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long sel_sort[];  // [SEL_SORT_MAX] (sorted path)
     __shared__ float s_red[SEL_THREADS / 64];
@@ -87,11 +90,46 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
     // ---- pass 1: values (optionally written out), maximum and its first index -------------------------
     float mx = -INFINITY;
     int mi = 0x7FFFFFFF;
-    for (int i = tid; i < V; i += SEL_THREADS) {
-        const float v = sel_value(p, b, i);
-        if (p.blend_out) p.blend_out[b * V + i] = v;
-        if (v > mx) { mx = v; mi = i; }
+    float vals[REG ? SEL_VPT : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < SEL_VPT; ++j) {
+            const int i = tid + j * SEL_THREADS;
+            vals[j] = i < V ? sel_value(p, b, i) : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < SEL_VPT; ++j) {
+            const int i = tid + j * SEL_THREADS;
+            if (i < V) {
+                if (p.blend_out) p.blend_out[b * V + i] = vals[j];
+                if (vals[j] > mx) { mx = vals[j]; mi = i; }
+            }
+        }
+    } else {
+        for (int i = tid; i < V; i += SEL_THREADS) {
+            const float v = sel_value(p, b, i);
+            if (p.blend_out) p.blend_out[b * V + i] = v;
+            if (v > mx) { mx = v; mi = i; }
+        }
     }
+    // f(value, column, valid) for this thread's columns, called by every lane of the wave the same number of times
+    // (the wave-aggregated atomics below ballot inside f)
+    auto each = [&](auto &&f) {
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < SEL_VPT; ++j) {
+                if (j * SEL_THREADS < V) {  // uniform
+                    const int i = tid + j * SEL_THREADS;
+                    f(vals[j], i, i < V);
+                }
+            }
+        } else {
+            for (int i0 = 0; i0 < V; i0 += SEL_THREADS) {
+                const int i = i0 + tid;
+                f(i < V ? sel_value(p, b, i) : -INFINITY, i, i < V);
+            }
+        }
+    };
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float om = __shfl_xor(mx, off);
@@ -155,19 +193,52 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
             const unsigned prefix = s_prefix, pmask = pass ? 0xFFFFFFFFu << (shift + 8) : 0u;
-            for (int i = tid; i < V; i += SEL_THREADS) {
-                const unsigned k = sel_key(sel_value(p, b, i));
-                if ((k & pmask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1u);
-            }
-            __syncthreads();
-            if (tid == 0) {  // walk the bins from the top: the bin where the running count reaches k
-                unsigned left = s_kleft, bin = 255;
-                for (int q = 255; q >= 0; --q) {
-                    if (s_hist[q] >= left) { bin = (unsigned)q; break; }
-                    left -= s_hist[q];
+            each([&](float v, int, bool valid) {
+                const unsigned k = sel_key(v);
+                const bool match = valid && (k & pmask) == prefix;
+                const unsigned bin = (k >> shift) & 255;
+                if (pass == 0) {
+                    // sign + 7 exponent bits: a row of logits falls into a handful of bins, 8192 single atomics on
+                    // them serialise; one atomic per (wave, distinct bin) instead
+                    unsigned long long todo = __ballot(match);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const unsigned lb = __shfl(bin, leader);
+                        const unsigned long long same = __ballot(match && bin == lb);
+                        if (lane == leader) atomicAdd(&s_hist[lb], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                } else if (match) {
+                    atomicAdd(&s_hist[bin], 1u);
                 }
-                s_kleft = left;
-                s_prefix = prefix | (bin << shift);
+            });
+            __syncthreads();
+            if (wave == 0) {
+                // the bin where the count from the top reaches k: the largest q with S_q = sum_{q' >= q} hist[q'] >= k.
+                // One wave, four bins per lane, suffix sums by shuffles (a single thread walking the 256 bins was
+                // 4 x ~10 us of dependent LDS reads: two thirds of the kernel).
+                const unsigned left = s_kleft;
+                const unsigned h0 = s_hist[4 * lane], h1 = s_hist[4 * lane + 1], h2 = s_hist[4 * lane + 2],
+                               h3 = s_hist[4 * lane + 3];
+                const unsigned tot = (h0 + h1) + (h2 + h3);
+                unsigned suf = tot;  // inclusive suffix sum over the lanes
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const unsigned y = __shfl_down(suf, off);
+                    if (lane + off < 64) suf += y;
+                }
+                const unsigned above = suf - tot;  // keys in the bins of higher lanes
+                const unsigned S3 = above + h3, S2 = S3 + h2, S1 = S2 + h1, S0 = S1 + h0;
+                int bin = -1;
+                unsigned over = 0;  // S_{bin + 1}
+                if (S3 >= left && above < left) { bin = 4 * lane + 3; over = above; }
+                else if (S2 >= left && S3 < left) { bin = 4 * lane + 2; over = S3; }
+                else if (S1 >= left && S2 < left) { bin = 4 * lane + 1; over = S2; }
+                else if (S0 >= left && S1 < left) { bin = 4 * lane; over = S1; }
+                if (bin >= 0) {  // exactly one lane (1 <= left <= number of matching keys)
+                    s_kleft = left - over;
+                    s_prefix = prefix | ((unsigned)bin << shift);
+                }
             }
             __syncthreads();
         }
@@ -176,13 +247,19 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
     // compact the survivors (order irrelevant: the sort below is total)
     if (tid == 0) s_count = 0;
     __syncthreads();
-    for (int i = tid; i < V; i += SEL_THREADS) {
-        const unsigned k = sel_key(sel_value(p, b, i));
-        if (k >= thr_key) {
-            const unsigned slot = atomicAdd(&s_count, 1u);
-            if (slot < SEL_SORT_MAX) sel_sort[slot] = ((unsigned long long)k << 32) | (0xFFFFFFFFu - (unsigned)i);
+    each([&](float v, int i, bool valid) {  // one counter atomic per wave and call
+        const unsigned k = sel_key(v);
+        const bool keep = valid && k >= thr_key;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&s_count, (unsigned)__popcll(m));
+            base = __shfl(base, leader);
+            const unsigned slot = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep && slot < SEL_SORT_MAX) sel_sort[slot] = ((unsigned long long)k << 32) | (0xFFFFFFFFu - (unsigned)i);
         }
-    }
+    });
     __syncthreads();
     const int n_keep = (int)s_count;
     if (n_keep > SEL_SORT_MAX) {
@@ -192,13 +269,43 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
         }
         return;
     }
-    int P = 64;
+    int P = 128;
     while (P < n_keep) P <<= 1;
     for (int i = n_keep + tid; i < P; i += SEL_THREADS) sel_sort[i] = 0ull;  // padding sorts last
     __syncthreads();
-    // bitonic sort, descending
-    for (int k = 2; k <= P; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    // bitonic sort, descending.  Compare-exchange distances j <= 64 stay inside aligned blocks of 128 elements: a wave
+    // takes a block into registers (two elements per lane), does j = 64 between its two registers and j = 32 .. 1 by
+    // shuffles, with no workgroup barrier; only the j >= 128 stages go through LDS stage by stage (P = 2048: 15
+    // barriers instead of 66 -- with 16 waves a barrier costs about as much as a stage).
+    auto inwave = [&](int k_lo, int k_hi) {  // phases k_lo .. k_hi, of each the sub-stages j = min(k / 2, 64) .. 1
+        for (int blk = wave; blk < (P >> 7); blk += SEL_THREADS / 64) {
+            const int e0 = (blk << 7) + lane, e1 = e0 + 64;
+            unsigned long long x0 = sel_sort[e0], x1 = sel_sort[e1];
+            for (int k = k_lo; k <= k_hi; k <<= 1) {
+                int j = k >> 1;
+                if (j >= 64) {
+                    const bool desc = (e0 & k) == 0;
+                    if ((x0 < x1) == desc) { const unsigned long long t = x0; x0 = x1; x1 = t; }
+                    j = 32;
+                }
+                for (; j > 0; j >>= 1) {
+                    const unsigned long long y0 = __shfl_xor(x0, j), y1 = __shfl_xor(x1, j);
+                    const bool is_lo = (lane & j) == 0;
+                    const bool d0 = ((e0 & ~j) & k) == 0, d1 = ((e1 & ~j) & k) == 0;  // direction of the pair
+                    const unsigned long long mx0 = x0 > y0 ? x0 : y0, mn0 = x0 > y0 ? y0 : x0;
+                    const unsigned long long mx1 = x1 > y1 ? x1 : y1, mn1 = x1 > y1 ? y1 : x1;
+                    x0 = (is_lo == d0) ? mx0 : mn0;  // descending pair: the lower index takes the larger key
+                    x1 = (is_lo == d1) ? mx1 : mn1;
+                }
+            }
+            sel_sort[e0] = x0;
+            sel_sort[e1] = x1;
+        }
+    };
+    inwave(2, 128);
+    __syncthreads();
+    for (int k = 256; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
             for (int t = tid; t < P / 2; t += SEL_THREADS) {
                 const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi2 = lo | j;
                 const bool desc = (lo & k) == 0;
@@ -207,6 +314,9 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
             }
             __syncthreads();
         }
+        inwave(k, k);
+        __syncthreads();
+    }
     // probabilities in rank order (unnormalised), prefix sums over contiguous per-thread chunks
     const int per = (n_keep + SEL_THREADS - 1) / SEL_THREADS;
     const int r0 = tid * per < n_keep ? tid * per : n_keep, r1 = r0 + per < n_keep ? r0 + per : n_keep;
@@ -287,8 +397,13 @@ extern "C" int omnitok_lm_select(const float *logits, const float *logits_uncond
     p.V = V; p.top_k = top_k; p.sample = sample; p.top_p = top_p; p.u = u; p.out = out; p.blend_out = blend_out;
     p.err_flag = err_flag;
     const int lds = SEL_SORT_MAX * 8;
-    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(lm_select_kernel), lds)) return rc;
-    hipLaunchKernelGGL(lm_select_kernel, dim3(B), dim3(SEL_THREADS), lds, stream, p);
+    if (V <= SEL_THREADS * SEL_VPT) {
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(lm_select_kernel<true>), lds)) return rc;
+        hipLaunchKernelGGL(lm_select_kernel<true>, dim3(B), dim3(SEL_THREADS), lds, stream, p);
+    } else {
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(lm_select_kernel<false>), lds)) return rc;
+        hipLaunchKernelGGL(lm_select_kernel<false>, dim3(B), dim3(SEL_THREADS), lds, stream, p);
+    }
     OT_LAUNCH_CHECK("lm_select");
     return OMNITOK_OK;
 }

@@ -280,7 +280,8 @@ def test_tokens_to_pixels_chain():
 # ---- token selection kernel (csrc/lm_select.hip) ---------------------------------------------------------------
 @pytest.mark.parametrize("V,top_k,top_p,temp", [(320, 50, 0.9, 0.9), (9193, 2048, 0.9, 1.0), (9193, 64, 1.0, 0.7),
                                                 (300, 300, 0.5, 1.0), (520, 1, 0.3, 1.0), (17385, None, None, 1.0),
-                                                (9193, 0, 0.7, 1.3), (8193, 8192, 0.95, 1.0)])
+                                                (9193, 0, 0.7, 1.3), (8193, 8192, 0.95, 1.0), (17385, 100, 0.9, 1.0),
+                                                (16384, 2048, 0.9, 1.0)])
 def test_select_kernel_vs_reference_semantics(V, top_k, top_p, temp):
     """greedy = argmax; stochastic = inverse CDF over the survivors of the reference's filter (gpt.py:19-51): for u
     at the midpoints of the oracle's CDF intervals the kernel returns exactly the oracle's token, for random u the
