@@ -47,16 +47,24 @@ int omnitok_gemm_pp(const void *a_planes, const float *a_scale, const void *w_pl
 const char *omnitok_last_error(void);
 /* "omnitok <version> gfx950 ..." */
 const char *omnitok_version(void);
-/* Tuning knobs for A/B measurements (process-global; not part of the functional contract):
- * "gemm_variant" (0 one tile per workgroup | 1 persistent 128x128 | 2 persistent 256x128, +4 forces it
- * whatever the size), "gemm_small" (1: 64x128 tiles when the 128x128 tiling has fewer workgroups
- * than CUs), "gemm_lds_pad_kb", "peg_variant". Unknown names return OMNITOK_ERR_INVALID. */
+/* Switches (process-global).  Arithmetic modes -- every mode holds the parity bars of tests/:
+ *   "gemm_mode"  2 (default) fp32 operands as 2 fp16 planes, 3 fp16-MFMA products (gemm_h2.hip) | 1 three bf16 planes, 6
+ *                products (gemm_x3.hip) | 0 fp32-input MFMA (gemm.hip)
+ *   "attn_mode"  1 (default) spatial attention on the fp16 matrix cores from split operands (attn_h2.hip) | 0 fp32 MFMA
+ *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
+ * Tuning knobs for A/B measurements (not part of the functional contract): "gemm_variant" (0 one tile per workgroup |
+ * 1 persistent 128x128 | 2 persistent 256x128, +4 forces it whatever the size), "gemm_small" (1: 64x128 tiles when the
+ * 128x128 tiling has fewer workgroups than CUs), "gemm_gn", "gemm_lds_pad_kb", "x3_tile", "h2_tile" (0 auto | 1 256x256
+ * | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "attn_h2_variant" (1 LDS-DMA pipelined | 0 register staged),
+ * "vq_split", "peg_variant", "lm_wide_u" (2 | 4 chunks per register buffer of the wide LM GEMVs); "x3_dbg" / "h2_dbg"
+ * select the wrong-result ablation builds of tools/x3_ablate.py and tools/h2_bench.py.
+ * Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
-/* Measurement only: pure v_mfma_f32_32x32x2_f32 stream (4 accumulators per wave, operands from
- * `in`[4096]) to find the sustained fp32-MFMA ceiling of the chip. out[blocks*256]. */
 /* Measurement only: device buffer of 4 x 96 int64; workgroup 0 of the persistent GEMM stores
  * s_memtime stamps (3 per K-step per wave: stream start, stream end, loop end). NULL = off. */
 int omnitok_debug_set_gemm_trace(long long *dev_ptr);
+/* Measurement only: pure v_mfma_f32_32x32x2_f32 stream (4 accumulators per wave, operands from
+ * `in`[4096]) to find the sustained fp32-MFMA ceiling of the chip. out[blocks*256]. */
 int omnitok_debug_mfma_peak(const float *in, float *out, int blocks, int iters, int lds_bytes,
                             long long *clk, omnitok_stream_t stream);
 
