@@ -249,7 +249,7 @@ def main():
                 watching[0] = False
                 th.join()
                 busy = {d: max(sn.get(d, 0) for sn in snaps) for d in idle}
-                files, hw = gpu_power.pick_hwmon(idle, busy)
+                files, hw = gpu_power.pick_hwmon(idle, busy, pci=gpu_power.pci_address(torch.cuda.current_device()))
                 if files:
                     smp = gpu_power.Sampler(files)
                     smp.start()

@@ -25,3 +25,26 @@ def test_pick_hwmon_selects_the_card_under_load(tmp_path):
     # nothing rose by 100 W: no pick
     assert gpu_power.pick_hwmon({d: v[0] for d, v in dirs.items()}, {d: v[0] + 1 for d, v in dirs.items()}) == ({}, None)
     assert gpu_power.pick_hwmon({}, {}) == ({}, None)
+
+
+def test_pick_hwmon_prefers_the_pci_address(tmp_path):
+    """two GPUs under load (another tenant's draws more): the PCI address of our device decides."""
+    snaps = {}
+    for name, pci, (idle, busy) in (("card8", "0000:0a:00.0", (250e6, 1400e6)), ("card48", "0000:d9:00.0", (246e6, 1300e6))):
+        dev = tmp_path / "pci" / pci
+        hw = dev / "hwmon" / "hwmon3"
+        hw.mkdir(parents=True)
+        (hw / "freq1_input").write_text("2000000000\n")
+        (hw / "power1_input").write_text(str(int(busy)) + "\n")
+        card = tmp_path / "drm" / name
+        card.mkdir(parents=True)
+        os.symlink(dev, card / "device")
+        snaps[str(card / "device" / "hwmon" / "hwmon3")] = (int(idle), int(busy))
+    idle = {d: v[0] for d, v in snaps.items()}
+    busy = {d: v[1] for d, v in snaps.items()}
+    files, info = gpu_power.pick_hwmon(idle, busy, pci="0000:d9:00.0")
+    assert "card48" in files["power_uw"] and info["picked_by"] == "pci_address"
+    files, info = gpu_power.pick_hwmon(idle, busy)                       # no address: the larger rise
+    assert "card8" in files["power_uw"] and info["picked_by"] == "power_rise"
+    files, info = gpu_power.pick_hwmon(idle, busy, pci="0000:ff:00.0")   # unknown address: falls back
+    assert "card8" in files["power_uw"] and info["picked_by"] == "power_rise"

@@ -28,7 +28,7 @@ def hwmon_files(load_fn):
     time.sleep(0.6)
     busy = gpu_power.snapshot()
     torch.cuda.synchronize()
-    return gpu_power.pick_hwmon(idle, busy)
+    return gpu_power.pick_hwmon(idle, busy, pci=gpu_power.pci_address(torch.cuda.current_device()))
 
 
 def smi_once():

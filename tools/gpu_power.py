@@ -29,13 +29,35 @@ def snapshot():
     return _powers()
 
 
-def pick_hwmon(idle, busy, min_rise_w=100.0):
-    """The hwmon directory whose power rose most between the two snapshots (a node lists every GPU and partition
-    under /sys/class/drm; only one is this process's).  Returns (files, info) or ({}, None)."""
+def pci_address(device_index=0):
+    """'dddd:bb:dd.0' of a torch device (None when torch / the properties are not available)."""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(device_index)
+        return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def pick_hwmon(idle, busy, min_rise_w=100.0, pci=None):
+    """The hwmon directory of this process's GPU (a node lists every GPU and partition under /sys/class/drm): the one
+    whose PCI address is `pci` if its power rose between the two snapshots, otherwise the one whose power rose most
+    (other tenants' GPUs may be busy too: the PCI match is the safer key).  Returns (files, info) or ({}, None)."""
     common = [d for d in idle if d in busy]
     if not common:
         return {}, None
-    d = max(common, key=lambda k: busy[k] - idle[k])
+    d, how = None, "power_rise"
+    if pci:
+        for c in common:
+            try:
+                dev = os.path.basename(os.path.realpath(os.path.dirname(os.path.dirname(c))))
+            except OSError:
+                continue
+            if dev == pci and busy[c] - idle[c] >= min_rise_w * 1e6:
+                d, how = c, "pci_address"
+                break
+    if d is None:
+        d = max(common, key=lambda k: busy[k] - idle[k])
     if busy[d] - idle[d] < min_rise_w * 1e6:
         return {}, None
     files = {}
@@ -43,7 +65,8 @@ def pick_hwmon(idle, busy, min_rise_w=100.0):
         for n in names:
             if key not in files and read_int(os.path.join(d, n)) is not None:
                 files[key] = os.path.join(d, n)
-    info = {"card": next((c for c in d.split("/") if c.startswith("card")), d), "idle_power_w": idle[d] / 1e6,
+    info = {"card": next((c for c in d.split("/") if c.startswith("card")), d), "picked_by": how,
+            "idle_power_w": idle[d] / 1e6,
             "power_cap_w": (read_int(os.path.join(d, "power1_cap")) or 0) / 1e6}
     try:
         info["sclk_levels"] = " ".join(open(os.path.join(os.path.dirname(os.path.dirname(d)), "pp_dpm_sclk")).read().split())
