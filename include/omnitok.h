@@ -163,6 +163,52 @@ int omnitok_gemm_h2_vpack(const float *a, int64_t lda, const void *w_planes, con
                           float ln_bound, float *c2, int64_t ldc2, int split_col, void *v_planes, int v_col0,
                           int n_tokens, int heads, float v_bound, const float *v_bound_dev, int v_bound_stride,
                           omnitok_stream_t stream);
+/* --- plane x plane GEMM (csrc/gemm_pl.h, gemm_pl.hip) --------------------------------------------------------
+ * The arithmetic of omnitok_gemm_h2 with BOTH operands already stored as fp16 hi|lo planes in blocks of 64 rows
+ * x 32 k ([rows/64][K/32][hi|lo][4 k groups][64 rows][8] fp16, 8 KiB per block): the K loop is LDS-DMA + ds_read +
+ * MFMA only, the producers of the activations (LayerNorm / GEGLU / attention epilogues, omnitok_pl_pack_rows,
+ * omnitok_ln_pack) write the planes.  Every nn.Linear of the Transformer blocks runs through it (reference
+ * attention.py:153-168, 386-393, 216-252).
+ *   weights: omnitok_pl_pack_weight (row-scaled by a power of two, rows permuted inside groups of 32 so that an
+ *            accumulator lane owns runs of 8 consecutive output columns); n_pad % 256 == 0 rows are written.
+ *   activations: one power-of-two scale per row (a_scale[m] = the factor that undoes it) and / or one static
+ *            factor; the plane buffer must hold ceil(M / 256) * 256 rows (rows >= M are never stored to outputs).
+ * c[m, n] = (sum_k a'[m, k] w'[n, k]) * a_scale[m] * a_scale_const * w_scale[n]  (+ bias[n]) (+ residual[m, n]). */
+typedef struct omnitok_pl_gemm {
+    const void *a;              /* activation planes                                                            */
+    const float *a_scale;       /* [M] or NULL                                                                  */
+    float a_scale_const;        /* <= 0: 1                                                                      */
+    const void *a2;             /* optional second activation operand for output columns >= a_split_n           */
+    const float *a2_scale;
+    float a2_scale_const;
+    int a_split_n;              /* % 256 == 0                                                                   */
+    const void *w;              /* weight planes                                                                */
+    const float *w_scale;       /* [N]                                                                          */
+    const float *bias;          /* [N] or NULL                                                                  */
+    const float *residual;      /* [M, ldr] or NULL (may alias c)                                               */
+    int64_t ldr;
+    float *c;                   /* fp32 output [M, ldc] (epilogue 0)                                            */
+    int64_t ldc;
+    float *c2;                  /* optional: columns >= c_split_n go to c2[m, n - c_split_n]                    */
+    int64_t ldc2;
+    int c_split_n;
+    void *out_planes;           /* epilogue 1 (GEGLU): hidden planes, K = out_planes_k = N / 2                  */
+    int out_planes_k;
+    float out_bound;            /* >= max |hidden|: the consumer uses a_scale_const = 1 / h2 scale of it        */
+    int epilogue;               /* 0 fp32 | 1 GEGLU -> planes                                                   */
+    int64_t M;
+    int N, K;
+    int cfg;                    /* 0 auto | 1 256x256 tiles, one workgroup per CU | 2 128x256, two per CU        */
+    long long *debug_cycles;    /* measurement: shader-clock span of workgroup 0 (NULL = off)                   */
+} omnitok_pl_gemm;
+int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad);
+int omnitok_pl_pack_weight(const float *w, int64_t ldw, int N, int K, int n_pad, void *planes, float *scale,
+                           omnitok_stream_t stream);
+/* x[M, ldx] fp32 -> planes (m_pad rows, rows >= M zero); per-row scales into a_scale, or one static scale from
+ * static_bound (> 0) */
+int omnitok_pl_pack_rows(const float *x, int64_t ldx, int64_t M, int K, int64_t m_pad, void *planes, float *a_scale,
+                         float static_bound, omnitok_stream_t stream);
+int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of

@@ -1,0 +1,509 @@
+// "pl" GEMM: c = a . w^T on the fp16 matrix cores with BOTH operands already stored as fp16 hi|lo planes
+// (2-way exact-scale split of fp32, see gemm_h2.hip for the arithmetic) in 8 KiB blocks of 64 rows x 32 k:
+//     block[row / 64][k / 32] = [plane (hi, lo)][k group (k / 8) % 4][row % 64][k % 8]   fp16
+// so that one (plane, k group) of a block is 1 KiB of contiguous memory = one global_load_lds_dwordx4 of a wave,
+// and the same bytes in LDS are MFMA fragments (lane (r32, half) reads row r32, k group `half`: 16 B).
+//
+// The K loop contains nothing but LDS-DMA issues, ds_read_b128 and MFMAs: no VALU work on the operands, no ds_write.
+// Producers write the activation planes (LayerNorm / GEGLU / attention epilogues, gemm_pl.hip: omnitok_pl_pack_rows).
+//
+// Orientation.  The WEIGHT fragments go to the MFMA's a slot and the ACTIVATION fragments to the b slot, i.e. a
+// 32x32 accumulator block holds out^T: lane (r32, half) owns ONE token row m = r32 and 16 output columns.  The weight
+// rows are stored permuted inside every group of 32 (pl_perm) so that those 16 columns are two runs of 8 consecutive n:
+//     registers 0..7  -> n0 + half * 8 + j,     registers 8..15 -> n0 + 16 + half * 8 + j
+// A lane therefore stores 32 contiguous bytes per run (fp32 output), or exactly one 16-byte fp16 chunk per plane of
+// the NEXT GEMM's activation operand (k group = run * 2 + half): epilogues write plane blocks with 512-byte
+// contiguous runs per half wave and no cross-lane traffic.  SWAP = true exchanges the slots (lane = column n,
+// registers = 16 token rows: the layout the packed-V epilogue of the attention kernel wants).
+//
+// Structure: wave tile 64 n x 128 m (2 x 4 accumulator blocks = 128 registers), WN x WM waves per workgroup, K steps
+// of 16, a ring of R LDS stages filled two steps ahead, one barrier per step, three MFMA groups per step
+// (W lo . A hi | W hi . A hi | W hi . A lo) with the fragment reads of a group issued one group earlier.
+#pragma once
+#include "gemm_x_common.h"
+#include "h2_common.h"
+
+namespace omnitok {
+
+typedef __attribute__((address_space(3))) void pl_lds_t;
+typedef __attribute__((address_space(1))) const void pl_glob_t;
+
+enum PlEpi {
+    PL_F32 = 0,         // fp32 row-major output (+ bias, + residual)
+    PL_GEGLU = 1,       // GEGLU of (value | gate) 32-column pairs -> fp16 planes of the hidden (next GEMM's operand)
+    PL_ROWLN = 2,       // full-row tiles (TN == N): fp32 output (+ bias, + residual) AND LayerNorm(out) as planes
+    PL_VPACK = 3,       // SWAP only: V columns into the attention kernel's packed fp16 planes (attn_h2.hip)
+};
+
+struct PlParams {
+    // activation planes; tiles whose first column is >= a_split_n read a2 / a2_scale instead (merged q | k launch:
+    // Q from LayerNorm(x), K from the raw x)
+    const unsigned char *a, *a2;
+    const float *a_scale, *a2_scale;  // [M] per-row factors that undo the activation scaling, or null
+    float a_scale_const, a2_scale_const;  // multiplied in (1 when the per-row array carries everything)
+    int a_split_n;                    // 0: no second operand
+    const unsigned char *w;           // weight planes (rows permuted, pl_perm)
+    const float *w_scale;             // [N]
+    const float *bias;                // [N] or null
+    const float *residual;
+    int64_t ldr;
+    float *c;
+    int64_t ldc;
+    float *c2;                        // columns >= c_split_n go to c2 (row stride ldc2), column index minus c_split_n
+    int64_t ldc2;
+    int c_split_n;
+    // plane outputs (PL_GEGLU: the hidden; PL_ROWLN: LayerNorm(out))
+    unsigned char *cp;
+    int cp_kblocks;                   // K / 32 of the consumer
+    float cp_scale;                   // power of two applied before the split (from a static bound)
+    const float *ln_gamma, *ln_beta;  // PL_ROWLN
+    float ln_eps;
+    // PL_VPACK
+    unsigned char *vp;
+    int v_ntok, v_heads;
+    float v_bound;
+    const float *v_bound_dev;
+    int v_bound_stride;
+    int64_t v_rpc;
+    int64_t M;
+    int N, K;
+    int nbm, nbn, ntiles, gn;
+    long long *cycles;                // measurement: s_memtime span of workgroup 0 (null = off)
+};
+
+// logical row (inside a group of 32) stored at physical position i: the MFMA a-slot row i lands in lane half
+// (i >> 2) & 1, register (i >> 3) * 4 + (i & 3)
+__host__ __device__ __forceinline__ int pl_perm(int i) {
+    const int half = (i >> 2) & 1, r = (i >> 3) * 4 + (i & 3);
+    return (r >> 3) * 16 + half * 8 + (r & 7);
+}
+
+__host__ __device__ __forceinline__ int64_t pl_offset(int64_t row, int k, int plane, int K) {  // in fp16 elements
+    return (((row >> 6) * (K >> 5) + (k >> 5)) * 8 + plane * 4 + ((k >> 3) & 3)) * 512 + (row & 63) * 8 + (k & 7);
+}
+
+// s_waitcnt vmcnt(n) only: gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+#define PL_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+
+// D = how many K steps the DMA cursor runs ahead (D < R).  DBG (measurement builds, wrong results): 1 no vmcnt wait in
+// front of the barrier, 2 no barrier, 4 no DMA in the K loop
+// Wave tile = NI x MI accumulator blocks of 32 x 32 (n x m): 2 x 4 at two waves per SIMD (256 registers), 4 x 4 at one
+// wave per SIMD (512 registers; a third fewer fragment bytes read from LDS per MFMA -- the kernel is power-bound, so
+// bytes moved per flop, not stalls, set its rate: profiles/r03_pl_ablation.txt).
+// PM = 1 ("product major", one wave per SIMD only): the three products of an accumulator block are issued back to back
+// (both fragment sets of a step live at once, the next step's set is read meanwhile: two sets of 4 * (NI + MI) registers).
+template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4, int PM_ = 0>
+struct PlCfg {
+    static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_, PM = PM_;
+    static constexpr int NW = WN * WM, NT = 64 * NW;
+    static constexpr int TN = 32 * NI * WN, TM = 32 * MI * WM;
+    static constexpr int WPS = NW > 4 ? 2 : 1;  // waves per SIMD of one workgroup
+    static constexpr int SA = TM * 64, SW = TN * 64, STAGE = SA + SW;  // bytes per K step of 16
+    static constexpr int NPA = 4 * (TM / 64), NPW = 4 * (TN / 64), NP = NPA + NPW;
+    static constexpr int PPW = NP / NW;  // DMA pieces (1 KiB) per wave per step
+    static constexpr int LDS = R * STAGE;
+    static_assert(NP % NW == 0, "pieces per wave");
+    static_assert(PPW <= 8 && (D_ - 1) * PPW < 48, "vmcnt bookkeeping");
+    static_assert(D_ >= 2 && D_ <= 3 && D_ < R_, "prefetch distance");
+};
+
+template <int EPI, bool SWAP, typename C>
+__global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_kernel(PlParams p) {
+    constexpr int TN = C::TN, TM = C::TM, R = C::R, PPW = C::PPW, NW = C::NW, D = C::D, DBG = C::DBG;
+    constexpr int NI = C::NI, MI = C::MI;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32_ = lane & 31, hi_ = lane >> 5;
+    const int wn = wave % C::WN, wm = wave / C::WN;
+    const int pair = (C::WPS == 2) ? (wave >> 2) : 0;  // the two waves of a SIMD inside one workgroup: staggered DMA issue
+    if ((int)blockIdx.x >= p.ntiles) return;
+    const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int nk = p.K >> 4, kblocks = p.K >> 5;
+    const int total = my_tiles * nk;
+    long long t_start = 0;
+    if (p.cycles && blockIdx.x == 0 && tid == 0) t_start = __builtin_amdgcn_s_memtime();
+
+    // ---- DMA pieces of this wave: piece q = wave + NW * j ------------------------------------------------------
+    unsigned pv_off[PPW];   // byte offset inside the tile's operand panel (+ lane * 16)
+    int pl_dst[PPW];        // byte offset inside a stage
+    bool p_is_w[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave + NW * j;
+        const bool is_w = q >= C::NPA;
+        const int qq = is_w ? q - C::NPA : q;
+        const int rowsb = is_w ? TN / 64 : TM / 64;
+        const int plkg = qq / rowsb, rb = qq % rowsb;
+        p_is_w[j] = is_w;
+        pv_off[j] = (unsigned)rb * (unsigned)kblocks * 8192u + (unsigned)(plkg >> 1) * 4096u + (unsigned)(plkg & 1) * 1024u +
+                    (unsigned)lane * 16u;
+        pl_dst[j] = (is_w ? C::SA : 0) + qq * 1024;
+    }
+    // the DMA cursor runs two steps ahead of the MFMAs, across tile boundaries
+    const unsigned char *d_a = nullptr, *d_w = nullptr;  // panel bases of the cursor's tile (wave-uniform)
+    int d_tile = -1, d_k = 0, d_stage = 0;
+    auto d_set_tile = [&](int ti) {
+        const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
+        int64_t bm;
+        int bn;
+        tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+        const unsigned char *ab = (p.a_split_n > 0 && bn * TN >= p.a_split_n) ? p.a2 : p.a;
+        d_a = ab + bm * (TM / 64) * (int64_t)kblocks * 8192;
+        d_w = p.w + (int64_t)bn * (TN / 64) * (int64_t)kblocks * 8192;
+        d_tile = ti;
+        d_k = 0;
+    };
+    auto dma_step = [&]() {  // issue the pieces of K step d_k of tile d_tile into stage d_stage, advance the cursor
+        const unsigned koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const unsigned char *src = (p_is_w[j] ? d_w : d_a) + koff + pv_off[j];
+            __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + d_stage * C::STAGE + pl_dst[j]), 16, 0, 0);
+        }
+        d_stage = d_stage + 1 == R ? 0 : d_stage + 1;
+        if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
+    };
+
+    // ---- fragments ---------------------------------------------------------------------------------------------
+    // A (activations, b slot unless SWAP): X = hi plane, Y = lo plane, 4 blocks of 32 rows; W: Ph / Pl, 2 blocks
+    u32x4 X[MI], Y[MI], Ph[NI], Pl[NI];
+    const int a_fr = (hi_ * TM + wm * (32 * MI) + r32_) * 16;
+    const int w_fr = C::SA + (hi_ * TN + wn * (32 * NI) + r32_) * 16;
+    auto rdA = [&](u32x4 (&f)[MI], int stage, int plane) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+            f[mi] = *reinterpret_cast<const u32x4 *>(pl_smem + stage * C::STAGE + a_fr + plane * (2 * TM * 16) + mi * 512);
+    };
+    auto rdW = [&](u32x4 (&f)[NI], int stage, int plane) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            f[ni] = *reinterpret_cast<const u32x4 *>(pl_smem + stage * C::STAGE + w_fr + plane * (2 * TN * 16) + ni * 512);
+    };
+    f32x16 acc[NI][MI];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.0f;
+    };
+    zero_acc();
+    auto mfma1 = [&](const u32x4 &wf, const u32x4 &af, f32x16 &c) {
+        if constexpr (SWAP)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, wf), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, af), c, 0, 0, 0);
+    };
+    // one MFMA group (NI * MI blocks) with `hook(i)` called after every second MFMA (NI * MI / 2 issue slots)
+    constexpr int SLOTS = NI * MI / 2;
+    auto group = [&](u32x4 (&wf)[NI], u32x4 (&af)[MI], auto &&hook) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                mfma1(wf[ni], af[mi], acc[ni][mi]);
+                if (mi & 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    hook((ni * MI + mi) >> 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+    };
+    auto nohook = [](int) {};
+
+    // ---- prologue ----------------------------------------------------------------------------------------------
+    d_set_tile(0);
+    dma_step();
+    if (total > 1) dma_step();
+    if (D > 2 && total > 2) dma_step();
+    int st = 0;  // stage of the current step
+    // second fragment set of the product-major form
+    u32x4 X2[C::PM ? MI : 1], Y2[C::PM ? MI : 1], Ph2[C::PM ? NI : 1], Pl2[C::PM ? NI : 1];
+    if constexpr (C::PM) {
+        // everything of step 0 must have landed; step 1 may stay in flight
+        if (total > 1) { PL_WAIT_VM(PPW); } else { PL_WAIT_VM(0); }
+        __builtin_amdgcn_s_barrier();
+        rdA(X, 0, 0);
+        rdA(Y, 0, 1);
+        rdW(Ph, 0, 0);
+        rdW(Pl, 0, 1);
+    } else {
+        PL_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+        rdA(X, 0, 0);
+        rdW(Pl, 0, 1);
+    }
+
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        if constexpr (C::PM) {
+            static_assert(!C::PM || (D == 2 && C::WPS == 1), "product-major form: D = 2, one wave per SIMD");
+            // K steps in pairs (nk is even): step s computes from set 0 / 1 while set 1 / 0 receives step s + 1
+            auto pm_step = [&](int s, u32x4 (&cx)[C::PM ? MI : 1], u32x4 (&cy)[C::PM ? MI : 1], u32x4 (&cph)[C::PM ? NI : 1],
+                               u32x4 (&cpl)[C::PM ? NI : 1], u32x4 (&nx)[C::PM ? MI : 1], u32x4 (&ny)[C::PM ? MI : 1],
+                               u32x4 (&nph)[C::PM ? NI : 1], u32x4 (&npl)[C::PM ? NI : 1]) {
+                const bool more = (DBG & 4) ? false : s + 2 < total;
+                const bool next = s + 1 < total;
+                const int st1 = st + 1 == R ? 0 : st + 1;
+                // step s + 1 has landed (issued one step ago; nothing newer is in flight at this point)
+                if constexpr ((DBG & 1) == 0) PL_WAIT_VM(0);
+                if constexpr ((DBG & 2) == 0) lds_barrier();
+                unsigned koff = 0;
+                const unsigned char *ca = d_a, *cw = d_w;
+                const int cst = d_stage;
+                if (more) koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
+                int slot = 0;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        mfma1(cpl[ni], cx[mi], acc[ni][mi]);
+                        mfma1(cph[ni], cx[mi], acc[ni][mi]);
+                        mfma1(cph[ni], cy[mi], acc[ni][mi]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        // one fragment read of the next step per block (NI * MI >= 2 (NI + MI) slots), one DMA piece per two
+                        if (next) {
+                            if (slot < MI)
+                                nx[slot] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + a_fr + slot * 512);
+                            else if (slot < 2 * MI)
+                                ny[slot - MI] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + a_fr + 2 * TM * 16 + (slot - MI) * 512);
+                            else if (slot < 2 * MI + NI)
+                                nph[slot - 2 * MI] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + w_fr + (slot - 2 * MI) * 512);
+                            else if (slot < 2 * MI + 2 * NI)
+                                npl[slot - 2 * MI - NI] =
+                                    *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + w_fr + 2 * TN * 16 + (slot - 2 * MI - NI) * 512);
+                        }
+                        if (more && (slot & 1) && (slot >> 1) < PPW) {
+                            const int j = slot >> 1;
+                            const unsigned char *src = (p_is_w[j] ? cw : ca) + koff + pv_off[j];
+                            __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + cst * C::STAGE + pl_dst[j]), 16, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        ++slot;
+                    }
+                if (more) {
+                    d_stage = d_stage + 1 == R ? 0 : d_stage + 1;
+                    if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
+                }
+                st = st1;
+            };
+            for (int k = 0; k < nk; k += 2) {
+                pm_step(ti * nk + k, X, Y, Ph, Pl, X2, Y2, Ph2, Pl2);
+                pm_step(ti * nk + k + 1, X2, Y2, Ph2, Pl2, X, Y, Ph, Pl);
+            }
+        } else
+        for (int k = 0; k < nk; ++k) {
+            const int s = ti * nk + k;
+            const bool more = (DBG & 4) ? false : s + D < total;  // wave-uniform
+            const int st1 = st + 1 == R ? 0 : st + 1;
+            // the cursor state is advanced by whichever group issues; pieces are spread over the MFMA gaps
+            unsigned koff = 0;
+            const unsigned char *ca = d_a, *cw = d_w;
+            const int cst = d_stage;
+            if (more) koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
+            auto dma_piece = [&](int j) {
+                if (j < PPW) {
+                    const unsigned char *src = (p_is_w[j] ? cw : ca) + koff + pv_off[j];
+                    __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + cst * C::STAGE + pl_dst[j]), 16, 0,
+                                                     0);
+                }
+            };
+            auto dma_slot = [&](int i) {  // slot i of SLOTS: the pieces are spread over the MFMA gaps of a group
+                if constexpr (PPW <= SLOTS) {
+                    dma_piece(i);
+                } else {
+                    dma_piece(2 * i);
+                    dma_piece(2 * i + 1);
+                }
+            };
+            // G1: W lo . A hi   | after the first MFMA pair: reads W hi, A lo of this step (their wait then sits in front
+            //                     of G2 and the wait in front of G1 covers only the fragments prefetched by the last G3)
+            group(Pl, X, [&](int i) {
+                if (i == 0) {
+                    rdW(Ph, st, 0);
+                    rdA(Y, st, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (more && pair == 0) dma_slot(i);
+            });
+            // G2: W hi . A hi
+            group(Ph, X, [&](int i) {
+                if (more && pair == 1) dma_slot(i);
+            });
+            if (more) {
+                d_stage = d_stage + 1 == R ? 0 : d_stage + 1;
+                if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
+            }
+            // this wave's share of step s + 1 has landed: everything but the pieces of steps s + 2 .. s + D
+            if constexpr ((DBG & 1) == 0) {
+                if (more) {
+                    PL_WAIT_VM((D - 1) * PPW);
+                } else if (D > 2 && s + D - 1 < total) {
+                    PL_WAIT_VM((D - 2) * PPW);
+                } else {
+                    PL_WAIT_VM(0);
+                }
+            }
+            if constexpr ((DBG & 2) == 0) lds_barrier();
+            // G3: W hi . A lo   | reads A hi, W lo of the next step
+            if (s + 1 < total) {
+                rdA(X, st1, 0);
+                rdW(Pl, st1, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            group(Ph, Y, nohook);
+            st = st1;
+        }
+        // ---- epilogue of tile ti -------------------------------------------------------------------------------
+        {
+            const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
+            int64_t bm;
+            int bn;
+            tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            // the epilogue's lane-dependent address arithmetic must not be hoisted out of the tile loop (loop-invariant
+            // code motion would keep dozens of addresses alive across the K loop: spills, and with them a vmcnt(0) in
+            // front of every scratch reload): launder the lane coordinates here
+            int r32 = r32_, hi = hi_;
+            asm volatile("" : "+v"(r32), "+v"(hi));
+            const bool second = p.a_split_n > 0 && bn * TN >= p.a_split_n;
+            const float *ascl = second ? p.a2_scale : p.a_scale;
+            const float ascl_c = second ? p.a2_scale_const : p.a_scale_const;
+            const int n_w0 = bn * TN + wn * (32 * NI);      // first column of this wave
+            const int64_t m_w0 = bm * TM + wm * (32 * MI);  // first row of this wave
+            if constexpr (!SWAP) {
+                // lane = row m_w0 + mi * 32 + r32; run c of block ni: columns n_w0 + ni * 32 + c * 16 + hi * 8 + 0..7
+                // per-row activation scales.  The load is unconditional and branch-free (a dummy address and an
+                // arithmetic select when there is no per-row array): a load on one side of a branch stays "pending" on
+                // the other side for the compiler's waitcnt pass, which then drains vmcnt -- the LDS-DMA ring -- in the K loop
+                float sa[MI];
+                {
+                    const float *abase = ascl ? ascl : p.w_scale;
+                    float has = ascl ? 1.0f : 0.0f;
+                    int64_t mmax = ascl ? p.M - 1 : 0;
+                    asm volatile("" : "+v"(abase), "+v"(has), "+v"(mmax));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int64_t m = m_w0 + mi * 32 + r32;
+                        const float av = abase[m < mmax ? m : mmax];
+                        sa[mi] = ascl_c * (av * has + (1.0f - has));  // exact: av (has = 1) or 1 (has = 0, av finite)
+                    }
+                }
+                if constexpr (EPI == PL_F32) {
+                    float *cb = p.c;
+                    int64_t ldc = p.ldc;
+                    int ncol0 = n_w0;
+                    if (p.c_split_n > 0 && n_w0 >= p.c_split_n) {
+                        cb = p.c2;
+                        ldc = p.ldc2;
+                        ncol0 = n_w0 - p.c_split_n;
+                    }
+                    // Rows are bounded by wave-uniform buffer descriptors (loads of rows >= M return 0, stores are dropped):
+                    // no divergent branch, so every load is waited for on every path -- a load left pending on a skipped
+                    // path would make the compiler drain vmcnt (and with it the LDS-DMA ring) inside the K loop.
+                    int64_t vr64 = p.M - m_w0;
+                    const int vr = vr64 > 32 * MI ? 32 * MI : (vr64 < 0 ? 0 : (int)vr64);
+                    int vc = p.N - n_w0;
+                    if (vc > 32 * NI) vc = 32 * NI;
+                    const auto c_rs = x3_rsrc(cb + m_w0 * ldc + ncol0, vr > 0 && vc > 0 ? ((vr - 1) * (int)ldc + vc) * 4 : 0);
+                    const auto r_rs = x3_rsrc(p.residual ? p.residual + m_w0 * p.ldr + n_w0 : cb,
+                                              p.residual && vr > 0 && vc > 0 ? ((vr - 1) * (int)p.ldr + vc) * 4 : 0);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if (ni * 32 >= vc) break;
+                        f32x4 sw[2][2], bv[2][2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int n = n_w0 + ni * 32 + c * 16 + hi * 8 + h * 4;
+                                sw[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
+                                bv[c][h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            __builtin_amdgcn_sched_barrier(0);  // one block at a time: bounds the live copies of accumulators
+                            const int row = mi * 32 + r32;
+                            const int c_off = (row * (int)ldc + ni * 32 + hi * 8) * 4;
+                            u32x4 res[2][2];
+                            if (p.residual) {
+                                const int r_off = (row * (int)p.ldr + ni * 32 + hi * 8) * 4;
+#pragma unroll
+                                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h)
+                                        res[c][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_off + (c * 16 + h * 4) * 4, 0, 0);
+                            }
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[c][h][e]);
+                                        t += bv[c][h][e];
+                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[c][h][e]);
+                                        v[e] = t;
+                                    }
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs,
+                                                                           c_off + (c * 16 + h * 4) * 4, 0, 0);
+                                }
+                        }
+                    }
+                } else if constexpr (EPI == PL_GEGLU) {
+                    // blocks 2 q / 2 q + 1 = value / gate columns of the same 32 hidden columns
+                    static_assert(NI % 2 == 0, "GEGLU pairs");
+#pragma unroll
+                    for (int q = 0; q < NI / 2; ++q) {
+                        const int n_q0 = n_w0 + q * 64;
+                        if (n_q0 >= p.N) break;
+                        const int jb = n_q0 >> 6;  // hidden k block (32 hidden columns per 64 packed ones)
+                        f32x4 sv[2][2], sg[2][2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int n = n_q0 + c * 16 + hi * 8 + h * 4;
+                                sv[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
+                                sg[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n + 32);
+                            }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int64_t m = m_w0 + mi * 32 + r32;  // rows beyond M: the plane buffers are padded to the tile
+                            unsigned char *blk = p.cp + ((m >> 6) * p.cp_kblocks + jb) * 8192 + (m & 63) * 16;
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                f32x4 va, vb;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float v0 = acc[2 * q][mi][c * 8 + e] * (sa[mi] * sv[c][0][e]);
+                                    const float g0 = acc[2 * q + 1][mi][c * 8 + e] * (sa[mi] * sg[c][0][e]);
+                                    const float v1 = acc[2 * q][mi][c * 8 + 4 + e] * (sa[mi] * sv[c][1][e]);
+                                    const float g1 = acc[2 * q + 1][mi][c * 8 + 4 + e] * (sa[mi] * sg[c][1][e]);
+                                    va[e] = (gelu_erf(g0) * v0) * p.cp_scale;
+                                    vb[e] = (gelu_erf(g1) * v1) * p.cp_scale;
+                                }
+                                const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb, f16x4);
+                                const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
+                                const f16x4 lb = __builtin_convertvector(vb - __builtin_convertvector(hb, f32x4), f16x4);
+                                unsigned char *dst = blk + (c * 2 + hi) * 1024;
+                                *reinterpret_cast<u32x4 *>(dst) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                *reinterpret_cast<u32x4 *>(dst + 4096) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        zero_acc();
+    }
+    if (p.cycles && blockIdx.x == 0 && tid == 0) {
+        p.cycles[0] = __builtin_amdgcn_s_memtime() - t_start;
+    }
+}
+
+}  // namespace omnitok

@@ -1,0 +1,214 @@
+// Launchers and operand packers of the plane x plane GEMM (gemm_pl.h).
+#include "gemm_pl.h"
+
+namespace omnitok {
+
+extern int g_gemm_gn;
+int g_pl_cfg = 0;  // "pl_cfg": 0 auto | 1 256x256 (8 waves, 1 workgroup per CU) | 2 128(n)x256(m) (4 waves, 2 per CU)
+
+// ---- weight rows -> scaled fp16 planes, rows permuted inside groups of 32 (pl_perm) ------------------------------
+// w' = w * 2^(14 - x) with max|w_n| = m 2^x (m in [0.5, 1)); scale[n] = 2^(x - 14) (by LOGICAL row).  Rows beyond N up
+// to n_pad are zero.  One wave per physical row.
+__global__ __launch_bounds__(256) void pl_pack_weight_kernel(const float *__restrict__ w, int64_t ldw, int N, int K, int n_pad,
+                                                             _Float16 *__restrict__ out, float *__restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int prow = blockIdx.x * 4 + (threadIdx.x >> 6);  // physical row
+    if (prow >= n_pad) return;
+    const int n = (prow & ~31) + pl_perm(prow & 31);       // logical row stored here
+    if (n >= N) {
+        for (int k = lane; k < K; k += 64) {
+            out[pl_offset(prow, k, 0, K)] = (_Float16)0.0f;
+            out[pl_offset(prow, k, 1, K)] = (_Float16)0.0f;
+        }
+        return;
+    }
+    const float *wr = w + (int64_t)n * ldw;
+    float mx = 0.0f;
+    for (int k = lane; k < K; k += 64) mx = fmaxf(mx, fabsf(wr[k]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int x = 14;
+    if (mx > 0.0f && mx < 3.0e38f) (void)frexpf(mx, &x);
+    const float s = ldexpf(1.0f, 14 - x);
+    if (lane == 0) scale[n] = ldexpf(1.0f, x - 14);
+    for (int k = lane; k < K; k += 64) {
+        const float v = wr[k] * s;
+        const _Float16 h = (_Float16)v;
+        const _Float16 l = (_Float16)(v - (float)h);
+        out[pl_offset(prow, k, 0, K)] = h;
+        out[pl_offset(prow, k, 1, K)] = l;
+    }
+}
+
+// ---- activation rows -> planes (not permuted), one power-of-two scale per row or one static scale -----------------
+// a' = a * s, s = 2^-e with bound * s in (2^14, 2^15]; a_scale[m] = 1 / s.  Rows [M, m_pad) are zero.
+// Workgroup = 64 rows; thread (row = t >> 2, q = t & 3) owns k group q of every 32-k block.
+__global__ __launch_bounds__(256) void pl_pack_rows_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int K,
+                                                           unsigned char *__restrict__ planes, float *__restrict__ a_scale,
+                                                           float static_bound) {
+    const int t = threadIdx.x, row = t >> 2, q = t & 3;
+    const int64_t m = (int64_t)blockIdx.x * 64 + row;
+    const bool live = m < M;
+    const float *xr = x + (live ? m : 0) * ldx;
+    float s;
+    if (static_bound > 0.0f) {
+        s = h2_scale_of_bound(static_bound);
+    } else {
+        float mx = 0.0f;
+        if (live)
+            for (int k = q * 8; k < K; k += 32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(xr + k), v1 = *reinterpret_cast<const f32x4 *>(xr + k + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mx = fmaxf(mx, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 1));
+        mx = fmaxf(mx, __shfl_xor(mx, 2));
+        s = h2_scale_of_bound(mx);
+    }
+    if (a_scale && q == 0 && live) a_scale[m] = 1.0f / s;
+    const int kblocks = K >> 5;
+    unsigned char *blk = planes + (int64_t)blockIdx.x * kblocks * 8192 + q * 1024 + row * 16;
+    for (int kb = 0; kb < kblocks; ++kb) {
+        f32x4 v0 = f32x4{0, 0, 0, 0}, v1 = v0;
+        if (live) {
+            v0 = *reinterpret_cast<const f32x4 *>(xr + kb * 32 + q * 8);
+            v1 = *reinterpret_cast<const f32x4 *>(xr + kb * 32 + q * 8 + 4);
+        }
+        v0 *= s;
+        v1 *= s;
+        const f16x4 h0 = __builtin_convertvector(v0, f16x4), h1 = __builtin_convertvector(v1, f16x4);
+        const f16x4 l0 = __builtin_convertvector(v0 - __builtin_convertvector(h0, f32x4), f16x4);
+        const f16x4 l1 = __builtin_convertvector(v1 - __builtin_convertvector(h1, f32x4), f16x4);
+        *reinterpret_cast<u32x4 *>(blk + (int64_t)kb * 8192) =
+            __builtin_bit_cast(u32x4, __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7));
+        *reinterpret_cast<u32x4 *>(blk + (int64_t)kb * 8192 + 4096) =
+            __builtin_bit_cast(u32x4, __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7));
+    }
+}
+
+template <int EPI, bool SWAP, typename C>
+static int launch_pl_cfg(PlParams p, hipStream_t stream) {
+    int n_cu = 0;
+    if (int rc = current_device_cus(&n_cu)) return rc;
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), C::LDS)) return rc;
+    const int64_t nbm = (p.M + C::TM - 1) / C::TM;
+    const int nbn = (p.N + C::TN - 1) / C::TN;
+    const int64_t nt = nbm * nbn;
+    OT_CHECK_ARG(nt < (1ll << 31), "gemm_pl: grid too large");
+    p.nbm = (int)nbm;
+    p.nbn = nbn;
+    p.ntiles = (int)nt;
+    p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
+    int wg_per_cu = (160 * 1024) / C::LDS;
+    const int by_waves = (C::NI * C::MI > 8) ? 1 : 8 / C::NW;
+    if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    // two small workgroups per CU: one tile each (the hardware dispatcher overlaps one's epilogue with the other's K loop);
+    // one big workgroup per CU: persistent
+    const int64_t cap = wg_per_cu > 1 ? nt : (int64_t)n_cu;
+    const int grid = (int)(nt < cap ? nt : cap);
+    hipLaunchKernelGGL((gemm_pl_kernel<EPI, SWAP, C>), dim3(grid), dim3(C::NT), C::LDS, stream, p);
+    OT_LAUNCH_CHECK("gemm_pl");
+    return OMNITOK_OK;
+}
+
+template <int EPI>
+static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
+    switch (cfg) {
+        case 2: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3>>(p, stream);
+        case 3: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3>>(p, stream);
+        case 4: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 4>>(p, stream);   // 4 waves x (128 x 128), one per SIMD
+        case 5: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 3, 0, 4, 4>>(p, stream);
+        case 6: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3, 2, 0, 4, 4, 1>>(p, stream);   // product-major order
+        case 18: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3, 2, 4, 4, 4, 1>>(p, stream);  // ... without DMA
+        case 14: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 4, 4>>(p, stream);  // no DMA
+        case 16: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 7, 4, 4>>(p, stream);  // no DMA, barrier, wait
+        case 11: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 1>>(p, stream);   // measurement builds
+        case 13: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 3>>(p, stream);
+        case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
+        case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
+        default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+    }
+}
+
+}  // namespace omnitok
+
+using namespace omnitok;
+
+extern "C" int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad) {
+    if (rows < 0 || K <= 0 || K % 32 || row_pad <= 0 || row_pad % 64) return -1;
+    const int64_t rp = (rows + row_pad - 1) / row_pad * row_pad;
+    return rp * K * 4;
+}
+
+extern "C" int omnitok_pl_pack_weight(const float *w, int64_t ldw, int N, int K, int n_pad, void *planes, float *scale,
+                                      omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(w && planes && scale && N > 0 && K > 0 && K % 32 == 0 && n_pad >= N && n_pad % 64 == 0 && N % 32 == 0,
+                 "pl_pack_weight: bad arguments (K %% 32, N %% 32, n_pad %% 64)");
+    hipLaunchKernelGGL(pl_pack_weight_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, w, ldw, N, K, n_pad,
+                       static_cast<_Float16 *>(planes), scale);
+    OT_LAUNCH_CHECK("pl_pack_weight");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_pl_pack_rows(const float *x, int64_t ldx, int64_t M, int K, int64_t m_pad, void *planes, float *a_scale,
+                                    float static_bound, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && planes && M >= 0 && K > 0 && K % 32 == 0 && m_pad >= M && m_pad % 64 == 0 && ldx % 4 == 0 && aligned16(x) &&
+                     (a_scale || static_bound > 0.0f),
+                 "pl_pack_rows: bad arguments");
+    if (m_pad == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(pl_pack_rows_kernel, dim3((unsigned)(m_pad / 64)), dim3(256), 0, stream, x, ldx, M, K,
+                       static_cast<unsigned char *>(planes), a_scale, static_bound);
+    OT_LAUNCH_CHECK("pl_pack_rows");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(g && g->a && g->w && g->w_scale, "gemm_pl: null pointer");
+    OT_CHECK_ARG(g->M >= 0 && g->N > 0 && g->K >= 32 && g->K % 32 == 0 && g->N % 32 == 0, "gemm_pl: bad sizes M=%lld N=%d K=%d",
+                 (long long)g->M, g->N, g->K);
+    if (g->M == 0) return OMNITOK_OK;
+    PlParams p{};
+    p.a = static_cast<const unsigned char *>(g->a);
+    p.a2 = static_cast<const unsigned char *>(g->a2);
+    p.a_scale = g->a_scale;
+    p.a2_scale = g->a2_scale;
+    p.a_scale_const = g->a_scale_const > 0.0f ? g->a_scale_const : 1.0f;
+    p.a2_scale_const = g->a2_scale_const > 0.0f ? g->a2_scale_const : 1.0f;
+    p.a_split_n = g->a2 ? g->a_split_n : 0;
+    p.w = static_cast<const unsigned char *>(g->w);
+    p.w_scale = g->w_scale;
+    p.bias = g->bias;
+    p.residual = g->residual;
+    p.ldr = g->ldr;
+    p.c = g->c;
+    p.ldc = g->ldc;
+    p.c2 = g->c2;
+    p.ldc2 = g->ldc2;
+    p.c_split_n = g->c2 ? g->c_split_n : 0;
+    p.cp = static_cast<unsigned char *>(g->out_planes);
+    p.cp_kblocks = g->out_planes_k / 32;
+    p.cp_scale = g->out_bound > 0.0f ? h2_scale_of_bound(g->out_bound) : 1.0f;
+    p.M = g->M;
+    p.N = g->N;
+    p.K = g->K;
+    p.cycles = g->debug_cycles;
+    const int cfg = g->cfg > 0 ? g->cfg : (g_pl_cfg > 0 ? g_pl_cfg : 1);
+    OT_CHECK_ARG(p.a_split_n % 256 == 0 && p.c_split_n % 256 == 0, "gemm_pl: split columns must be multiples of 256");
+    switch (g->epilogue) {
+        case PL_F32:
+            OT_CHECK_ARG(g->c && g->ldc % 4 == 0 && aligned16(g->c) && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))),
+                         "gemm_pl: fp32 output must be 16-byte aligned with ldc %% 4 == 0");
+            return launch_pl<PL_F32>(p, cfg, stream);
+        case PL_GEGLU:
+            OT_CHECK_ARG(g->out_planes && g->N % 64 == 0 && g->out_planes_k == g->N / 2 && g->out_bound > 0.0f,
+                         "gemm_pl: GEGLU needs out_planes with out_planes_k == N / 2 and a bound of the hidden");
+            return launch_pl<PL_GEGLU>(p, cfg, stream);
+        default:
+            set_error("gemm_pl: unsupported epilogue %d", g->epilogue);
+            return OMNITOK_ERR_INVALID;
+    }
+}
