@@ -192,16 +192,21 @@ typedef struct omnitok_pl_gemm {
     float *c2;                  /* optional: columns >= c_split_n go to c2[m, n - c_split_n]                    */
     int64_t ldc2;
     int c_split_n;
-    void *out_planes;           /* epilogue 1 (GEGLU): hidden planes, K = out_planes_k = N / 2                  */
-    int out_planes_k;
-    float out_bound;            /* >= max |hidden|: the consumer uses a_scale_const = 1 / h2 scale of it        */
-    int epilogue;               /* 0 fp32 | 1 GEGLU -> planes                                                   */
+    void *out_planes;           /* epilogue 1 (GEGLU): hidden planes, K = out_planes_k = N / 2;                 */
+    int out_planes_k;           /* epilogue 2: LayerNorm(c) planes, out_planes_k = N                            */
+    float out_bound;            /* >= max |plane values|: the consumer uses a_scale_const = omnitok_pl_unscale() */
+    const float *ln_gamma;      /* epilogue 2: LayerNorm over the N output columns (two-pass statistics)        */
+    const float *ln_beta;       /* or NULL                                                                      */
+    float ln_eps;
+    int epilogue;               /* 0 fp32 | 1 GEGLU -> planes | 2 fp32 AND LayerNorm -> planes (N == 512)       */
     int64_t M;
     int N, K;
     int cfg;                    /* 0 auto | 1 256x256 tiles, one workgroup per CU | 2 128x256, two per CU        */
     long long *debug_cycles;    /* measurement: shader-clock span of workgroup 0 (NULL = off)                   */
 } omnitok_pl_gemm;
 int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad);
+/* the factor that undoes the power-of-two scale derived from a static bound (a_scale_const of the consumer) */
+float omnitok_pl_unscale(float bound);
 int omnitok_pl_pack_weight(const float *w, int64_t ldw, int N, int K, int n_pad, void *planes, float *scale,
                            omnitok_stream_t stream);
 /* x[M, ldx] fp32 -> planes (m_pad rows, rows >= M zero); per-row scales into a_scale, or one static scale from
@@ -304,6 +309,13 @@ int omnitok_attn_spatial_h2(const void *qp, const void *kp, const void *vp, floa
                             int heads, float q_bound, float k_bound, float v_bound, const float *v_bound_dev,
                             int v_bound_stride, int seq_per_clip, const float *bias_table, int gh, int gw,
                             omnitok_stream_t stream);
+/* The same kernel with the output written as fp16 hi|lo planes (out_planes != NULL; the A operand of the to_out GEMM,
+ * omnitok_gemm_pl, K = heads * 64) instead of fp32 rows: scaled per clip by the power of two of the V bound (the
+ * output is a convex combination of V rows), out_scale[row] receives the factor that undoes it. */
+int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, const void *vp, float *out, int64_t ldo,
+                                   void *out_planes, float *out_scale, int Bn, int N, int heads, float q_bound,
+                                   float k_bound, float v_bound, const float *v_bound_dev, int v_bound_stride,
+                                   int seq_per_clip, const float *bias_table, int gh, int gw, omnitok_stream_t stream);
 
 /* WindowAttention core (reference attention.py:266-286): qkv[Bn*N, 3*heads*64] from LN(x),
  * ws x ws (ws = 8) non-overlapping windows of the gh x gw grid, softmax(0.125 q k^T + bias) v.
@@ -311,6 +323,11 @@ int omnitok_attn_spatial_h2(const void *qp, const void *kp, const void *vp, floa
  * relative_position_index (attention.py:277-281), transposed. out[Bn*N, heads*64]. */
 int omnitok_attn_window(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out,
                         int64_t ldo, int Bn, int gh, int gw, int heads, omnitok_stream_t stream);
+/* ... with the output as fp16 hi|lo planes (out_planes != NULL) scaled by the power of two of the static bound
+ * out_bound >= max |output|; the consuming omnitok_gemm_pl takes a_scale_const = omnitok_pl_unscale(out_bound). */
+int omnitok_attn_window_planes(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out, int64_t ldo,
+                               void *out_planes, float out_bound, int Bn, int gh, int gw, int heads,
+                               omnitok_stream_t stream);
 
 /* Temporal attention (reference attention.py:402-486 with is_spatial=False): per (column, head)
  * T tokens; l2norm, q/k scales and scale applied inside. causal: is_causal / causal mask;
@@ -319,6 +336,13 @@ int omnitok_attn_temporal(const float *q, int64_t ldq, const float *k, const flo
                           int64_t ldkv, float *out, int64_t ldo, int64_t cols, int T, int heads,
                           const float *q_scale, const float *k_scale, float scale, int causal,
                           const float *alibi_slopes, omnitok_stream_t stream);
+/* ... with the output as fp16 hi|lo planes (out_planes != NULL; T <= 17, cols % 16 == 0), scaled per clip by the power
+ * of two of v_bound (x v_bound_dev[v_bound_stride * (col / cols_per_clip)]) >= max |v|; out_scale[row] = the inverse. */
+int omnitok_attn_temporal_planes(const float *q, int64_t ldq, const float *k, const float *v, int64_t ldkv,
+                                 float *out, int64_t ldo, void *out_planes, float *out_scale, float v_bound,
+                                 const float *v_bound_dev, int v_bound_stride, int64_t cols_per_clip, int64_t cols,
+                                 int T, int heads, const float *q_scale, const float *k_scale, float scale,
+                                 int causal, const float *alibi_slopes, omnitok_stream_t stream);
 
 /* z[n, 0:cdim] = l2norm(x[n, :] . w[cdim, D]^T + b)   (reference omnitokenizer.py:143-148 +
  * F.normalize :251-252; normalize skipped if l2 == 0).  cdim == 8, D % 64 == 0. */

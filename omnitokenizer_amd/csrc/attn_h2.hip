@@ -30,6 +30,7 @@
 // so that every fragment is one conflict-free ds_read_b128 per lane (lanes 0-31 and 32-63 read two contiguous
 // 512-byte runs) and a K/V tile is staged by a linear copy.
 #include "h2_common.h"
+#include "planes.h"
 
 namespace omnitok {
 
@@ -152,6 +153,10 @@ struct AttnH2Params {
     float v_bound; const float *v_bound_dev; int v_bound_stride; int seq_per_clip;
     const float *bias_table;  // [(2gh-1)*(2gw-1), heads] or null
     int gh, gw;
+    // optional: the output as fp16 hi|lo planes, the A operand of the to_out GEMM (gemm_pl.h), instead of fp32 rows;
+    // scaled per clip by the power of two of the V bound (|O| <= max |V|), whose inverse goes to out_scale[row]
+    unsigned char *out_planes;
+    float *out_scale;
 };
 
 template <bool HAS_BIAS>
@@ -309,6 +314,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2_kernel(AttnH2Params p)
     float bound = p.v_bound;
     if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
     const float inv_l = 1.0f / (l_run * h2_scale_of_bound(bound));  // the scale is a power of two: exact
+    if (p.out_planes) {
+        const float so = h2_scale_of_bound(bound);
+        const int64_t row = (int64_t)seq * p.N + q_local;
+        if (head == 0 && hi == 0) p.out_scale[row] = 1.0f / so;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) pl_store_ot_block(ot[d], inv_l * so, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+        return;
+    }
     float *orow = p.out + ((int64_t)seq * p.N + q_local) * p.ldo + head * 64;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -502,6 +515,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2p_kernel(AttnH2Params p
     float bound = p.v_bound;
     if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
     const float inv_l = 1.0f / (l_run * h2_scale_of_bound(bound));
+    if (p.out_planes) {
+        const float so = h2_scale_of_bound(bound);
+        const int64_t row = (int64_t)seq * p.N + q_local;
+        if (head == 0 && hi == 0) p.out_scale[row] = 1.0f / so;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) pl_store_ot_block(ot[d], inv_l * so, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+        return;
+    }
     float *orow = p.out + ((int64_t)seq * p.N + q_local) * p.ldo + head * 64;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -559,11 +580,21 @@ extern "C" int omnitok_attn_spatial_h2(const void *qp, const void *kp, const voi
                                        int N, int heads, float q_bound, float k_bound, float v_bound,
                                        const float *v_bound_dev, int v_bound_stride, int seq_per_clip,
                                        const float *bias_table, int gh, int gw, omnitok_stream_t stream_) {
+    return omnitok_attn_spatial_h2_planes(qp, kp, vp, out, ldo, nullptr, nullptr, Bn, N, heads, q_bound, k_bound, v_bound,
+                                          v_bound_dev, v_bound_stride, seq_per_clip, bias_table, gh, gw, stream_);
+}
+
+extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, const void *vp, float *out, int64_t ldo,
+                                              void *out_planes, float *out_scale, int Bn, int N, int heads, float q_bound,
+                                              float k_bound, float v_bound, const float *v_bound_dev, int v_bound_stride,
+                                              int seq_per_clip, const float *bias_table, int gh, int gw,
+                                              omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(qp && kp && vp && out, "attn_spatial_h2: null pointer");
+    OT_CHECK_ARG(qp && kp && vp && (out || out_planes), "attn_spatial_h2: null pointer");
+    OT_CHECK_ARG(!out_planes || (out_scale && aligned16(out_planes)), "attn_spatial_h2: plane output needs out_scale");
     OT_CHECK_ARG(N % 64 == 0 && N > 0, "attn_spatial_h2: N=%d must be a multiple of 64 tokens", N);
     OT_CHECK_ARG(!bias_table || gh * gw == N, "attn_spatial_h2: bias grid %dx%d != N=%d", gh, gw, N);
-    OT_CHECK_ARG(ldo % 4 == 0 && aligned16(qp) && aligned16(kp) && aligned16(vp) && aligned16(out),
+    OT_CHECK_ARG((out_planes || ldo % 4 == 0) && aligned16(qp) && aligned16(kp) && aligned16(vp) && (!out || aligned16(out)),
                  "attn_spatial_h2: unaligned");
     OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && v_bound > 0.0f, "attn_spatial_h2: operand bounds must be positive");
     OT_CHECK_ARG(!v_bound_dev || seq_per_clip > 0, "attn_spatial_h2: seq_per_clip");
@@ -577,6 +608,7 @@ extern "C" int omnitok_attn_spatial_h2(const void *qp, const void *kp, const voi
     p.v_bound = v_bound; p.v_bound_dev = v_bound_dev; p.v_bound_stride = v_bound_stride;
     p.seq_per_clip = v_bound_dev ? seq_per_clip : (Bn > 0 ? Bn : 1);
     p.bias_table = bias_table; p.gh = gh; p.gw = gw;
+    p.out_planes = static_cast<unsigned char *>(out_planes); p.out_scale = out_scale;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2_kernel<false>), AH_LDS_BYTES)) return rc;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2_kernel<true>), AH_LDS_BYTES)) return rc;
     p.nqb = (N + 127) / 128;

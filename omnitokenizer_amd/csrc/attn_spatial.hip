@@ -18,6 +18,8 @@
 // pixels 1e-4) does not survive bf16 (SURVEY.md section 7 "Hard parts").
 #include "common.h"
 
+#include "planes.h"
+
 namespace omnitok {
 
 // exp(x) for x <= 0 as one multiply-add and one v_exp_f32 (1 ulp): on gfx950 every VALU instruction
@@ -246,6 +248,9 @@ struct WinParams {
     const float *bias_dense;  // [heads][64 kv][64 q]
     float *out; int64_t ldo;
     int gh, gw, heads, nwin_x, nwin;  // windows per row / per image
+    // optional plane output (A operand of the proj GEMM, gemm_pl.h) with one static power-of-two scale
+    unsigned char *out_planes;
+    float out_mul;  // h2 scale of the static bound of |attention output|
 };
 
 __device__ __forceinline__ int win_token(int wy, int wx, int idx, int gw) {
@@ -344,6 +349,16 @@ __global__ __launch_bounds__(256, 2) void attn_window_kernel(WinParams p, int64_
                 ot[1][qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, st[kb][qb][r], ot[1][qb], 0, 0, 0);
             }
         }
+    if (p.out_planes) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const int64_t row = row0 + win_token(wy, wx, qb * 32 + r32, p.gw);
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+                pl_store_ot_block(ot[d][qb], inv_l[qb] * p.out_mul, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+        }
+        return;
+    }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int tok = win_token(wy, wx, qb * 32 + r32, p.gw);
@@ -411,13 +426,24 @@ extern "C" int omnitok_attn_spatial(const float *q, int64_t ldq, const float *k,
 
 extern "C" int omnitok_attn_window(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out,
                                    int64_t ldo, int Bn, int gh, int gw, int heads, omnitok_stream_t stream_) {
+    return omnitok_attn_window_planes(qkv, ldqkv, bias_dense, out, ldo, nullptr, 0.0f, Bn, gh, gw, heads, stream_);
+}
+
+// out_planes != NULL: the output goes to fp16 hi|lo planes (K = heads * 64; the A operand of the proj GEMM, gemm_pl.h)
+// scaled by the power of two of out_bound (>= max |output|; the consumer's a_scale_const = omnitok_pl_unscale(out_bound))
+extern "C" int omnitok_attn_window_planes(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out,
+                                          int64_t ldo, void *out_planes, float out_bound, int Bn, int gh, int gw,
+                                          int heads, omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(qkv && bias_dense && out, "attn_window: null pointer");
+    OT_CHECK_ARG(qkv && bias_dense && (out || out_planes), "attn_window: null pointer");
     OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "attn_window: grid %dx%d not divisible by the 8x8 window", gh, gw);
-    OT_CHECK_ARG(ldqkv % 4 == 0 && ldo % 4 == 0 && aligned16(qkv) && aligned16(out), "attn_window: unaligned");
+    OT_CHECK_ARG(ldqkv % 4 == 0 && (out_planes || ldo % 4 == 0) && aligned16(qkv) && (!out || aligned16(out)), "attn_window: unaligned");
+    OT_CHECK_ARG(!out_planes || (out_bound > 0.0f && aligned16(out_planes)), "attn_window: plane output needs a bound");
     WinParams p;
     p.qkv = qkv; p.ldqkv = ldqkv; p.bias_dense = bias_dense; p.out = out; p.ldo = ldo;
     p.gh = gh; p.gw = gw; p.heads = heads; p.nwin_x = gw / 8; p.nwin = (gh / 8) * (gw / 8);
+    p.out_planes = static_cast<unsigned char *>(out_planes);
+    p.out_mul = out_planes ? h2_scale_of_bound(out_bound) : 1.0f;
     const int64_t total = (int64_t)Bn * p.nwin * heads;
     if (total == 0) return OMNITOK_OK;
     hipLaunchKernelGGL(attn_window_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, total);

@@ -65,6 +65,8 @@ extern int g_gemm_mode;
 extern int g_attn_mode;
 extern int g_attn_h2_variant;
 extern int g_attn_vpack;
+extern int g_gemm_pl;
+extern int g_pl_cfg;
 extern int g_lm_wide_u;
 }  // namespace omnitok
 
@@ -80,6 +82,8 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "attn_mode")) omnitok::g_attn_mode = value;
     else if (!strcmp(name, "attn_h2_variant")) omnitok::g_attn_h2_variant = value;
     else if (!strcmp(name, "attn_vpack")) omnitok::g_attn_vpack = value;
+    else if (!strcmp(name, "gemm_pl")) omnitok::g_gemm_pl = value;
+    else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
     else if (!strcmp(name, "lm_wide_u")) omnitok::g_lm_wide_u = value;
     else if (!strcmp(name, "h2_dbg")) omnitok::g_h2_dbg = value;
     else if (!strcmp(name, "h2_tile")) omnitok::g_h2_tile = value;

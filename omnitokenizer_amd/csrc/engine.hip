@@ -121,6 +121,7 @@ struct omnitok_engine {
     int64_t ext_ws_bytes = 0;
     // fp16-split GEMM (gemm_mode 2): packed weights by fp32 weight pointer, device-side range slots
     std::map<const float *, H2W> h2w;
+    std::map<const float *, H2W> plw;  // ... packed for the plane x plane GEMM (gemm_pl.h: rows permuted, padded to 256)
     float pe_bound[2] = {0.0f, 0.0f};
     float *bounds = nullptr;  // [launch][clip][2] range slots, zeroed at the start of every encode / decode
     int bound_next = 0, bound_clips = 0, bound_cap = 0;
@@ -359,6 +360,21 @@ static int pack_h2(omnitok_engine *e, const float *w, int64_t ld, int N, int K, 
     return OMNITOK_OK;
 }
 
+// pack a GEMM weight for gemm_pl (the activation operand arrives as planes written by its producer)
+static int pack_pl(omnitok_engine *e, const float *w, int64_t ld, int N, int K, hipStream_t stream) {
+    if (!w || N % 32 || K % 32 || ld != K) return OMNITOK_OK;
+    const int n_pad = (N + 255) / 256 * 256;
+    float *pl, *sc;
+    if (int rc = alloc_f(e, &pl, (int64_t)n_pad * K)) return rc;
+    if (int rc = alloc_f(e, &sc, N)) return rc;
+    if (int rc = omnitok_pl_pack_weight(w, ld, N, K, n_pad, pl, sc, stream)) return rc;
+    H2W h;
+    h.pl = pl;
+    h.sc = sc;
+    e->plw[w] = h;
+    return OMNITOK_OK;
+}
+
 static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &prefix, const std::string &block,
                              bool spatial, hipStream_t stream) {
     const omnitok_config &c = e->cfg;
@@ -395,6 +411,7 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
                 }
             }
             if (int rc = pack_h2(e, L.t.wo, c.dim, c.dim, c.dim, stream)) return rc;
+            if (int rc = pack_pl(e, L.t.wo, c.dim, c.dim, c.dim, stream)) return rc;
             if (int rc = ln_range(e, L.t.ng, L.t.nb, c.dim, &L.t.ln_bound, nullptr, stream)) return rc;
             if (int rc = weight_range(e, L.t.wkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &L.t.vnorm, nullptr, stream))
                 return rc;
@@ -428,6 +445,7 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
             L.w.bias_dense = dense;
             if (int rc = pack_h2(e, L.w.wqkv, c.dim, 3 * c.dim, c.dim, stream)) return rc;
             if (int rc = pack_h2(e, L.w.wproj, c.dim, c.dim, c.dim, stream)) return rc;
+            if (int rc = pack_pl(e, L.w.wproj, c.dim, c.dim, c.dim, stream)) return rc;
             {
                 float l2 = 0, vn = 0;
                 if (int rc = ln_range(e, L.w.ng, L.w.nb, c.dim, &L.w.ln_bound, &l2, stream)) return rc;
@@ -454,6 +472,8 @@ static int build_transformer(omnitok_engine *e, TransformerW &tw, const std::str
         L.ff.w2p = w2p;
         if (int rc = pack_h2(e, w1p, c.dim, 2 * e->inner_pad, c.dim, stream)) return rc;
         if (int rc = pack_h2(e, w2p, e->inner_pad, c.dim, e->inner_pad, stream)) return rc;
+        if (int rc = pack_pl(e, w1p, c.dim, 2 * e->inner_pad, c.dim, stream)) return rc;
+        if (int rc = pack_pl(e, w2p, e->inner_pad, c.dim, e->inner_pad, stream)) return rc;
         {
             float l2 = 0, wn = 0;
             if (int rc = ln_range(e, L.ff.lw, L.ff.lb, c.dim, &L.ff.ln_bound, &l2, stream)) return rc;
@@ -650,6 +670,11 @@ int g_gemm_mode = 2;
 int g_attn_mode = 1;
 // "attn_vpack" 1 (default): the merged q|k|v launch writes V straight into the attention kernel's fp16 planes
 int g_attn_vpack = 1;
+// "gemm_pl" 1 (default): to_out / proj, FF-in and FF-out run as plane x plane GEMMs (gemm_pl.h) whose activation operands
+// are written as fp16 hi|lo planes by their producers (attention kernels, the LayerNorm epilogue of to_out, the GEGLU
+// epilogue of FF-in): no row-statistics pass and no in-loop LayerNorm / split in front of the FeedForward.  0: the
+// r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
+int g_gemm_pl = 1;
 
 static bool x3_ok(int N, int K, int flags) {
     return g_gemm_mode >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
@@ -697,6 +722,18 @@ static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *
     return omnitok_gemm(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff, stream);
 }
 
+// plane x plane GEMM of the engine: the weight is looked up by its fp32 pointer
+static int eg_gemm_pl(omnitok_engine *e, omnitok_pl_gemm g, const float *w, hipStream_t stream) {
+    auto it = e->plw.find(w);
+    if (it == e->plw.end()) {
+        set_error("eg_gemm_pl: weight was not packed for the plane GEMM");
+        return OMNITOK_ERR_STATE;
+    }
+    g.w = it->second.pl;
+    g.w_scale = it->second.sc;
+    return omnitok_gemm_pl(&g, stream);
+}
+
 // One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
 // Pooling blocks shrink the token grid (attention.py:683-684): *ghp / *gwp are updated.
 // transpose_out: the final LayerNorm stores its rows in the OTHER stage's token order ('(b t)(h w)' <-> '(b h w) t'),
@@ -711,7 +748,45 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
     double gemm_f = 2.0 * (double)L * D;
     // split-operand GEMMs apply the LayerNorm while staging their A operand (no LN pass over HBM)
     const bool fused = x3_ok(3 * D, D, 0) && D <= 512;
+    // Plane data flow (gemm_pl.h): attention output -> planes (AO) -> to_out / proj with the residual add and the
+    // FeedForward's LayerNorm in its epilogue (x in place, LN(x) planes -> Y) -> FF-in with the GEGLU hidden as planes
+    // (HD) -> FF-out (+ residual).  Needs full-row tiles for the LayerNorm epilogue (dim 512 = the reference's only width).
+    const bool pl = g_gemm_pl && g_gemm_mode == 2 && fused && D == 512 && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    bool ln_planes_ready = false;  // Y holds the planes of the FeedForward's LayerNorm(x) for the current x
+    // producers that cannot write planes themselves: fp32 rows -> planes with one power-of-two scale per row
+    auto pack_rows = [&](const float *src, void *planes, float *scales) -> int {
+        const int64_t Lp = (L + 255) / 256 * 256;
+        OT_RUN("pack_rows", 2.0 * L * D * 4.0, omnitok_pl_pack_rows(src, D, L, D, Lp, planes, scales, 0.0f, stream));
+        return OMNITOK_OK;
+    };
+    // to_out / proj as a plane GEMM: x += a . w^T (+ bias), and the planes of LN_ff(x) -> Y
+    auto gemm_out_pl = [&](const Layer &ly, const void *a_planes, const float *a_scale, float a_const, const float *w,
+                           const float *bias) -> int {
+        omnitok_pl_gemm g{};
+        g.a = a_planes;
+        g.a_scale = a_scale;
+        g.a_scale_const = a_const;
+        g.bias = bias;
+        g.residual = e->X.p;
+        g.ldr = D;
+        g.c = e->X.p;
+        g.ldc = D;
+        g.out_planes = e->Y.p;
+        g.out_planes_k = D;
+        g.out_bound = ly.ff.ln_bound;
+        g.ln_gamma = ly.ff.lw;
+        g.ln_beta = ly.ff.lb;
+        g.ln_eps = 1e-5f;
+        g.epilogue = 2;
+        g.M = L;
+        g.N = D;
+        g.K = D;
+        OT_RUN("gemm_out", gemm_f * D, eg_gemm_pl(e, g, w, stream));
+        ln_planes_ready = true;
+        return OMNITOK_OK;
+    };
     for (const Layer &ly : tw.layers) {
+        ln_planes_ready = false;
         if (ly.kind == 'a' || ly.kind == 'm' || ly.kind == 'l') {
             // Pooling (reference attention.py:83-113), no residual (:674); then FF (+residual) on the
             // quarter-size sequence
@@ -785,6 +860,11 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 OT_RUN("gemm_qkv", gemm_f * D,
                        eg_gemm(e, e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D, 0, 0,
                                0, 0, stream, ab_x));
+                if (pl) {
+                    if (int rc = pack_rows(e->AO.p, e->QKV.p, e->ST.p)) return rc;
+                    if (int rc = gemm_out_pl(ly, e->QKV.p, e->ST.p, 1.0f, ly.t.wo, nullptr)) return rc;
+                    goto feed_forward;
+                }
                 OT_RUN("gemm_out", gemm_f * D,
                        eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
                                0, 0, 0, stream, ab_ao));
@@ -802,6 +882,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             unsigned char *vp = kp + (size_t)L * D * 4;
             const VPack vpk{vp, 2 * D, S, heads, ab_ao.stat, ab_ao.dev};
             bool vpacked = false;  // the q|k|v launch wrote the V planes itself (no fp32 V round trip)
+            bool ao_planes = false;  // the attention kernel wrote its output as planes (AO) with row scales (ST)
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
             if (fused && D % 256 == 0) {
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
@@ -843,8 +924,10 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                                              ly.t.q_scale, ly.t.k_scale, 8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp,
                                              vpacked ? nullptr : vp, stream));
                     OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
-                           omnitok_attn_spatial_h2(qp, kp, vp, e->AO.p, D, B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev,
-                                                   2, T, bias, gh, gw, stream));
+                           omnitok_attn_spatial_h2_planes(qp, kp, vp, e->AO.p, D, pl ? e->AO.p : nullptr, pl ? e->ST.p : nullptr,
+                                                          B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev, 2, T, bias, gh, gw,
+                                                          stream));
+                    ao_planes = pl;
                 } else {
                     OT_RUN("qk_prep", 4.0 * L * D * 4.0,
                            omnitok_qk_prep(Q, ldq, KV, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
@@ -855,9 +938,22 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 }
             } else {
                 const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
+                const bool tp = pl && bs && T <= 17 && S % 16 == 0;
                 OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
-                       omnitok_attn_temporal(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, (int64_t)B * S, T, heads,
-                                             ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi, stream));
+                       omnitok_attn_temporal_planes(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, tp ? e->AO.p : nullptr,
+                                                    tp ? e->ST.p : nullptr, ab_ao.stat, ab_ao.dev, 2, S, (int64_t)B * S, T,
+                                                    heads, ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi,
+                                                    stream));
+                ao_planes = tp;
+            }
+            if (pl) {
+                const void *ap = e->AO.p;
+                if (!ao_planes) {  // fp32 attention output (fp32-MFMA attention kernel, long temporal sequences): pack it
+                    if (int rc = pack_rows(e->AO.p, e->QKV.p, e->ST.p)) return rc;
+                    ap = e->QKV.p;
+                }
+                if (int rc = gemm_out_pl(ly, ap, e->ST.p, 1.0f, ly.t.wo, nullptr)) return rc;
+                goto feed_forward;
             }
             OT_RUN("gemm_out", gemm_f * D,
                    eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL, 0, 0,
@@ -875,6 +971,14 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                        eg_gemm(e, e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
                                stream));
             }
+            if (pl && ly.w.ao_bound > 0.0f) {
+                OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
+                       omnitok_attn_window_planes(e->QKV.p, 3 * D, ly.w.bias_dense, nullptr, 0, e->AO.p, ly.w.ao_bound, B * T, gh,
+                                                  gw, heads, stream));
+                if (int rc = gemm_out_pl(ly, e->AO.p, nullptr, omnitok_pl_unscale(ly.w.ao_bound), ly.w.wproj, ly.w.bproj))
+                    return rc;
+                goto feed_forward;
+            }
             OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
                    omnitok_attn_window(e->QKV.p, 3 * D, ly.w.bias_dense, e->AO.p, D, B * T, gh, gw, heads, stream));
             OT_RUN("gemm_out", gemm_f * D,
@@ -884,7 +988,38 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
         }
     feed_forward:
         // FeedForward (reference attention.py:153-168)
-        if (fused && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
+        if (pl) {
+            if (!ln_planes_ready) {  // after pooling / Up blocks: LayerNorm pass, then planes
+                const int64_t Lp = (L + 255) / 256 * 256;
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->AO.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("pack_rows", 2.0 * L * D * 4.0,
+                       omnitok_pl_pack_rows(e->AO.p, D, L, D, Lp, e->Y.p, nullptr, ly.ff.ln_bound, stream));
+            }
+            omnitok_pl_gemm g{};
+            g.a = e->Y.p;
+            g.a_scale_const = omnitok_pl_unscale(ly.ff.ln_bound);
+            g.out_planes = e->HD.p;
+            g.out_planes_k = e->inner_pad;
+            g.out_bound = ly.ff.h_bound;
+            g.epilogue = 1;
+            g.M = L;
+            g.N = 2 * e->inner_pad;
+            g.K = D;
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner, eg_gemm_pl(e, g, ly.ff.w1p, stream));
+            omnitok_pl_gemm h{};
+            h.a = e->HD.p;
+            h.a_scale_const = omnitok_pl_unscale(ly.ff.h_bound);
+            h.residual = e->X.p;
+            h.ldr = D;
+            h.c = e->X.p;
+            h.ldc = D;
+            h.epilogue = 0;
+            h.M = L;
+            h.N = D;
+            h.K = e->inner_pad;
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner, eg_gemm_pl(e, h, ly.ff.w2p, stream));
+        } else if (fused && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
             OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
             OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
                    eg_gemm(e, e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
@@ -949,6 +1084,7 @@ static void workspace_widths(const omnitok_engine *e, int64_t (&wd)[8]) {
 static int64_t workspace_bytes_for(const omnitok_engine *e, int64_t L) {
     int64_t wd[8], total = 0;
     workspace_widths(e, wd);
+    L = (L + 255) / 256 * 256;  // plane operands are read in whole 256-row tiles (gemm_pl.h)
     for (int i = 0; i < 8; ++i) total += ((L * wd[i] * 4 + 255) / 256) * 256;
     return total;
 }
@@ -956,12 +1092,14 @@ static int64_t workspace_bytes_for(const omnitok_engine *e, int64_t L) {
 static int ensure_workspace(omnitok_engine *e, int64_t L) {
     int64_t wd[8];
     workspace_widths(e, wd);
+    const int64_t L_real = L;
+    L = (L + 255) / 256 * 256;
     Buf *bufs[8] = {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST};
     if (e->ext_ws) {  // slices of the caller's block, 256-byte aligned
         const int64_t need = workspace_bytes_for(e, L);
         if (need > e->ext_ws_bytes) {
             set_error("workspace of %lld bytes is too small: %lld tokens need %lld (omnitok_engine_workspace_need_*)",
-                      (long long)e->ext_ws_bytes, (long long)L, (long long)need);
+                      (long long)e->ext_ws_bytes, (long long)L_real, (long long)need);
             return OMNITOK_ERR_STATE;
         }
         char *p = reinterpret_cast<char *>(e->ext_ws);
@@ -1179,6 +1317,7 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
     for (void *p : e->owned) (void)hipFree(p);
     e->owned.clear();
     e->h2w.clear();
+    e->plw.clear();
     e->rope.clear();
     e->bias_tables.clear();
     const omnitok_config &c = e->cfg;

@@ -90,11 +90,9 @@ __host__ __device__ __forceinline__ int64_t pl_offset(int64_t row, int k, int pl
 // Wave tile = NI x MI accumulator blocks of 32 x 32 (n x m): 2 x 4 at two waves per SIMD (256 registers), 4 x 4 at one
 // wave per SIMD (512 registers; a third fewer fragment bytes read from LDS per MFMA -- the kernel is power-bound, so
 // bytes moved per flop, not stalls, set its rate: profiles/r03_pl_ablation.txt).
-// PM = 1 ("product major", one wave per SIMD only): the three products of an accumulator block are issued back to back
-// (both fragment sets of a step live at once, the next step's set is read meanwhile: two sets of 4 * (NI + MI) registers).
-template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4, int PM_ = 0>
+template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4>
 struct PlCfg {
-    static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_, PM = PM_;
+    static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_;
     static constexpr int NW = WN * WM, NT = 64 * NW;
     static constexpr int TN = 32 * NI * WN, TM = 32 * MI * WM;
     static constexpr int WPS = NW > 4 ? 2 : 1;  // waves per SIMD of one workgroup
@@ -219,80 +217,12 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     if (total > 1) dma_step();
     if (D > 2 && total > 2) dma_step();
     int st = 0;  // stage of the current step
-    // second fragment set of the product-major form
-    u32x4 X2[C::PM ? MI : 1], Y2[C::PM ? MI : 1], Ph2[C::PM ? NI : 1], Pl2[C::PM ? NI : 1];
-    if constexpr (C::PM) {
-        // everything of step 0 must have landed; step 1 may stay in flight
-        if (total > 1) { PL_WAIT_VM(PPW); } else { PL_WAIT_VM(0); }
-        __builtin_amdgcn_s_barrier();
-        rdA(X, 0, 0);
-        rdA(Y, 0, 1);
-        rdW(Ph, 0, 0);
-        rdW(Pl, 0, 1);
-    } else {
-        PL_WAIT_VM(0);
-        __builtin_amdgcn_s_barrier();
-        rdA(X, 0, 0);
-        rdW(Pl, 0, 1);
-    }
+    PL_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    rdA(X, 0, 0);
+    rdW(Pl, 0, 1);
 
     for (int ti = 0; ti < my_tiles; ++ti) {
-        if constexpr (C::PM) {
-            static_assert(!C::PM || (D == 2 && C::WPS == 1), "product-major form: D = 2, one wave per SIMD");
-            // K steps in pairs (nk is even): step s computes from set 0 / 1 while set 1 / 0 receives step s + 1
-            auto pm_step = [&](int s, u32x4 (&cx)[C::PM ? MI : 1], u32x4 (&cy)[C::PM ? MI : 1], u32x4 (&cph)[C::PM ? NI : 1],
-                               u32x4 (&cpl)[C::PM ? NI : 1], u32x4 (&nx)[C::PM ? MI : 1], u32x4 (&ny)[C::PM ? MI : 1],
-                               u32x4 (&nph)[C::PM ? NI : 1], u32x4 (&npl)[C::PM ? NI : 1]) {
-                const bool more = (DBG & 4) ? false : s + 2 < total;
-                const bool next = s + 1 < total;
-                const int st1 = st + 1 == R ? 0 : st + 1;
-                // step s + 1 has landed (issued one step ago; nothing newer is in flight at this point)
-                if constexpr ((DBG & 1) == 0) PL_WAIT_VM(0);
-                if constexpr ((DBG & 2) == 0) lds_barrier();
-                unsigned koff = 0;
-                const unsigned char *ca = d_a, *cw = d_w;
-                const int cst = d_stage;
-                if (more) koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
-                int slot = 0;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        mfma1(cpl[ni], cx[mi], acc[ni][mi]);
-                        mfma1(cph[ni], cx[mi], acc[ni][mi]);
-                        mfma1(cph[ni], cy[mi], acc[ni][mi]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        // one fragment read of the next step per block (NI * MI >= 2 (NI + MI) slots), one DMA piece per two
-                        if (next) {
-                            if (slot < MI)
-                                nx[slot] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + a_fr + slot * 512);
-                            else if (slot < 2 * MI)
-                                ny[slot - MI] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + a_fr + 2 * TM * 16 + (slot - MI) * 512);
-                            else if (slot < 2 * MI + NI)
-                                nph[slot - 2 * MI] = *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + w_fr + (slot - 2 * MI) * 512);
-                            else if (slot < 2 * MI + 2 * NI)
-                                npl[slot - 2 * MI - NI] =
-                                    *reinterpret_cast<const u32x4 *>(pl_smem + st1 * C::STAGE + w_fr + 2 * TN * 16 + (slot - 2 * MI - NI) * 512);
-                        }
-                        if (more && (slot & 1) && (slot >> 1) < PPW) {
-                            const int j = slot >> 1;
-                            const unsigned char *src = (p_is_w[j] ? cw : ca) + koff + pv_off[j];
-                            __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + cst * C::STAGE + pl_dst[j]), 16, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        ++slot;
-                    }
-                if (more) {
-                    d_stage = d_stage + 1 == R ? 0 : d_stage + 1;
-                    if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
-                }
-                st = st1;
-            };
-            for (int k = 0; k < nk; k += 2) {
-                pm_step(ti * nk + k, X, Y, Ph, Pl, X2, Y2, Ph2, Pl2);
-                pm_step(ti * nk + k + 1, X2, Y2, Ph2, Pl2, X, Y, Ph, Pl);
-            }
-        } else
         for (int k = 0; k < nk; ++k) {
             const int s = ti * nk + k;
             const bool more = (DBG & 4) ? false : s + D < total;  // wave-uniform
@@ -489,6 +419,139 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                 const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
                                 const f16x4 lb = __builtin_convertvector(vb - __builtin_convertvector(hb, f32x4), f16x4);
                                 unsigned char *dst = blk + (c * 2 + hi) * 1024;
+                                *reinterpret_cast<u32x4 *>(dst) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                *reinterpret_cast<u32x4 *>(dst + 4096) =
+                                    __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                            }
+                        }
+                    }
+                } else if constexpr (EPI == PL_ROWLN) {
+                    // Full-row tiles (TN == N == 32 * NI * WN): out = acc (+ bias) + residual is stored as fp32 AND
+                    // LayerNorm(out) (two-pass statistics like norm.hip::row_stats) is written as fp16 planes, the A
+                    // operand of the GEMM that follows (reference attention.py:666-680: x = attn(x) + x; x = ff(x) + x
+                    // with ff = Sequential(LayerNorm, ...)).  A lane owns 32 * NI of the row's columns; the row sums
+                    // go through a [WN][TM] LDS table behind the ring.
+                    static_assert(C::WM == 1 || EPI != PL_ROWLN, "row statistics: one wave row per tile");
+                    float *red0 = reinterpret_cast<float *>(pl_smem + C::LDS);
+                    float *red1 = red0 + C::WN * TM;
+                    int64_t vr64 = p.M - m_w0;
+                    const int vr = vr64 > 32 * MI ? 32 * MI : (vr64 < 0 ? 0 : (int)vr64);
+                    const auto c_rs = x3_rsrc(p.c + m_w0 * p.ldc + n_w0, vr > 0 ? ((vr - 1) * (int)p.ldc + 32 * NI) * 4 : 0);
+                    const auto r_rs = x3_rsrc(p.residual ? p.residual + m_w0 * p.ldr + n_w0 : p.c,
+                                              p.residual && vr > 0 ? ((vr - 1) * (int)p.ldr + 32 * NI) * 4 : 0);
+                    float rsum[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) rsum[mi] = 0.0f;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        f32x4 sw[2][2], bv[2][2];
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h) {
+                                const int n = n_w0 + ni * 32 + c * 16 + hi * 8 + h * 4;
+                                sw[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
+                                bv[c][h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int row = mi * 32 + r32;
+                            const int c_off = (row * (int)p.ldc + ni * 32 + hi * 8) * 4;
+                            u32x4 res[2][2];
+                            if (p.residual) {
+                                const int r_off = (row * (int)p.ldr + ni * 32 + hi * 8) * 4;
+#pragma unroll
+                                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h)
+                                        res[c][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_off + (c * 16 + h * 4) * 4, 0, 0);
+                            }
+#pragma unroll
+                            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[c][h][e]);
+                                        t += bv[c][h][e];
+                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[c][h][e]);
+                                        v[e] = t;
+                                        acc[ni][mi][c * 8 + h * 4 + e] = t;  // kept for the statistics
+                                    }
+                                    rsum[mi] += (v[0] + v[1]) + (v[2] + v[3]);
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs,
+                                                                           c_off + (c * 16 + h * 4) * 4, 0, 0);
+                                }
+                        }
+                    }
+                    // mean
+                    float mean[MI], rstd[MI];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float t = rsum[mi] + swap32(rsum[mi]);
+                        if (hi == 0) red0[wn * TM + mi * 32 + r32] = t;
+                    }
+                    lds_barrier();
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        float t = 0.0f;
+#pragma unroll
+                        for (int w8 = 0; w8 < C::WN; ++w8) t += red0[w8 * TM + mi * 32 + r32];
+                        mean[mi] = t / (float)(32 * NI * C::WN);
+                    }
+                    // centred sum of squares
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        float q = 0.0f;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int r = 0; r < 16; r += 4) {
+                                const float a = acc[ni][mi][r] - mean[mi], b = acc[ni][mi][r + 1] - mean[mi];
+                                const float c2 = acc[ni][mi][r + 2] - mean[mi], d = acc[ni][mi][r + 3] - mean[mi];
+                                q += (a * a + b * b) + (c2 * c2 + d * d);
+                            }
+                        q += swap32(q);
+                        if (hi == 0) red1[wn * TM + mi * 32 + r32] = q;
+                    }
+                    lds_barrier();
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        float t = 0.0f;
+#pragma unroll
+                        for (int w8 = 0; w8 < C::WN; ++w8) t += red1[w8 * TM + mi * 32 + r32];
+                        rstd[mi] = 1.0f / sqrtf(t / (float)(32 * NI * C::WN) + p.ln_eps);
+                    }
+                    // LayerNorm -> planes
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int kb = (n_w0 >> 5) + ni;
+#pragma unroll
+                        for (int c = 0; c < 2; ++c) {
+                            const int n = n_w0 + ni * 32 + c * 16 + hi * 8;
+                            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p.ln_gamma + n);
+                            const f32x4 g1 = *reinterpret_cast<const f32x4 *>(p.ln_gamma + n + 4);
+                            f32x4 b0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
+                            if (p.ln_beta) {
+                                b0 = *reinterpret_cast<const f32x4 *>(p.ln_beta + n);
+                                b1 = *reinterpret_cast<const f32x4 *>(p.ln_beta + n + 4);
+                            }
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int64_t m = m_w0 + mi * 32 + r32;
+                                f32x4 va, vb;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    va[e] = ((acc[ni][mi][c * 8 + e] - mean[mi]) * rstd[mi] * g0[e] + b0[e]) * p.cp_scale;
+                                    vb[e] = ((acc[ni][mi][c * 8 + 4 + e] - mean[mi]) * rstd[mi] * g1[e] + b1[e]) * p.cp_scale;
+                                }
+                                const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb, f16x4);
+                                const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
+                                const f16x4 lb = __builtin_convertvector(vb - __builtin_convertvector(hb, f32x4), f16x4);
+                                unsigned char *dst = p.cp + ((m >> 6) * p.cp_kblocks + kb) * 8192 + (c * 2 + hi) * 1024 + (m & 63) * 16;
                                 *reinterpret_cast<u32x4 *>(dst) =
                                     __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
                                 *reinterpret_cast<u32x4 *>(dst + 4096) =

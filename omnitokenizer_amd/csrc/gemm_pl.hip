@@ -90,7 +90,9 @@ template <int EPI, bool SWAP, typename C>
 static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     int n_cu = 0;
     if (int rc = current_device_cus(&n_cu)) return rc;
-    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), C::LDS)) return rc;
+    constexpr int LDS = C::LDS + (EPI == PL_ROWLN ? 2 * C::WN * C::TM * 4 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), LDS)) return rc;
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
     const int nbn = (p.N + C::TN - 1) / C::TN;
     const int64_t nt = nbm * nbn;
@@ -99,7 +101,7 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     p.nbn = nbn;
     p.ntiles = (int)nt;
     p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
-    int wg_per_cu = (160 * 1024) / C::LDS;
+    int wg_per_cu = (160 * 1024) / LDS;
     const int by_waves = (C::NI * C::MI > 8) ? 1 : 8 / C::NW;
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
     if (wg_per_cu < 1) wg_per_cu = 1;
@@ -107,27 +109,29 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     // one big workgroup per CU: persistent
     const int64_t cap = wg_per_cu > 1 ? nt : (int64_t)n_cu;
     const int grid = (int)(nt < cap ? nt : cap);
-    hipLaunchKernelGGL((gemm_pl_kernel<EPI, SWAP, C>), dim3(grid), dim3(C::NT), C::LDS, stream, p);
+    hipLaunchKernelGGL((gemm_pl_kernel<EPI, SWAP, C>), dim3(grid), dim3(C::NT), LDS, stream, p);
     OT_LAUNCH_CHECK("gemm_pl");
     return OMNITOK_OK;
 }
 
 template <int EPI>
 static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
-    switch (cfg) {
-        case 2: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3>>(p, stream);
-        case 3: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3>>(p, stream);
-        case 4: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 4>>(p, stream);   // 4 waves x (128 x 128), one per SIMD
-        case 5: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 3, 0, 4, 4>>(p, stream);
-        case 6: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3, 2, 0, 4, 4, 1>>(p, stream);   // product-major order
-        case 18: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3, 2, 4, 4, 4, 1>>(p, stream);  // ... without DMA
-        case 14: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 4, 4>>(p, stream);  // no DMA
-        case 16: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 7, 4, 4>>(p, stream);  // no DMA, barrier, wait
-        case 11: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 1>>(p, stream);   // measurement builds
-        case 13: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 3>>(p, stream);
-        case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
-        case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
-        default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+    if constexpr (EPI == PL_ROWLN) {
+        return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
+    } else {
+        switch (cfg) {
+            case 2: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3>>(p, stream);
+#ifdef OMNITOK_PL_MEASUREMENT_BUILDS  // wrong-result ablation builds of profiles/r03_gemm_limiter_probe.txt
+            case 3: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3>>(p, stream);
+            case 4: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 4>>(p, stream);
+            case 11: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 1>>(p, stream);
+            case 13: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 3>>(p, stream);
+            case 14: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 4, 4>>(p, stream);
+            case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
+            case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
+#endif
+            default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+        }
     }
 }
 
@@ -140,6 +144,8 @@ extern "C" int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad) {
     const int64_t rp = (rows + row_pad - 1) / row_pad * row_pad;
     return rp * K * 4;
 }
+
+extern "C" float omnitok_pl_unscale(float bound) { return 1.0f / h2_scale_of_bound(bound); }
 
 extern "C" int omnitok_pl_pack_weight(const float *w, int64_t ldw, int N, int K, int n_pad, void *planes, float *scale,
                                       omnitok_stream_t stream_) {
@@ -207,6 +213,15 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             OT_CHECK_ARG(g->out_planes && g->N % 64 == 0 && g->out_planes_k == g->N / 2 && g->out_bound > 0.0f,
                          "gemm_pl: GEGLU needs out_planes with out_planes_k == N / 2 and a bound of the hidden");
             return launch_pl<PL_GEGLU>(p, cfg, stream);
+        case PL_ROWLN:
+            OT_CHECK_ARG(g->N == 512 && g->c && g->ldc % 4 == 0 && aligned16(g->c) && g->out_planes && g->out_planes_k == g->N &&
+                             g->out_bound > 0.0f && g->ln_gamma && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))) &&
+                             !g->c2 && !g->a2,
+                         "gemm_pl: the LayerNorm epilogue needs N == 512 (full-row tiles), c, out_planes (K = N), gamma and a bound");
+            p.ln_gamma = g->ln_gamma;
+            p.ln_beta = g->ln_beta;
+            p.ln_eps = g->ln_eps;
+            return launch_pl<PL_ROWLN>(p, cfg, stream);
         default:
             set_error("gemm_pl: unsupported epilogue %d", g->epilogue);
             return OMNITOK_ERR_INVALID;

@@ -48,7 +48,7 @@ static float *dmalloc_f(int64_t n) {
     return (float *)p;
 }
 
-struct Shape { const char *name; int N, K; bool geglu, residual; };
+struct Shape { const char *name; int N, K; bool geglu, residual; bool rowln = false; };
 
 int main(int argc, char **argv) {
     int iters = 10;
@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&dcyc, 8));
 
     const Shape shapes[] = {{"q_or_out", 512, 512, false, false}, {"out_res", 512, 512, false, true}, {"qkv", 1536, 512, false, false},
-                            {"ff_in", 2816, 512, true, false},   {"ff_out", 512, 1408, false, true}};
+                            {"ff_in", 2816, 512, true, false},   {"ff_out", 512, 1408, false, true}, {"out_res_ln", 512, 512, false, true, true}};
     const int64_t Lp = (L + 255) / 256 * 256;
     for (const Shape &sh : shapes) {
         if (!only.empty() && only != sh.name) continue;
@@ -93,7 +93,10 @@ int main(int argc, char **argv) {
         const int Nout = sh.geglu ? N / 2 : N;
         float *c = dmalloc_f(L * (int64_t)Nout);
         void *outp = nullptr;
-        if (sh.geglu) CK(hipMalloc(&outp, (size_t)Lp * Nout * 4));
+        if (sh.geglu || sh.rowln) CK(hipMalloc(&outp, (size_t)Lp * Nout * 4));
+        float *gam = dmalloc_f(512), *bet = dmalloc_f(512);
+        fill_randn<<<2, 256, 0, st>>>(gam, 512, 4, 0.3f);
+        fill_randn<<<2, 256, 0, st>>>(bet, 512, 5, 0.1f);
         // old kernel operands
         void *wp_h2;
         CK(hipMalloc(&wp_h2, (size_t)((N + 63) / 64 * 64) * K * 4));
@@ -111,6 +114,10 @@ int main(int argc, char **argv) {
             g.debug_cycles = timed ? dcyc : nullptr;
             if (sh.geglu) {
                 g.epilogue = 1; g.out_planes = outp; g.out_planes_k = Nout; g.out_bound = 64.0f;
+            } else if (sh.rowln) {
+                g.epilogue = 2; g.c = c; g.ldc = Nout; g.residual = res; g.ldr = 512;
+                g.out_planes = outp; g.out_planes_k = Nout; g.out_bound = 64.0f;
+                g.ln_gamma = gam; g.ln_beta = bet; g.ln_eps = 1e-5f;
             } else {
                 g.epilogue = 0; g.c = c; g.ldc = Nout;
                 if (sh.residual) { g.residual = res; g.ldr = 512; }
@@ -138,7 +145,7 @@ int main(int argc, char **argv) {
             const float ms = time_it(run_h2);
             printf("   h2 (fp32 A, in-loop split)     %.4f ms  %6.1f TF\n", ms, flops / ms / 1e9);
         }
-        if (!sh.geglu && !sh.residual) {
+        if (!sh.geglu && !sh.residual && !sh.rowln) {
             for (size_t pos = 0; pos < h2dbg.size();) {
                 const int dbg = atoi(h2dbg.c_str() + pos);
                 size_t nx = h2dbg.find(',', pos);
@@ -224,10 +231,38 @@ int main(int argc, char **argv) {
                 } else {
                     std::vector<float> got(N);
                     CK(hipMemcpy(got.data(), c + m * N, (size_t)N * 4, hipMemcpyDeviceToHost));
+                    std::vector<double> xo(N);
                     for (int n = 0; n < N; ++n) {
                         const double r = ref[n] + (sh.residual ? hr[n] : 0.0);
+                        xo[n] = r;
                         maxerr = fmax(maxerr, fabs(got[n] - r));
                         maxref = fmax(maxref, fabs(r));
+                    }
+                    if (sh.rowln) {
+                        std::vector<float> hg(512), hb(512);
+                        CK(hipMemcpy(hg.data(), gam, 2048, hipMemcpyDeviceToHost));
+                        CK(hipMemcpy(hb.data(), bet, 2048, hipMemcpyDeviceToHost));
+                        double mean = 0, var = 0;
+                        for (int n = 0; n < N; ++n) mean += xo[n];
+                        mean /= N;
+                        for (int n = 0; n < N; ++n) var += (xo[n] - mean) * (xo[n] - mean);
+                        var /= N;
+                        std::vector<uint16_t> rowp((size_t)N * 2);
+                        for (int n = 0; n < N; ++n) {
+                            const double y = (xo[n] - mean) / sqrt(var + 1e-5) * hg[n] + hb[n];
+                            const int64_t off = (((m >> 6) * (N >> 5) + (n >> 5)) * 8 + ((n >> 3) & 3)) * 512 + (m & 63) * 8 + (n & 7);
+                            uint16_t h, l;
+                            CK(hipMemcpy(&h, (uint16_t *)outp + off, 2, hipMemcpyDeviceToHost));
+                            CK(hipMemcpy(&l, (uint16_t *)outp + off + 4 * 512, 2, hipMemcpyDeviceToHost));
+                            auto f16 = [](uint16_t v) {
+                                const int sg = v >> 15, e = (v >> 10) & 31, f = v & 1023;
+                                double r = e == 0 ? ldexp((double)f, -24) : ldexp((double)(f + 1024), e - 25);
+                                return sg ? -r : r;
+                            };
+                            const double got2 = (f16(h) + f16(l)) / 256.0;
+                            maxerr = fmax(maxerr, fabs(got2 - y));
+                            if (n >= 64 && m > 2) break;
+                        }
                     }
                 }
             }
