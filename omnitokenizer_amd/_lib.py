@@ -31,6 +31,19 @@ class OmnitokLmConfig(Structure):
                 ("n_embd", c_int)]
 
 
+class OmnitokPlGemm(Structure):
+    """omnitok_pl_gemm (include/omnitok.h): arguments of the plane x plane GEMM."""
+    _fields_ = [
+        ("a", c_void_p), ("a_scale", c_void_p), ("a_scale_const", c_float),
+        ("a2", c_void_p), ("a2_scale", c_void_p), ("a2_scale_const", c_float), ("a_split_n", c_int),
+        ("w", c_void_p), ("w_scale", c_void_p), ("bias", c_void_p), ("residual", c_void_p), ("ldr", c_int64),
+        ("c", c_void_p), ("ldc", c_int64), ("c2", c_void_p), ("ldc2", c_int64), ("c_split_n", c_int),
+        ("out_planes", c_void_p), ("out_planes_k", c_int), ("out_bound", c_float),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("epilogue", c_int),
+        ("M", c_int64), ("N", c_int), ("K", c_int), ("cfg", c_int), ("debug_cycles", c_void_p),
+    ]
+
+
 class OmnitokError(RuntimeError):
     pass
 
@@ -115,6 +128,16 @@ _PROTOS = {
     "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "omnitok_lm_attn_decode": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
     "omnitok_gemm_pp": [P, P, P, P, P, I64, I64, c_int, c_int, P],
+    "omnitok_pl_planes_bytes": [I64, c_int, c_int],
+    "omnitok_pl_unscale": [c_float],
+    "omnitok_pl_pack_weight": [P, I64, c_int, c_int, c_int, P, P, P],
+    "omnitok_pl_pack_rows": [P, I64, I64, c_int, I64, P, P, c_float, P],
+    "omnitok_gemm_pl": [POINTER(OmnitokPlGemm), P],
+    "omnitok_attn_spatial_h2_planes": [P, P, P, P, I64, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P, c_int,
+                                       c_int, P, c_int, c_int, P],
+    "omnitok_attn_window_planes": [P, I64, P, P, I64, P, c_float, c_int, c_int, c_int, c_int, P],
+    "omnitok_attn_temporal_planes": [P, I64, P, P, I64, P, I64, P, P, c_float, P, c_int, I64, I64, c_int, c_int, P, P,
+                                     c_float, c_int, P, P],
     "omnitok_set_option": [c_char_p, c_int],
     "omnitok_debug_set_gemm_trace": [P],
     "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
@@ -124,7 +147,8 @@ _PROTOS = {
 _RESTYPES = {"omnitok_last_error": c_char_p, "omnitok_version": c_char_p,
              "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64,
              "omnitok_engine_workspace_need_encode": c_int64, "omnitok_engine_workspace_need_decode": c_int64,
-             "omnitok_lm_destroy": None, "omnitok_lm_cache_bytes": c_int64}
+             "omnitok_lm_destroy": None, "omnitok_lm_cache_bytes": c_int64,
+             "omnitok_pl_planes_bytes": c_int64, "omnitok_pl_unscale": c_float}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)
 

@@ -215,6 +215,124 @@ def linear_h2_vpack(x, packed, a_bound, ln, ln_cols, ln_bound, v_col0, n_tokens,
     return out, vp
 
 
+# ---- plane x plane GEMM (csrc/gemm_pl.h): both operands as fp16 hi|lo planes in 64-row x 32-k blocks ------------------
+
+def _pad256(n: int) -> int:
+    return (n + 255) // 256 * 256
+
+
+def pl_pack_weight(weight):
+    """nn.Linear weight [N, K] -> (planes, row scales) for linear_pl (rows permuted inside groups of 32, padded to 256)."""
+    w = _req(weight, "weight")
+    N, K = w.shape
+    planes = torch.empty(_pad256(N) * K, device=w.device, dtype=torch.int32)
+    scale = torch.empty(N, device=w.device, dtype=torch.float32)
+    check(_lib.load().omnitok_pl_pack_weight(_p(w), K, N, K, _pad256(N), _p(planes), _p(scale), _stream()), "pl_pack_weight")
+    return planes, scale
+
+
+def pl_pack_rows(x, static_bound=None):
+    """Activation rows [M, K] -> (planes, per-row scales or None).  static_bound: one power-of-two scale from an upper
+    bound of |x| (the consumer then takes a_scale_const = pl_unscale(bound)); default: one scale per row."""
+    x = _req(x, "x")
+    M, K = x.shape
+    planes = torch.empty(_pad256(M) * K, device=x.device, dtype=torch.int32)
+    scales = None if static_bound else torch.empty(max(M, 1), device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_pl_pack_rows(_p(x), K, M, K, _pad256(M), _p(planes), _p(scales), float(static_bound or 0.0),
+                                           _stream()), "pl_pack_rows")
+    return planes, scales
+
+
+def pl_unscale(bound: float) -> float:
+    return float(_lib.load().omnitok_pl_unscale(float(bound)))
+
+
+def pl_unpack_planes(planes, M, K):
+    """hi + lo of a plane buffer as fp64 [M, K] (test helper; plain torch indexing on the GPU tensor)."""
+    h = planes.view(torch.float16).view(-1, K // 32, 2, 4, 64, 8)  # [row block][k block][plane][k group][row][8]
+    v = h[:, :, 0].double() + h[:, :, 1].double()                  # [rb][kb][kg][row][8]
+    v = v.permute(0, 3, 1, 2, 4).reshape(-1, K)                    # [rb, row][kb, kg, 8]
+    return v[:M]
+
+
+def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias=None, residual=None, epilogue=0,
+              out_bound=0.0, ln=None, a2=None, a_split_n=0, c_split_n=0, cfg=0):
+    """c = a . w^T from plane operands.  epilogue 0: fp32 [M, N] (+ bias, + residual; c_split_n: two outputs);
+    1: GEGLU -> hidden planes [M, N / 2]; 2: (fp32, planes of LayerNorm(c)) with ln = (gamma, beta or None, eps).
+    a2 = (planes, scales or None, const): second activation operand for output columns >= a_split_n."""
+    g = _lib.OmnitokPlGemm()
+    dev = a_planes.device
+    g.a = a_planes.data_ptr()
+    g.a_scale = a_scale.data_ptr() if a_scale is not None else None
+    g.a_scale_const = float(a_scale_const)
+    if a2 is not None:
+        g.a2 = a2[0].data_ptr()
+        g.a2_scale = a2[1].data_ptr() if a2[1] is not None else None
+        g.a2_scale_const = float(a2[2])
+        g.a_split_n = int(a_split_n)
+    g.w = w_packed[0].data_ptr()
+    g.w_scale = w_packed[1].data_ptr()
+    g.bias = bias.data_ptr() if bias is not None else None
+    outs = []
+    if epilogue in (0, 2):
+        if c_split_n:
+            c = torch.empty(M, c_split_n, device=dev, dtype=torch.float32)
+            c2 = torch.empty(M, N - c_split_n, device=dev, dtype=torch.float32)
+            g.c, g.ldc, g.c2, g.ldc2, g.c_split_n = c.data_ptr(), c_split_n, c2.data_ptr(), N - c_split_n, c_split_n
+            outs = [c, c2]
+        else:
+            c = torch.empty(M, N, device=dev, dtype=torch.float32)
+            g.c, g.ldc = c.data_ptr(), N
+            outs = [c]
+        if residual is not None:
+            g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+    if epilogue in (1, 2):
+        ko = N // 2 if epilogue == 1 else N
+        op = torch.empty(_pad256(M) * ko, device=dev, dtype=torch.int32)
+        g.out_planes, g.out_planes_k, g.out_bound = op.data_ptr(), ko, float(out_bound)
+        outs.append(op)
+    if epilogue == 2:
+        g.ln_gamma = ln[0].data_ptr()
+        g.ln_beta = ln[1].data_ptr() if ln[1] is not None else None
+        g.ln_eps = float(ln[2])
+    g.epilogue, g.M, g.N, g.K, g.cfg = epilogue, M, N, K, cfg
+    check(_lib.load().omnitok_gemm_pl(ctypes.byref(g), _stream()), "gemm_pl")
+    return outs[0] if len(outs) == 1 else tuple(outs)
+
+
+def attn_spatial_h2_planes(packed, bounds, Bn, N, heads, bias_table=None, gh=0, gw=0, v_bound_dev=None, v_bound_stride=1,
+                           seq_per_clip=0):
+    """attn_spatial_h2 with the output as (planes, row scales) of K = heads * 64 (the to_out GEMM's operand)."""
+    planes = torch.empty(_pad256(Bn * N) * heads * 64, device=packed.device, dtype=torch.int32)
+    scales = torch.empty(Bn * N, device=packed.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_spatial_h2_planes(_p(packed[0]), _p(packed[1]), _p(packed[2]), None, 0, _p(planes),
+                                                     _p(scales), Bn, N, heads, bounds[0], bounds[1], bounds[2],
+                                                     _p(v_bound_dev), v_bound_stride, seq_per_clip, _p(bias_table), gh, gw,
+                                                     _stream()), "attn_spatial_h2_planes")
+    return planes, scales
+
+
+def attn_window_planes(qkv, bias_dense, Bn, gh, gw, heads, out_bound):
+    qkv = _req(qkv, "qkv")
+    planes = torch.empty(_pad256(qkv.shape[0]) * heads * 64, device=qkv.device, dtype=torch.int32)
+    check(_lib.load().omnitok_attn_window_planes(_p(qkv), qkv.shape[1], _p(_req(bias_dense, "bias_dense")), None, 0,
+                                                 _p(planes), float(out_bound), Bn, gh, gw, heads, _stream()),
+          "attn_window_planes")
+    return planes
+
+
+def attn_temporal_planes(q, k, v, cols, T, heads, q_scale, k_scale, causal, v_bound, alibi=None, scale=8.0,
+                         v_bound_dev=None, v_bound_stride=1, cols_per_clip=0):
+    assert k.stride(0) == v.stride(0)
+    planes = torch.empty(_pad256(q.shape[0]) * heads * 64, device=q.device, dtype=torch.int32)
+    scales = torch.empty(q.shape[0], device=q.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_temporal_planes(_p(q), q.stride(0), _p(k), _p(v), k.stride(0), None, 0, _p(planes),
+                                                   _p(scales), float(v_bound), _p(v_bound_dev), v_bound_stride,
+                                                   cols_per_clip, cols, T, heads, _p(q_scale), _p(k_scale), scale,
+                                                   int(bool(causal)), _p(alibi), _stream()), "attn_temporal_planes")
+    return planes, scales
+
+
 def pack_geglu_weight(w1, inner_pad):
     w1 = _req(w1, "w1")
     inner, K = w1.shape[0] // 2, w1.shape[1]

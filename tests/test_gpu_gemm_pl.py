@@ -1,0 +1,220 @@
+"""GPU (-m gpu): the plane x plane GEMM (csrc/gemm_pl.h) that carries to_out / proj, FF-in and FF-out of the
+Transformer blocks (reference attention.py:153-168, 386-393, 216-252), its three epilogues, and the attention kernels'
+plane outputs that feed it -- against fp64 (the oracle for a GEMM is a matrix product), and for the properties the
+engine relies on: results independent of the tile configuration and of the batch (bitwise), ragged sizes, rows beyond
+M never stored."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    from omnitokenizer_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def maxerr(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+# (M, N, K): production shapes at reduced M, ragged M, N below / not a multiple of the 256-wide tile
+SHAPES = [(1024, 512, 512), (1000, 192, 512), (4096 + 33, 1536, 512), (257, 512, 1408), (5, 64, 32), (777, 768, 512)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("cfg", [1, 2], ids=["256x256", "128x256"])
+def test_pl_gemm_fp32_epilogue_vs_fp64(ops, M, N, K, cfg):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    ap, asc = ops.pl_pack_rows(x)
+    wp = ops.pl_pack_weight(w)
+    ref = x.double() @ w.double().t()
+    tol = 2e-6 * math.sqrt(K / 512) * max(1.0, ref.abs().max().item())
+    assert maxerr(ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=cfg), ref) < tol
+    out = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, bias=bias, residual=res, cfg=cfg)
+    assert maxerr(out, ref + bias.double() + res.double()) < tol
+    # in place (x += ...), as the engine runs FF-out
+    r2 = res.clone()
+    g_out = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, residual=r2, cfg=cfg)
+    assert torch.equal(g_out, ops.linear_pl(ap, wp, M, N, K, a_scale=asc, residual=res, cfg=cfg))
+
+
+def test_pl_gemm_planes_roundtrip_and_scales(ops):
+    # a plane buffer is the fp32 operand to 22 bits: hi + lo reproduces x * scale within 2^-22 of the row maximum
+    x = rnd(300, 512, seed=5) * torch.logspace(-3, 3, 300).cuda()[:, None]
+    ap, asc = ops.pl_pack_rows(x)
+    back = ops.pl_unpack_planes(ap, 300, 512) * asc.double()[:, None]
+    rowmax = x.abs().max(dim=1).values.double()
+    assert ((back - x.double()).abs().max(dim=1).values <= rowmax * 2.0 ** -21).all()
+    # a static bound gives one scale for all rows
+    ap2, none = ops.pl_pack_rows(x, static_bound=float(x.abs().max()) * 1.01)
+    assert none is None
+    back2 = ops.pl_unpack_planes(ap2, 300, 512) * ops.pl_unscale(float(x.abs().max()) * 1.01)
+    assert (back2 - x.double()).abs().max().item() <= float(x.abs().max()) * 2.0 ** -21
+
+
+def test_pl_gemm_results_do_not_depend_on_tiling_or_batch(ops):
+    M, N, K = 2048 + 64, 1024, 512
+    x, w = rnd(M, K, seed=6), rnd(N, K, seed=7, scale=0.05)
+    ap, asc = ops.pl_pack_rows(x)
+    wp = ops.pl_pack_weight(w)
+    full1 = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=1)
+    full2 = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=2)
+    assert torch.equal(full1, full2)
+    # the first 512 rows alone (another grid, other tiles per workgroup): bit-identical rows
+    ap3, asc3 = ops.pl_pack_rows(x[:512].contiguous())
+    assert torch.equal(ops.linear_pl(ap3, wp, 512, N, K, a_scale=asc3, cfg=1), full1[:512])
+    # determinism across launches
+    assert torch.equal(ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=1), full1)
+
+
+def test_pl_gemm_two_operands_and_two_outputs(ops):
+    # merged launch: columns < 256 from operand a (e.g. LayerNorm(x)), the rest from a2 (raw x); outputs split at 256
+    M, K = 1300, 512
+    xa, xb = rnd(M, K, seed=8), rnd(M, K, seed=9, scale=3.0)
+    w = rnd(768, K, seed=10, scale=0.05)
+    ap, asc = ops.pl_pack_rows(xa, static_bound=float(xa.abs().max()) * 1.01)
+    bp, bsc = ops.pl_pack_rows(xb)
+    wp = ops.pl_pack_weight(w)
+    c, c2 = ops.linear_pl(ap, wp, M, 768, K, a_scale_const=ops.pl_unscale(float(xa.abs().max()) * 1.01), a2=(bp, bsc, 0.0),
+                          a_split_n=256, c_split_n=256)
+    assert maxerr(c, xa.double() @ w[:256].double().t()) < 1e-5
+    assert maxerr(c2, xb.double() @ w[256:].double().t()) < 3e-5
+
+
+def test_pl_gemm_geglu_epilogue_writes_hidden_planes(ops):
+    # FF-in (reference attention.py:153-168): value | gate halves, exact-erf GELU; the hidden leaves as planes
+    M, K, inner, inner_pad = 1000, 512, 1365, 1408
+    x = rnd(M, K, seed=11)
+    w1 = rnd(2 * inner, K, seed=12, scale=0.05)
+    w1p = ops.pack_geglu_weight(w1, inner_pad)
+    ap, _ = ops.pl_pack_rows(x, static_bound=8.0)
+    hid = ops.linear_pl(ap, ops.pl_pack_weight(w1p), M, 2 * inner_pad, K, a_scale_const=ops.pl_unscale(8.0), epilogue=1,
+                        out_bound=64.0)
+    h = (x.double() @ w1.double().t())
+    ref = F.gelu(h[:, inner:]) * h[:, :inner]
+    got = ops.pl_unpack_planes(hid, M, inner_pad) * ops.pl_unscale(64.0)
+    assert maxerr(got[:, :inner], ref) < 5e-6 * max(1.0, ref.abs().max().item())
+    assert (got[:, inner:] == 0).all()  # pad columns are exactly zero (zero weight rows)
+    # ... and feed FF-out
+    w2 = rnd(512, inner, seed=13, scale=0.05)
+    w2p = torch.zeros(512, inner_pad, device="cuda")
+    w2p[:, :inner] = w2
+    res = rnd(M, 512, seed=14)
+    out = ops.linear_pl(hid, ops.pl_pack_weight(w2p), M, 512, inner_pad, a_scale_const=ops.pl_unscale(64.0), residual=res)
+    ref2 = ref @ w2.double().t() + res.double()
+    assert maxerr(out, ref2) < 1e-5 * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("M", [128, 1000, 4096 + 17])
+@pytest.mark.parametrize("with_beta", [True, False])
+def test_pl_gemm_layernorm_epilogue(ops, M, with_beta):
+    # to_out with the residual add and the FeedForward's LayerNorm in the epilogue (reference attention.py:666-680, 163)
+    K = 512
+    x, w = rnd(M, K, seed=15), rnd(512, K, seed=16, scale=0.05)
+    bias, res = rnd(512, seed=17), rnd(M, 512, seed=18, scale=2.0)
+    gamma, beta = 1.0 + 0.2 * rnd(512, seed=19), (0.1 * rnd(512, seed=20) if with_beta else None)
+    ap, asc = ops.pl_pack_rows(x)
+    bound = 1.01 * (math.sqrt(512) * float(gamma.abs().max()) + (float(beta.abs().max()) if with_beta else 0.0))
+    c, lnp = ops.linear_pl(ap, ops.pl_pack_weight(w), M, 512, K, a_scale=asc, bias=bias, residual=res, epilogue=2,
+                           out_bound=bound, ln=(gamma, beta, 1e-5))
+    ref = x.double() @ w.double().t() + bias.double() + res.double()
+    assert maxerr(c, ref) < 5e-6 * ref.abs().max().item()
+    ln = F.layer_norm(ref, (512,), gamma.double(), beta.double() if with_beta else None, 1e-5)
+    got = ops.pl_unpack_planes(lnp, M, 512) * ops.pl_unscale(bound)
+    assert maxerr(got, ln) < 1e-5
+    # batch independence of the fused statistics: the first 128 rows alone give the same planes and rows
+    ap1, asc1 = ops.pl_pack_rows(x[:128].contiguous())
+    c1, lnp1 = ops.linear_pl(ap1, ops.pl_pack_weight(w), 128, 512, K, a_scale=asc1, bias=bias, residual=res[:128].contiguous(),
+                             epilogue=2, out_bound=bound, ln=(gamma, beta, 1e-5))
+    assert torch.equal(c1, c[:128])
+    assert torch.equal(ops.pl_unpack_planes(lnp1, 128, 512), ops.pl_unpack_planes(lnp, 128, 512))
+
+
+def test_pl_gemm_argument_errors(ops):
+    x, w = rnd(64, 512, seed=21), rnd(500, 512, seed=22)
+    with pytest.raises(ValueError):
+        ops.pl_pack_weight(w)  # N % 32
+    ap, asc = ops.pl_pack_rows(x)
+    wp = ops.pl_pack_weight(rnd(256, 512, seed=23))
+    with pytest.raises(ValueError):  # the LayerNorm epilogue owns whole rows of 512
+        ops.linear_pl(ap, wp, 64, 256, 512, a_scale=asc, epilogue=2, out_bound=30.0, ln=(rnd(256), None, 1e-5))
+    with pytest.raises(ValueError):  # GEGLU needs the bound of the hidden
+        ops.linear_pl(ap, wp, 64, 256, 512, a_scale=asc, epilogue=1)
+
+
+# ---- attention kernels writing planes ----------------------------------------------------------------------------------
+
+def test_spatial_attention_plane_output_equals_fp32_output(ops):
+    Bn, N, heads = 3, 256, 8
+    q, k, v = rnd(Bn * N, 512, seed=24), rnd(Bn * N, 512, seed=25), rnd(Bn * N, 512, seed=26, scale=2.0)
+    qs, ks = 1.0 + 0.1 * rnd(64, seed=27), 1.0 + 0.1 * rnd(64, seed=28)
+    packed, bounds = ops.attn_pack(q, k, v, N, heads, qs, ks)
+    o = ops.attn_spatial_h2(packed, bounds, Bn, N, heads)
+    planes, scales = ops.attn_spatial_h2_planes(packed, bounds, Bn, N, heads)
+    got = ops.pl_unpack_planes(planes, Bn * N, 512) * scales.double()[:, None]
+    assert (scales == ops.pl_unscale(bounds[2])).all()
+    assert maxerr(got, o) <= bounds[2] * 2.0 ** -21
+
+
+def test_window_attention_plane_output_equals_fp32_output(ops):
+    Bn, gh, gw, heads = 2, 16, 16, 8
+    qkv = rnd(Bn * gh * gw, 1536, seed=29)
+    bias = rnd(heads, 64, 64, seed=30, scale=0.5)
+    o = ops.attn_window(qkv, bias, Bn, gh, gw, heads)
+    bound = 1.01 * float(qkv[:, 1024:].abs().max())
+    planes = ops.attn_window_planes(qkv, bias, Bn, gh, gw, heads, bound)
+    got = ops.pl_unpack_planes(planes, Bn * gh * gw, 512) * ops.pl_unscale(bound)
+    assert maxerr(got, o) <= bound * 2.0 ** -21
+
+
+@pytest.mark.parametrize("T", [1, 2, 5, 9, 17])
+@pytest.mark.parametrize("causal", [True, False])
+def test_temporal_attention_plane_output_equals_fp32_output(ops, T, causal):
+    cols, heads = 48, 8
+    q, k, v = rnd(cols * T, 512, seed=31), rnd(cols * T, 512, seed=32), rnd(cols * T, 512, seed=33, scale=2.0)
+    qs, ks = 1.0 + 0.1 * rnd(64, seed=34), 1.0 + 0.1 * rnd(64, seed=35)
+    o = ops.attn_temporal(q, k, v, cols, T, heads, qs, ks, causal)
+    # per-clip bounds: 3 clips of 16 columns
+    bdev = torch.tensor([1.0, 9.0, 2.0, 9.0, 4.0, 9.0], device="cuda")
+    vb = 1.01 * float(v.abs().max())
+    planes, scales = ops.attn_temporal_planes(q, k, v, cols, T, heads, qs, ks, causal, vb, v_bound_dev=bdev, v_bound_stride=2,
+                                              cols_per_clip=16)
+    got = ops.pl_unpack_planes(planes, cols * T, 512) * scales.double()[:, None]
+    assert maxerr(got, o) <= 4 * vb * 2.0 ** -21
+    for clip, f in enumerate((1.0, 2.0, 4.0)):
+        assert (scales[clip * 16 * T:(clip + 1) * 16 * T] == ops.pl_unscale(vb * f)).all()
+
+
+def test_engine_plane_data_flow_matches_fp32_data_flow(ops):
+    """The engine with gemm_pl 1 (planes between the kernels) against gemm_pl 0 (r02: fp32 activations, split in the K
+    loop): the same arithmetic class, so ids agree except provable near-ties and pixels agree far inside the 1e-4 bar."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    args = make_args(2, resolution=64, sequence_length=5)
+    model = OmniTokenizer_VQGAN(args)
+    model.load_state_dict(synth.synth_state_dict(OmniTokConfig.from_args(args), seed=3), strict=True)
+    model = model.cuda().eval()
+    x = synth.synth_video(2, 5, 64, seed=7).cuda()
+    try:
+        _lib.set_option("gemm_pl", 0)
+        ids0 = model.encode(x, False)
+        px0 = model.decode(ids0, False)
+        _lib.set_option("gemm_pl", 1)
+        ids1 = model.encode(x, False)
+        px1 = model.decode(ids0, False)
+    finally:
+        _lib.set_option("gemm_pl", 1)
+    assert (ids0 != ids1).float().mean().item() <= 2e-3
+    assert maxerr(px0, px1) < 2e-5
