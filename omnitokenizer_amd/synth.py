@@ -155,17 +155,36 @@ def _key_seed(seed: int, name: str) -> int:
     return (seed * 1000003 + zlib.crc32(name.encode())) & 0xFFFFFFFF
 
 
-def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+def synth_state_dict(cfg: OmniTokConfig, seed: int = 0, profile: str = "default") -> "OrderedDict[str, torch.Tensor]":
     """Random but non-degenerate parameters: every gamma/bias/scale is perturbed so that a
-    kernel that drops one of them is caught."""
+    kernel that drops one of them is caught.
+
+    profile "heavy": statistics a trained checkpoint can have and the default generator never produces -- heavy-tailed
+    (Student-t, 3 degrees of freedom, unclipped) linear and depthwise-conv weights, LayerNorm gains with 1 % outlier
+    channels of magnitude 5..20 (outlier activation channels in front of every GEMM), q/k scales up to 4 (logits up to
+    8 * 4 * 4 = 128: near one-hot softmax rows), biases ten times larger.  This is the family that stresses the
+    power-of-two operand scales of the fp16-split GEMMs and attention (gemm_h2.hip, gemm_pl.h, attn_h2.hip)."""
+    if profile not in ("default", "heavy"):
+        raise ValueError(f"unknown weight profile {profile!r}")
+    heavy = profile == "heavy"
     sd: OrderedDict = OrderedDict()
     for name, shape in path_state_spec(cfg).items():
-        rng = np.random.Generator(np.random.PCG64(_key_seed(seed, name)))
+        rng = np.random.Generator(np.random.PCG64(_key_seed(seed, name + ("|heavy" if heavy else ""))))
         leaf = name.rsplit(".", 1)[-1]
 
         def randn(scale=1.0, mean=0.0):
             return (rng.standard_normal(shape, dtype=np.float32) * np.float32(scale)
                     + np.float32(mean)).astype(np.float32)
+
+        def student_t(scale):
+            return (rng.standard_t(3.0, size=shape) * scale).astype(np.float32)
+
+        def gain():  # LayerNorm gains: 1 +- 0.1 with 1 % outlier channels of magnitude 5..20 and random sign
+            v = randn(0.1, 1.0)
+            n = v.size
+            idx = rng.choice(n, size=max(1, n // 100), replace=False)
+            v.reshape(-1)[idx] = (rng.uniform(5.0, 20.0, size=idx.size) * rng.choice([-1.0, 1.0], size=idx.size)).astype(np.float32)
+            return v
 
         if name.endswith("relative_position_index"):
             sd[name] = relative_position_index(cfg.window_size)
@@ -195,6 +214,22 @@ def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, tor
             v = sd["codebook.embeddings"].numpy().copy()
         elif name in ("codebook.N", "codebook.codebook_usage"):
             v = np.zeros(shape, np.float32)
+        elif heavy and "dsconv.weight" in name:
+            v = student_t(0.5 / np.sqrt(27.0))
+        elif heavy and "dsconv.bias" in name:
+            v = randn(0.5)
+        elif heavy and leaf in ("q_scale", "k_scale"):
+            v = rng.uniform(0.5, 4.0, size=shape).astype(np.float32)
+        elif heavy and leaf == "gamma":
+            v = gain()
+        elif heavy and leaf == "relative_position_bias_table":
+            v = randn(2.0)
+        elif heavy and "spatial_rel_pos_bias" not in name and leaf == "weight" and len(shape) == 1:
+            v = gain()
+        elif heavy and "spatial_rel_pos_bias" not in name and leaf == "bias":
+            v = randn(0.5)
+        elif heavy and "spatial_rel_pos_bias" not in name and leaf == "weight":
+            v = student_t(0.02)
         elif "dsconv.weight" in name:
             v = (rng.random(shape, dtype=np.float32) * 2 - 1) * np.float32(1 / np.sqrt(27.0))
         elif "dsconv.bias" in name:
@@ -221,9 +256,32 @@ def synth_state_dict(cfg: OmniTokConfig, seed: int = 0) -> "OrderedDict[str, tor
 
 
 def synth_video(batch: int, frames: int, resolution: int, seed: int = 1234, smooth: bool = True,
-                channels: int = 3) -> torch.Tensor:
+                channels: int = 3, kind: str = "noise") -> torch.Tensor:
     """[B,C,F,H,W] fp32 in [-0.5, 0.5] (the reference's preprocess contract, data.py:346).
-    smooth=True low-pass filters the noise so LayerNorm inputs are not white."""
+    smooth=True low-pass filters the noise so LayerNorm inputs are not white.
+    kind "natural": image-like content -- strongly low-pass noise (large smooth regions, a few edges) with a slow
+    drift over the frames; kind "mixed": clip 0 is ONE constant colour (zero-variance patches: LayerNorm's 1/sqrt(eps)
+    branch), the others are "natural"."""
+    if kind in ("natural", "mixed"):
+        rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+        x = rng.standard_normal((batch, channels, 1, resolution, resolution)).astype(np.float32)
+        for width in (resolution // 4, resolution // 8, 3):  # repeated box blurs: ~1/f^2 spectrum
+            w = max(1, int(width))
+            for ax in (3, 4):
+                acc = np.zeros_like(x)
+                for sh in range(-(w // 2), w - w // 2):
+                    acc += np.roll(x, sh, ax)
+                x = acc / np.float32(w)
+        x = x + np.float32(0.15) * np.sign(x - np.median(x))  # a few hard edges
+        drift = np.linspace(0.0, 1.0, frames, dtype=np.float32).reshape(1, 1, frames, 1, 1)
+        x = x * (np.float32(1.0) - np.float32(0.3) * drift) + np.float32(0.05) * drift * np.roll(x, resolution // 8, 4)
+        x = (x - x.min()) / (x.max() - x.min())
+        if kind == "mixed":
+            col = rng.random((channels, 1, 1, 1), dtype=np.float32)
+            x[0] = np.broadcast_to(col, x[0].shape)
+        return torch.from_numpy(np.ascontiguousarray((x - np.float32(0.5)).astype(np.float32)))
+    if kind != "noise":
+        raise ValueError(f"unknown input kind {kind!r}")
     rng = np.random.Generator(np.random.PCG64(seed))
     x = rng.random((batch, channels, frames, resolution, resolution), dtype=np.float32)
     if smooth:
@@ -233,9 +291,9 @@ def synth_video(batch: int, frames: int, resolution: int, seed: int = 1234, smoo
     return torch.from_numpy(np.ascontiguousarray((x - np.float32(0.5)).astype(np.float32)))
 
 
-def synth_image(batch: int, resolution: int, seed: int = 1234, smooth: bool = True) -> torch.Tensor:
+def synth_image(batch: int, resolution: int, seed: int = 1234, smooth: bool = True, kind: str = "noise") -> torch.Tensor:
     """[B,C,H,W]."""
-    return synth_video(batch, 1, resolution, seed, smooth)[:, :, 0].contiguous()
+    return synth_video(batch, 1, resolution, seed, smooth, kind=kind)[:, :, 0].contiguous()
 
 
 def state_checksum(sd) -> int:

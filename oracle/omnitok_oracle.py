@@ -79,7 +79,7 @@ def continuous_position_bias(sd, prefix, h, w):
     grid = torch.stack([ys, xs]).reshape(2, -1).t()  # (h w) 2
     rel = grid[:, None, :] - grid[None, :, :]
     rel = torch.sign(rel) * torch.log(rel.abs() + 1)
-    r = rel.float()
+    r = rel.float().to(sd[f"{prefix}.net.0.0.weight"].dtype)  # fp32 like the reference (fp64 only for noise measurements)
     r = F.leaky_relu(F.linear(r, sd[f"{prefix}.net.0.0.weight"], sd[f"{prefix}.net.0.0.bias"]), 0.1)
     r = F.leaky_relu(F.linear(r, sd[f"{prefix}.net.1.0.weight"], sd[f"{prefix}.net.1.0.bias"]), 0.1)
     r = F.linear(r, sd[f"{prefix}.net.2.weight"], sd[f"{prefix}.net.2.bias"])
@@ -93,7 +93,7 @@ def continuous_position_bias_table(sd, prefix, h, w):
     dy, dx = torch.meshgrid(torch.arange(-(h - 1), h), torch.arange(-(w - 1), w), indexing="ij")
     rel = torch.stack([dy, dx], dim=-1)
     rel = torch.sign(rel) * torch.log(rel.abs() + 1)
-    r = rel.float()
+    r = rel.float().to(sd[f"{prefix}.net.0.0.weight"].dtype)  # fp32 like the reference (fp64 only for noise measurements)
     r = F.leaky_relu(F.linear(r, sd[f"{prefix}.net.0.0.weight"], sd[f"{prefix}.net.0.0.bias"]), 0.1)
     r = F.leaky_relu(F.linear(r, sd[f"{prefix}.net.1.0.weight"], sd[f"{prefix}.net.1.0.bias"]), 0.1)
     r = F.linear(r, sd[f"{prefix}.net.2.weight"], sd[f"{prefix}.net.2.bias"])

@@ -81,16 +81,29 @@ VARIANT_CASES = [
 ]
 
 
-def run_case(name, stage, mode, overrides, batch, frames, stride):
+# Trained-checkpoint-like statistics (VERDICT r02 "missing" #2): synth profile "heavy" (Student-t weights, outlier
+# LayerNorm gains up to 20, q/k scales up to 4, large biases) on image-like inputs; "mixed" = clip 0 one constant colour.
+# name, stage, mode, overrides, batch, frames, stride, input kind
+HEAVY_CASES = [
+    ("heavy_s2_sdpa_r64_img", 2, "sdpa", dict(resolution=64), 2, 1, 1, "mixed"),
+    ("heavy_s2_sdpa_r64_vid", 2, "sdpa", dict(resolution=64), 2, 5, 1, "mixed"),
+    ("heavy_s1_legacy_r64_vid", 1, "legacy", dict(resolution=64), 1, 5, 1, "natural"),
+    ("heavy_s2_sdpa_r128_vid_16k", 2, "sdpa", dict(resolution=128, n_codes=16384), 1, 5, 2, "natural"),
+    ("heavy_s2_sdpa_r256_vid17", 2, "sdpa", dict(resolution=256), 1, 17, 8, "natural"),
+]
+
+
+def run_case(name, stage, mode, overrides, batch, frames, stride, input_kind="noise", profile="default"):
     args = make_args(stage, **overrides)
     cfg = OmniTokConfig.from_args(args, attention_mode=mode)
-    sd = synth.synth_state_dict(cfg, seed=0)
+    sd = synth.synth_state_dict(cfg, seed=0, profile=profile)
     model = rh.build_reference_model(args)
     msg = model.load_state_dict(sd, strict=False)
     assert not msg.unexpected_keys, msg.unexpected_keys
     is_image = frames == 1
     res = cfg.resolution
-    x = synth.synth_image(batch, res, seed=1234) if is_image else synth.synth_video(batch, frames, res, seed=1234)
+    x = (synth.synth_image(batch, res, seed=1234, kind=input_kind) if is_image
+         else synth.synth_video(batch, frames, res, seed=1234, kind=input_kind))
     with torch.no_grad(), rh.attention_mode(mode):
         emb, ids = model.encode(x, is_image, include_embeddings=True)
         # pre-VQ z exactly as the reference feeds Codebook.forward (omnitokenizer.py:248-252)
@@ -103,10 +116,23 @@ def run_case(name, stage, mode, overrides, batch, frames, stride):
             assert torch.equal(recon, model.decode(flat, is_image))
     assert int(ids.max()) < 32768
     sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
+    extra = {}
+    if profile != "default":
+        # The yardstick for these fixtures: how far the reference's OWN fp32 arithmetic is from the exact result.  The
+        # oracle (pinned to the reference: tests/test_oracle_vs_golden.py) is evaluated in fp64 on the same weights.
+        from oracle import omnitok_oracle as orc
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        with torch.no_grad():
+            taps = {}
+            orc.encode(sd64, x.double(), is_image, cfg, taps=taps)
+            rec64 = orc.decode(sd64, ids, is_image, cfg)
+        extra = dict(fp32_noise_z=np.float32((taps["z"] - z.permute(0, 2, 3, 4, 1).double()).abs().max().item()),
+                     fp32_noise_pix=np.float32((rec64 - recon.double()).abs().max().item()))
+        print(f"    reference fp32 vs fp64: z {extra['fp32_noise_z']:.2e}, pixels {extra['fp32_noise_pix']:.2e}")
     np.savez_compressed(
-        os.path.join(OUT, name + ".npz"),
+        os.path.join(OUT, name + ".npz"), **extra,
         stage=stage, mode=mode, overrides=repr(overrides), batch=batch, frames=frames,
-        stride=stride, weight_seed=0, input_seed=1234,
+        stride=stride, weight_seed=0, input_seed=1234, profile=profile, input_kind=input_kind,
         state_crc=np.uint32(synth.state_checksum(sd)),
         input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
         ids=ids.numpy().astype(np.int16),
@@ -449,3 +475,6 @@ if __name__ == "__main__":
     if only in (None, "vae"):
         for c in VAE_CASES:
             run_vae_case(*c)
+    if only in (None, "heavy"):
+        for c in HEAVY_CASES:
+            run_case(*c, profile="heavy")

@@ -27,6 +27,9 @@ VARIANT_CASES = ["var_pool_a_r128_vid", "var_pool_m_r128_img", "var_pool_l_r128_
 # external VectorQuantize: cosine-similarity codebook (l2_code) and Euclidean codebook (no l2_code)
 EXT_CASES = ["ext_s2_sdpa_r64_img", "ext_s2_sdpa_r64_vid", "ext_s1_legacy_r128_vid", "ext_euclid_s2_sdpa_r64_img",
              "ext_euclid_s2_sdpa_r64_vid"]
+# trained-checkpoint-like statistics (synth profile "heavy") and image-like / constant-colour inputs
+HEAVY_CASES = ["heavy_s2_sdpa_r64_img", "heavy_s2_sdpa_r64_vid", "heavy_s1_legacy_r64_vid", "heavy_s2_sdpa_r128_vid_16k",
+               "heavy_s2_sdpa_r256_vid17"]
 VAE_CASES = ["vae_s2_sdpa_r64_img", "vae_s2_sdpa_r64_vid", "vae_s1_legacy_r64_vid", "vae_s2_sdpa_r256_vid"]
 
 
@@ -43,13 +46,15 @@ class GoldenCase:
         self.is_image = self.frames == 1
         self.args = make_args(self.stage, **self.overrides)
         self.cfg = OmniTokConfig.from_args(self.args, attention_mode=self.mode)
-        self.sd = synth.synth_state_dict(self.cfg, seed=int(g["weight_seed"]))
+        self.profile = str(g["profile"]) if "profile" in g.files else "default"
+        self.input_kind = str(g["input_kind"]) if "input_kind" in g.files else "noise"
+        self.sd = synth.synth_state_dict(self.cfg, seed=int(g["weight_seed"]), profile=self.profile)
         assert synth.state_checksum(self.sd) == int(g["state_crc"]), \
             "synthetic weight generator drifted from the golden fixtures"
         res = self.cfg.resolution
         seed = int(g["input_seed"])
-        self.x = (synth.synth_image(self.batch, res, seed) if self.is_image
-                  else synth.synth_video(self.batch, self.frames, res, seed))
+        self.x = (synth.synth_image(self.batch, res, seed, kind=self.input_kind) if self.is_image
+                  else synth.synth_video(self.batch, self.frames, res, seed, kind=self.input_kind))
         assert zlib.crc32(self.x.numpy().tobytes()) == int(g["input_crc"]), "synthetic input drifted"
         self.is_vae = "noise" in g.files
         if self.is_vae:  # --use_vae fixture (make_golden.run_vae_case)
@@ -61,6 +66,9 @@ class GoldenCase:
             self.ids = torch.from_numpy(g["ids"].astype(np.int64))
             self.z = torch.from_numpy(g["z"])          # b t h w c
             self.emb = torch.from_numpy(g["emb"])      # b t h w c
+        # how far the reference's own fp32 result is from the fp64 one (heavy-statistics fixtures only)
+        self.fp32_noise_z = float(g["fp32_noise_z"]) if "fp32_noise_z" in g.files else 0.0
+        self.fp32_noise_pix = float(g["fp32_noise_pix"]) if "fp32_noise_pix" in g.files else 0.0
         self.recon = torch.from_numpy(g["recon"])  # strided
         self.perplexity = float(g["perplexity"]) if "perplexity" in g.files else None
         self.recon_absmax = float(g["recon_absmax"])

@@ -6,7 +6,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, VAE_CASES, VARIANT_CASES
+from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, HEAVY_CASES, VAE_CASES, VARIANT_CASES
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -46,6 +46,22 @@ def test_oracle_end_to_end_matches_reference(name):
     if c.is_image or c.cfg.resolution // c.cfg.patch_size == c.ids.shape[-1]:
         recon_flat = orc.decode(c.sd, c.ids.reshape(c.ids.shape[0], -1), c.is_image, c.cfg)
         assert torch.equal(recon_flat, recon)
+
+
+@pytest.mark.parametrize("name", [c for c in HEAVY_CASES if "r256" not in c])
+def test_oracle_matches_reference_on_heavy_statistics(name):
+    """The fixtures with trained-checkpoint-like statistics (synth profile "heavy", image-like / constant-colour inputs):
+    the oracle still reproduces the reference to fp32 noise, far below the reference's own distance to fp64."""
+    c = GoldenCase(name)
+    assert c.profile == "heavy" and c.fp32_noise_pix > 0
+    with torch.no_grad():
+        taps = {}
+        ids = orc.encode(c.sd, c.x, c.is_image, c.cfg, taps=taps)
+        recon = orc.decode(c.sd, c.ids, c.is_image, c.cfg)
+    assert torch.equal(ids, c.ids)
+    assert (taps["z"] - c.z).abs().max().item() < 4e-6
+    assert (c.strided(recon) - c.recon).abs().max().item() < 1e-4
+    assert c.recon_absmax > 5.0  # an order of magnitude beyond the default generator's outputs
 
 
 def test_oracle_vq_on_golden_z_is_bit_exact():
