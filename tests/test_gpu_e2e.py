@@ -29,7 +29,7 @@ def models():
     cache = {}
 
     def get(case):
-        key = (case.stage, case.mode, tuple(sorted(case.overrides.items())))
+        key = (case.stage, case.mode, tuple(sorted(case.overrides.items())), case.profile)
         if key not in cache:
             from omnitokenizer_amd import OmniTokenizer_VQGAN
             m = OmniTokenizer_VQGAN(case.args, attention_mode=case.mode)
@@ -332,6 +332,40 @@ def test_c3_batch_of_32_distinct_clips_vs_reference(models):
     assert len({zlib.crc32(ids[b].cpu().numpy().tobytes()) for b in range(32)}) == 32
     assert torch.equal(m.encode(x[20:21].cuda().contiguous(), False), ids[20:21])
     print(f"C3 batch of 32 distinct clips: id flips {flips}, z err {zerr:.1e}, pixel err {err:.1e}")
+
+
+def test_c3_batch_all_32_clips_vs_oracle(models):
+    """Every one of the 32 distinct clips bench.py feeds at C3 (not only the four the reference fixture holds), encoded and
+    decoded in ONE batch on the MI355X, against the CPU oracle run clip by clip on the host (the oracle is pinned to the
+    reference on four of these very clips by tests/test_oracle_vs_golden.py / the fixture above)."""
+    import os
+    from omnitokenizer_amd import synth
+    c = GoldenCase("s2_sdpa_r256_vid17")
+    m = models(c)
+    x = synth.synth_video(32, 17, 256, seed=1234)
+    ids, z = m.encode(x.cuda(), False, return_latents=True)
+    ids_c, z_c = ids.cpu(), z.cpu()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    zerr = perr = 0.0
+    flips = 0
+    ids_ref_all = []
+    try:
+        with torch.no_grad():
+            for b in range(32):
+                taps = {}
+                ids_ref = orc.encode(c.sd, x[b:b + 1], False, c.cfg, taps=taps)
+                ids_ref_all.append(ids_ref)
+                zerr = max(zerr, (z_c[b:b + 1] - taps["z"]).abs().max().item())
+                flips += assert_ids_match_or_near_tie(ids_c[b:b + 1], ids_ref, z_c[b:b + 1], c.sd["codebook.embeddings"], f"clip {b}")
+            rec = m.decode(torch.cat(ids_ref_all).cuda(), False).cpu()
+            for b in range(32):
+                rec_ref = orc.decode(c.sd, ids_ref_all[b], False, c.cfg)
+                perr = max(perr, (rec[b:b + 1] - rec_ref).abs().max().item())
+    finally:
+        torch.set_num_threads(threads)
+    print(f"C3, all 32 clips vs the oracle: id flips {flips}/{ids.numel()}, z err {zerr:.1e}, pixel err {perr:.1e}")
+    assert zerr < Z_TOL and perr < PIXEL_TOL
 
 
 def test_c5_long_sequence_stress(models):
