@@ -22,25 +22,61 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class IdGather:
+    """The one collective of the path (reference launch contract ddp_utils.py:333-364: one process per GPU, a default
+    process group): all-gather of the token ids, int32 on the wire, off the critical path.
+
+        g = IdGather(n_total, tail_shape, device)      # buffers allocated once, reused every step
+        g.start(ids_local)                             # one cast-copy into the send buffer, asynchronous all_gather
+        ... decode(ids_local) ...                      # the local decode does not need the other ranks' ids
+        ids_all = g.wait()                             # [n_total, ...] int64
+
+    Even shards (n_total % world == 0, e.g. BASELINE config C4: 256 clips on 8 GPUs = 32 each) cost one cast-copy in,
+    the collective and one cast-copy out; ragged shards copy each rank's valid rows out of the padded receive buffer."""
+
+    def __init__(self, n_total: int, tail, device, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_total = int(n_total)
+        self.tail = tuple(int(v) for v in tail)
+        self.bmax = -(-self.n_total // self.world)
+        self.even = self.n_total % self.world == 0
+        self.send = torch.zeros((self.bmax,) + self.tail, dtype=torch.int32, device=device)
+        self.recv = torch.empty((self.world * self.bmax,) + self.tail, dtype=torch.int32, device=device)
+        self.out = torch.empty((self.n_total,) + self.tail, dtype=torch.int64, device=device)
+        self.work = None
+
+    def start(self, ids_local: torch.Tensor):
+        assert self.work is None, "IdGather.start() called twice without wait()"
+        lo, hi = shard_range(self.n_total, self.rank, self.world)
+        assert ids_local.shape[0] == hi - lo and tuple(ids_local.shape[1:]) == self.tail, (ids_local.shape, lo, hi, self.tail)
+        if hi > lo:
+            self.send[: hi - lo].copy_(ids_local)  # int64 -> int32 in the copy kernel
+        # asynchronous: NCCL/RCCL runs it on its own stream behind the copy; gloo on its worker thread
+        self.work = dist.all_gather_into_tensor(self.recv, self.send, group=self.group, async_op=True)
+        return self
+
+    def wait(self) -> torch.Tensor:
+        assert self.work is not None, "IdGather.wait() without start()"
+        self.work.wait()
+        self.work = None
+        if self.even:
+            self.out.copy_(self.recv)  # int32 -> int64
+        else:
+            for r in range(self.world):
+                lo, hi = shard_range(self.n_total, r, self.world)
+                if hi > lo:
+                    self.out[lo:hi].copy_(self.recv[r * self.bmax: r * self.bmax + (hi - lo)])
+        return self.out
+
+
 def all_gather_ids(ids_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
-    """ids_local [b_local, ...] int64 -> [n_total, ...] int64 on every rank."""
+    """ids_local [b_local, ...] int64 -> [n_total, ...] int64 on every rank (blocking form of IdGather)."""
     world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     if world == 1:
         return ids_local
-    tail = tuple(ids_local.shape[1:])
-    bmax = -(-n_total // world)
-    send = torch.zeros((bmax,) + tail, dtype=torch.int32, device=ids_local.device)
-    send[: ids_local.shape[0]] = ids_local.to(torch.int32)
-    recv = torch.empty((world * bmax,) + tail, dtype=torch.int32, device=ids_local.device)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        parts.append(recv[r * bmax: r * bmax + (hi - lo)])
-    out = torch.cat(parts, dim=0).to(torch.int64)
-    assert out.shape[0] == n_total, (out.shape, n_total, rank)
-    return out
+    return IdGather(n_total, ids_local.shape[1:], ids_local.device, group).start(ids_local).wait().clone()
 
 
 def encode_sharded(encode_fn: Callable[[torch.Tensor], torch.Tensor], x_global_or_local: torch.Tensor,

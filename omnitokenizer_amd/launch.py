@@ -118,18 +118,34 @@ def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.T
     b_local = x_local.shape[0]
     n_total = b_local * info.world
     lo, hi = od.shard_range(n_total, info.rank, info.world)
-    state = {}
+    state = {"gather": None}
+    trace = [] if os.environ.get("OMNITOK_TRACE_STEP") else None  # tests: order of the phases of the last step
 
     def step():
+        if trace is not None:
+            trace.clear()
         ids_local = encode(x_local)
+        if trace is not None:
+            trace.append("encode")
+        g = None
         if info.world > 1:
-            ids_all = od.all_gather_ids(ids_local, n_total)     # the one collective of the path
-            state["ids_all"] = ids_all
-            ids_dec = ids_all[lo:hi].contiguous()
+            # the one collective of the path, issued asynchronously: decode consumes only the local shard, so the
+            # gather overlaps it and is waited for only when the gathered tensor is needed (its CRC, the caller)
+            if state["gather"] is None:
+                state["gather"] = od.IdGather(n_total, ids_local.shape[1:], ids_local.device)
+            g = state["gather"].start(ids_local)
+            if trace is not None:
+                trace.append("gather_start")
+        rec = decode(ids_local)
+        if trace is not None:
+            trace.append("decode")
+        if g is not None:
+            state["ids_all"] = g.wait()
+            if trace is not None:
+                trace.append("gather_wait")
         else:
             state["ids_all"] = ids_local
-            ids_dec = ids_local
-        return ids_local, decode(ids_dec)
+        return ids_local, rec
 
     for _ in range(warmup):
         step()
@@ -141,6 +157,8 @@ def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.T
     dt = time.perf_counter() - t0
     res = ShardedResult(seconds=dt, steps=steps, ids_local=ids, rec_local=rec, n_total=n_total,
                         world_seen=info.world)
+    if trace is not None:
+        res.extra["step_trace"] = list(trace)
     ids_all = state["ids_all"]
     res.ids_crc = zlib.crc32(ids_all.cpu().numpy().tobytes())
     if info.world > 1:

@@ -348,6 +348,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         # shape function instead of opaque Python
         x5 = x if x.dim() == 5 else x[:, :, None]
         ids, emb, z = torch.ops.omnitok.vqgan_encode(x5, self._handle, bool(include_embeddings), bool(return_latents))
+        # decode() trusts these ids (no range check read-back) for as long as the tensor is not modified
+        self._own_ids = (ids.data_ptr(), ids._version, tuple(ids.shape))
         if not include_embeddings:
             emb = None
         elif self.use_external_codebook:
@@ -486,8 +488,11 @@ class OmniTokenizer_VQGAN(nn.Module):
         stream = torch.cuda.current_stream().cuda_stream
         if check_ids is None:
             # like the reference's F.embedding, out-of-range ids raise; the check is one int read-back (a
-            # host synchronisation), so it is skipped by default only while a HIP graph is being captured
-            check_ids = not torch.cuda.is_current_stream_capturing()
+            # host synchronisation), so it is skipped by default while a HIP graph is being captured and for the
+            # untouched output of this module's own encode() (its ids are in range by construction)
+            own = getattr(self, "_own_ids", None)
+            trusted = own is not None and own == (encodings.data_ptr(), encodings._version, tuple(encodings.shape))
+            check_ids = not torch.cuda.is_current_stream_capturing() and not trusted
         if check_ids:
             rc = lib.omnitok_engine_check_ids(self._engine, stream)
             if rc == -1:

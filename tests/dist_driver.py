@@ -43,7 +43,8 @@ def main():
     if info.rank == 0:
         print(json.dumps({"n_gpus": info.world, "world_seen": res.world_seen, "ids_crc32": res.ids_crc,
                           "n_total": res.n_total, "allgather_ms": res.allgather_ms, "seconds": res.seconds,
-                          "ids_local_shape": list(res.ids_local.shape), "rec_local_shape": list(res.rec_local.shape)}),
+                          "ids_local_shape": list(res.ids_local.shape), "rec_local_shape": list(res.rec_local.shape),
+                          "step_trace": res.extra.get("step_trace")}),
               flush=True)
     launch.finish(info, on_gpu=False)
 

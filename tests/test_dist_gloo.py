@@ -65,6 +65,47 @@ def test_sharded_encode_allgather_gloo(n_total):
     assert res == {0: True, 1: True}
 
 
+def _gather_worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from omnitokenizer_amd import dist as od
+        lo, hi = od.shard_range(n_total, rank, world)
+        full = (torch.arange(n_total * 6, dtype=torch.int64).reshape(n_total, 2, 3) * 7) % 8192
+        g = od.IdGather(n_total, (2, 3), torch.device("cpu"))
+        ok = True
+        for step in range(3):  # the buffers are reused every step
+            mine = (full[lo:hi] + step) % 8192
+            g.start(mine)
+            ok = ok and g.work is not None            # asynchronous: nothing waited for yet
+            out = g.wait()
+            ok = ok and out.dtype == torch.int64 and torch.equal(out, (full + step) % 8192)
+        ok = ok and g.even == (n_total % world == 0) and g.send.dtype == torch.int32 and g.recv.dtype == torch.int32
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 5, 1])
+def test_id_gather_async_even_and_ragged(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(world)) == {0: True, 1: True}
+
+
+def test_c4_shards_are_32_clips_each():
+    # BASELINE config C4: 256 clips on 8 GPUs = the C3 load per GPU, even shards (no padding, no per-rank copies)
+    assert [shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 32, 256):
         for w in (1, 2, 3, 8):
@@ -83,6 +124,7 @@ def test_self_spawning_launcher_gloo():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMNITOK_TRACE_STEP"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_driver.py"), "--gpus", "2"],
                        capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -90,6 +132,8 @@ def test_self_spawning_launcher_gloo():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["n_total"] == 4
     assert out["allgather_ms"] is not None and out["ids_local_shape"][0] == 2
+    # the id all-gather is off the critical path: issued after encode, waited for only AFTER the local decode
+    assert out["step_trace"] == ["encode", "gather_start", "decode", "gather_wait"]
     # single-rank run of the same driver: no respawn, no collective
     r1 = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_driver.py"), "--gpus", "1"],
                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
