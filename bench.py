@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
                     help="omnitok_set_option switch for A/B measurements (e.g. attn_vpack=0); recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the hwmon clock / power sampling (profiled runs)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     a = ap.parse_args()
 
@@ -123,31 +124,37 @@ def main():
                 "attn_window", "vq_argmin"}
         gm_name, gm_products, gm_pipe_peak = GEMM_MODES[a.gemm_mode]
         gemm_roof = gm_pipe_peak / gm_products   # fp32-equivalent roof of the GEMM kernels in this mode
+        # the roof each MFMA kernel family is graded against: the split-operand kernels (GEMMs in gemm_mode 1 / 2, spatial
+        # attention in gemm_mode 2 with attn_mode 1) run on the fp16 / bf16 pipe with `products` MFMAs per fp32 multiply-add;
+        # window attention and the quantiser stay on the fp32-input MFMA
+        opts = dict(kv.split("=") for kv in a.option)
+        attn_split = a.gemm_mode == 2 and int(opts.get("attn_mode", 1)) == 1
+        roofs = {n: gemm_roof for n in mfma if n.startswith("gemm_")}
+        roofs["attn_spatial"] = PEAK_F16_TFLOPS / 3 if attn_split else PEAK_F32_TFLOPS
+        roofs["attn_window"] = roofs["vq_argmin"] = PEAK_F32_TFLOPS
         for name, k in kernels.items():
             if k["ms_per_step"] > 0:
                 if name in mfma:
-                    # algorithmic (fp32-equivalent) rate; GEMM families run on the split-operand kernels
+                    # algorithmic (fp32-equivalent) rate against the roof of the arithmetic the kernel runs on
                     k["tflops"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e12, 2)
-                    k["frac_f32_peak"] = round(k["tflops"] / PEAK_F32_TFLOPS, 4)
-                    if name.startswith("gemm_"):
-                        k["frac_of_mode_roof"] = round(k["tflops"] / gemm_roof, 4)
+                    k["roof_tflops"] = round(roofs[name], 1)
+                    k["frac_of_mode_roof"] = round(k["tflops"] / roofs[name], 4)
                 else:
                     k["gbs"] = round(k["work_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9, 1)
                     k["frac_hbm_peak"] = round(k["gbs"] / PEAK_HBM_GBS, 4)
         dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
         dk = kernels[dom]
+        is_gemm = dom.startswith("gemm_")
         if dom in mfma:
             per_launch_flops = dk["work_per_step"] / dk["launches_per_step"]
             avg_ms = dk["ms_per_step"] / dk["launches_per_step"]
-            is_gemm = dom.startswith("gemm_")
-            peak = gemm_roof if is_gemm else PEAK_F32_TFLOPS
+            peak = roofs[dom]
             roofline = dict(kernel=dom, bound="mfma", achieved=round(per_launch_flops / (avg_ms * 1e-3) / 1e12, 2),
                             peak=round(peak, 1), unit="TFLOP/s", avg_launch_ms=round(avg_ms, 4),
                             flops_per_launch=per_launch_flops, traffic=None)
             if is_gemm:
                 roofline["peak_definition"] = (f"{gm_pipe_peak:.0f} TF dense MFMA peak / {gm_products} matrix-pipe "
                                                f"products per fp32 multiply-add ({gm_name}); algorithmic fp32 flops")
-                roofline["frac_of_f32_mfma_peak"] = round(roofline["achieved"] / PEAK_F32_TFLOPS, 4)
                 roofline["matrix_pipe_tflops"] = round(roofline["achieved"] * gm_products, 1)
         else:
             per_launch_bytes = dk["work_per_step"] / dk["launches_per_step"]
@@ -156,44 +163,55 @@ def main():
                             peak=PEAK_HBM_GBS, unit="GB/s", avg_launch_ms=round(avg_ms, 4),
                             bytes_per_launch=per_launch_bytes, traffic=None)
         roofline["frac"] = round(roofline["achieved"] / roofline["peak"], 4)
-        # HBM traffic per launch of the dominant kernel, from the committed PMC passes (rocprofv3
-        # --pmc FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 correction applied; bench.py cannot
-        # collect counters itself).  null if no PMC run covers this kernel / workload.
-        pmc = {}
+        # Counter-derived fields (HBM-side traffic per launch, matrix-pipe busy cycles): bench.py cannot collect PMC
+        # counters itself, they come from profiles/pmc_traffic.json -- rocprofv3 --pmc passes of this very command
+        # (tools/pmc_collect.sh), stamped with the sha256 of the csrc/ tree they were measured on.  A stamp that does not
+        # match the sources of the library in use nulls them: a driver-run line never carries counters of other code.
+        pmc, pmc_state = {}, "profiles/pmc_traffic.json missing"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(f"gemm_mode_{a.gemm_mode}", {})
-            if is_gemm and "dvfs_check" in pmc:
-                # the same binary on constant operands: what the kernel reaches when the chip is not clocking down
-                # under the data-dependent power of random operands (MI355X_MICROARCH.md "DVFS give-back")
-                roofline["power_limit_evidence"] = pmc["dvfs_check"]
-                if pmc["dvfs_check"].get("mfma_stream_only_tflops"):
-                    # what a bare MFMA + fragment-read stream of this kernel sustains on random operands (ablation
-                    # build): the practical ceiling under the chip's power-limited clock
-                    roofline["frac_of_measured_mfma_stream"] = round(
-                        roofline["achieved"] / pmc["dvfs_check"]["mfma_stream_only_tflops"], 4)
-            if dom in pmc and B == 32 and a.frames == 17 and a.resolution == 256:
+            from tools.pmc_to_json import csrc_digest
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            stamp = pj.get("stamp", {})
+            if stamp.get("csrc_sha256") != csrc_digest(ROOT):
+                pmc_state = (f"stale: profiles/pmc_traffic.json was measured on csrc {str(stamp.get('csrc_sha256'))[:12]} "
+                             f"(HEAD {str(stamp.get('git_head'))[:10]}), this tree is {csrc_digest(ROOT)[:12]}")
+            elif not (B == 32 and a.frames == 17 and a.resolution == 256 and cfg.n_codes == 8192 and a.gemm_mode == 2
+                      and not a.option):
+                pmc_state = "the committed PMC passes cover the default C3 command only"
+            else:
+                pmc = pj.get(f"gemm_mode_{a.gemm_mode}", {})
+                pmc_state = f"ok: stamp {stamp.get('csrc_sha256', '')[:12]} (HEAD {str(stamp.get('git_head'))[:10]}, {stamp.get('tag')})"
+            if is_gemm and "power_limit_evidence" in pj:
+                roofline["power_limit_evidence"] = pj["power_limit_evidence"]
+        except Exception as ex:  # noqa: BLE001
+            pmc_state = f"unreadable: {ex!r}"
+        roofline["pmc_fields"] = pmc_state
+        if dom in pmc:
+            if "read_bytes" in pmc[dom]:
                 roofline["traffic"] = pmc[dom]["read_bytes"] + pmc[dom]["write_bytes"]
                 roofline["traffic_source"] = pmc[dom]["source"]
-                if "mfma_busy_pct" in pmc[dom]:  # matrix-pipe busy cycles from the committed PMC pass
-                    roofline["mfma_busy_pct_pmc"] = pmc[dom]["mfma_busy_pct"]
-                    roofline["mfma_busy_source"] = pmc[dom]["mfma_source"]
-                alg_bytes = {"gemm_ff_in": (B * tokens_per_clip) * (512 + 1408) * 4 + 2816 * 512 * 4}.get(dom)
-                if alg_bytes:
-                    roofline["algorithmic_bytes"] = alg_bytes
-        except Exception:
-            pass
-        # the two kernels north_star names, with its formulas
+            if "mfma_busy_pct" in pmc[dom]:
+                roofline["mfma_busy_pct_pmc"] = pmc[dom]["mfma_busy_pct"]
+                roofline["mfma_busy_source"] = pmc[dom]["mfma_source"]
+        # algorithmic bytes of the dominant GEMM families at this workload: A operand + output (+ residual) + weight
+        Ltok = B * tokens_per_clip
+        alg_bytes = {"gemm_ff_in": Ltok * (512 + 1408) * 4 + 2816 * 512 * 4,
+                     "gemm_ff_out": Ltok * (1408 + 512 + 512) * 4 + 512 * 1408 * 4,
+                     "gemm_qkv": Ltok * (512 + 1536) * 4 + 1536 * 512 * 4}.get(dom)
+        if alg_bytes:
+            roofline["algorithmic_bytes"] = alg_bytes
+        # the two kernels north_star names, with its formulas: always on the line; the counter-derived
+        # parts are null when the PMC stamp does not match
+        for name in ("attn_spatial", "vq_argmin"):
+            if name in kernels and kernels[name]["ms_per_step"] > 0:
+                k, e = kernels[name], pmc.get(name, {})
+                k["mfma_busy_pct"] = e.get("mfma_busy_pct")
+                tr = e["read_bytes"] + e["write_bytes"] if "read_bytes" in e else None
+                k["traffic_bytes_per_launch"] = tr
+                k["traffic_gbs"] = round(tr * k["launches_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9, 1) if tr else None
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
-            L = B * tokens_per_clip
-            vq_bytes = L * 40 + cfg.n_codes * 32
-            kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3)
-                                                           / 1e9, 2)
-            if "vq_argmin" in pmc and B == 32 and a.frames == 17 and a.resolution == 256 and cfg.n_codes == 8192:
-                # counted memory-side bytes of the sweep (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)
-                kernels["vq_argmin"]["traffic"] = pmc["vq_argmin"]["read_bytes"] + pmc["vq_argmin"]["write_bytes"]
-                kernels["vq_argmin"]["traffic_gbs"] = round(kernels["vq_argmin"]["traffic"]
-                                                            / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 1)
-                kernels["vq_argmin"]["traffic_source"] = pmc["vq_argmin"]["source"]
+            vq_bytes = Ltok * 40 + cfg.n_codes * 32
+            kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 2)
 
         if is_image:
             wl_name = "C2" if (B, a.resolution) == (64, 256) else "images"
@@ -227,7 +245,7 @@ def main():
         # The dominant kernels run at the board's power cap with the clock well under 2400 MHz on real data
         # (profiles/r02_clock_power_probe.txt); this puts the live reading next to the roofline fractions.
         out["clock_power"] = None
-        if world == 1:
+        if world == 1 and not a.no_clock_probe:
             try:
                 from tools import gpu_power
                 torch.cuda.synchronize()

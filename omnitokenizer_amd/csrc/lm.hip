@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
                 const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * S;
                 const float M0 = pp[0], L0 = pp[1];
                 const float q00 = pp[2 + d], q01 = pp[3 + d], q02 = pp[4 + d], q03 = pp[5 + d];
-                const int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+                int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+                if (used > mg.nchunk) used = mg.nchunk;  // a stream stepped past max_len (flagged by the attention kernel,
+                                                         // which clamps the same way): never read past this head's partials
                 float M = M0;
                 for (int c = 1; c < used; ++c) M = fmaxf(M, pp[c * S]);
                 float L = 0.0f;

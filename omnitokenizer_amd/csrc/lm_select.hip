@@ -156,12 +156,19 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
     }
     const float u = p.u[b];
 
-    if (p.top_k < 0) {
-        // ---- unsorted path: multinomial over all V in index order ---------------------------------------
+    // ---- unsorted path: one inverse-CDF draw over the columns whose key is >= thr (index order) -----------------
+    // (multinomial over all V when nothing is filtered; also the form of a top-k draw WITHOUT a nucleus cut when more
+    // columns survive than the sort buffer holds -- top_k = 0 / top_k > 16384 on a large vocabulary, or massive ties at
+    // the k-th value: no order is needed when top_p >= 1)
+    auto unsorted_draw = [&](unsigned thr) {
         const int per = (V + SEL_THREADS - 1) / SEL_THREADS;
         const int i0 = tid * per, i1 = i0 + per < V ? i0 + per : V;
+        auto mass = [&](int i) {
+            const float v = sel_value(p, b, i);
+            return sel_key(v) >= thr ? expf(v - gmax) : 0.0f;
+        };
         float loc = 0.0f;
-        for (int i = i0; i < i1; ++i) loc += expf(sel_value(p, b, i) - gmax);
+        for (int i = i0; i < i1; ++i) loc += mass(i);
         float total;
         const float before = block_exclusive_scan(loc, s_red, &total);
         const float target = u * total;
@@ -171,15 +178,20 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
         // the first non-empty one
         if (loc > 0.0f && before <= target && target < before + loc) {
             float c = before;
-            int pick = i1 - 1;
+            int pick = -1;
             for (int i = i0; i < i1; ++i) {
-                c += expf(sel_value(p, b, i) - gmax);
-                if (c > target) { pick = i; break; }
+                const float m = mass(i);
+                c += m;
+                if (m > 0.0f) pick = i;           // the last column with mass so far (rounding fell off the chunk's end)
+                if (c > target && m > 0.0f) break;
             }
-            atomicMin(&s_count, (unsigned)pick);
+            if (pick >= 0) atomicMin(&s_count, (unsigned)pick);
         }
         __syncthreads();
         if (tid == 0) p.out[b] = s_count == 0x7FFFFFFFu ? gidx : (int64_t)s_count;  // rounding fell off the end: mode
+    };
+    if (p.top_k < 0) {
+        unsorted_draw(0u);
         return;
     }
 
@@ -262,8 +274,13 @@ __global__ __launch_bounds__(SEL_THREADS) void lm_select_kernel(SelParams p) {
     });
     __syncthreads();
     const int n_keep = (int)s_count;
-    if (n_keep > SEL_SORT_MAX) {
-        if (tid == 0) {
+    __syncthreads();  // s_count is reused below
+    if (n_keep > SEL_SORT_MAX) {  // workgroup-uniform
+        if (p.top_p >= 1.0f) {    // no nucleus cut: the draw needs no order
+            unsorted_draw(thr_key);
+            return;
+        }
+        if (tid == 0) {           // a nucleus over more survivors than the sort buffer: reported, never silently greedy
             if (p.err_flag) atomicOr(p.err_flag, 1);
             p.out[b] = gidx;
         }

@@ -192,7 +192,12 @@ class GPT(nn.Module):
     def check_overflow(self):
         """Raises if a decode step since the last check ran past the allocated K/V cache (its logits are
         invalid); one host synchronisation -- the sampling loops call it once at their end."""
-        if self._engine and _lib.load().omnitok_lm_overflowed(self._engine, torch.cuda.current_stream().cuda_stream) > 0:
+        if not self._engine:
+            return
+        rc = _lib.load().omnitok_lm_overflowed(self._engine, torch.cuda.current_stream().cuda_stream)
+        if rc < 0:
+            check(rc, "lm_overflowed")  # a failed read-back is an error, not "no overflow"
+        if rc > 0:
             raise RuntimeError("a stream stepped past the K/V cache length it was allocated with")
 
     @staticmethod
@@ -382,11 +387,16 @@ class GPT(nn.Module):
 
 
 def select_tokens(logits, sample_logits=True, top_k=None, top_p=None, temperature=1.0, logits_uncond=None,
-                  cfg_t=0.0, generator=None, return_logits=False):
+                  cfg_t=0.0, generator=None, return_logits=False, err=None):
     """Token selection of the reference's loops (gpt.py:347-357, CFG blend :428-431) as ONE kernel
     (include/omnitok_lm.h omnitok_lm_select): logits [B, V] (raw, this call divides by temperature) ->
     ids [B] int64.  top_k None: no filtering (like the reference, top_p is then ignored).  Stochastic draws are
-    inverse-CDF lookups with one torch uniform per stream."""
+    inverse-CDF lookups with one torch uniform per stream.
+    A nucleus cut (top_p < 1) over more survivors than the kernel's sort buffer (16384: top_k = 0 or > 16384 on a large
+    vocabulary, or a tie at the k-th value that wide) cannot be evaluated: the kernel raises a device flag instead of
+    silently decoding greedily.  `err` (int32[1] on the device, zeroed by the caller) accumulates it so that a sampling
+    loop reads it back ONCE at its end (check_select_overflow); without `err` this call checks it itself (one host
+    synchronisation, only when top_p < 1).  Without a nucleus cut any number of survivors is sampled exactly."""
     if logits.device.type != "cuda" or logits.dtype != torch.float32:
         raise RuntimeError("select_tokens: logits must be float32 on the GPU (no CPU path)")
     logits = logits.contiguous()
@@ -394,7 +404,9 @@ def select_tokens(logits, sample_logits=True, top_k=None, top_p=None, temperatur
     out = torch.empty(B, dtype=torch.int64, device=logits.device)
     u = torch.rand(B, device=logits.device, generator=generator) if sample_logits else None
     blend = torch.empty(B, V, device=logits.device, dtype=torch.float32) if return_logits else None
-    err = torch.zeros(1, dtype=torch.int32, device=logits.device)
+    own_err = err is None
+    if own_err:
+        err = torch.zeros(1, dtype=torch.int32, device=logits.device)
     lu = None if logits_uncond is None else logits_uncond.contiguous()
     fp = GPT._fp
     # (1 + t) and t enter as fp32 scalars like `(1 + t) * lc - t * lu` on fp32 tensors
@@ -402,10 +414,15 @@ def select_tokens(logits, sample_logits=True, top_k=None, top_p=None, temperatur
                                         -1 if top_k is None else int(top_k), 1.0 if top_p is None else float(top_p),
                                         int(bool(sample_logits)), fp(u), fp(out), fp(blend), fp(err),
                                         torch.cuda.current_stream().cuda_stream), "lm_select")
-    if sample_logits and top_k is not None and top_p is not None and top_p < 1.0 and (top_k == 0 or top_k > 16384):
-        if int(err.item()):  # only this corner can overflow the sort buffer: one readback there
-            raise NotImplementedError("nucleus sampling over more than 16384 surviving logits (set top_k)")
+    if own_err and sample_logits and top_k is not None and top_p is not None and top_p < 1.0:
+        check_select_overflow(err)
     return (out, blend) if return_logits else out
+
+
+def check_select_overflow(err):
+    """Raises if a token selection since `err` was zeroed met a nucleus cut it could not evaluate (select_tokens)."""
+    if int(err.item()):
+        raise NotImplementedError("nucleus sampling (top_p < 1) over more than 16384 surviving logits: lower top_k")
 
 
 @torch.no_grad()
@@ -430,6 +447,8 @@ def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, t
     nxt = x[:, -1].contiguous()
     out = torch.empty(B, steps, dtype=torch.int64, device=model.device)
     all_logits = [] if return_logits else None
+    nucleus = bool(sample_logits) and top_k is not None and top_p is not None and top_p < 1.0
+    sel_err = torch.zeros(1, dtype=torch.int32, device=model.device)
     for n in range(steps):
         if callback is not None:
             callback(n)
@@ -442,13 +461,15 @@ def sample_with_past(x, model: GPT, steps, temperature=1., sample_logits=True, t
             logits = logits_buf
         else:
             logits = model.step(nxt, pos_extra=ex)
-        sel = select_tokens(logits, sample_logits, top_k, top_p, temperature, return_logits=return_logits)
+        sel = select_tokens(logits, sample_logits, top_k, top_p, temperature, return_logits=return_logits, err=sel_err)
         if return_logits:
             nxt, lg = sel
             all_logits.append(lg)
         else:
             nxt = sel
         out[:, n] = nxt
+    if nucleus:
+        check_select_overflow(sel_err)  # one read-back for the whole loop
     return (out, torch.stack(all_logits, 1)) if return_logits else out
 
 
@@ -484,6 +505,8 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
         idx_buf, logits_buf, replay = model.graph_step(2 * B)
     out = torch.empty(B, steps, dtype=torch.int64, device=model.device)
     all_logits = [] if return_logits else None
+    nucleus = bool(sample_logits) and top_k is not None and top_p is not None and top_p < 1.0
+    sel_err = torch.zeros(1, dtype=torch.int32, device=model.device)
     for n in range(steps):
         if callback is not None:
             callback(n)
@@ -498,7 +521,7 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
             logits = model.step(nxt)
         t = cfg_ratio * (n if scale_cfg else 1)
         sel = select_tokens(logits[:B], sample_logits, top_k, top_p, temperature, logits_uncond=logits[B:], cfg_t=t,
-                            return_logits=return_logits)  # blend = (1 + t) * lc - t * lu inside the kernel
+                            return_logits=return_logits, err=sel_err)  # blend = (1 + t) * lc - t * lu inside the kernel
         if return_logits:
             tok, lg = sel
             all_logits.append(lg)
@@ -506,4 +529,6 @@ def sample_with_past_cfg(x, model: GPT, steps, temperature=1., sample_logits=Tru
             tok = sel
         out[:, n] = tok
         nxt = torch.cat((tok, tok)).contiguous()
+    if nucleus:
+        check_select_overflow(sel_err)
     return (out, torch.stack(all_logits, 1)) if return_logits else out

@@ -195,7 +195,8 @@ class Net2NetTransformer(nn.Module):
         """reference lm_transformer.py:200-249.  The reference re-runs the whole sequence through the transformer
         for every new token; here the prefix goes through the K/V cache once and each step is one decode step
         (same logits), with the reference's selection rule: top-k only, then argmax or one multinomial draw."""
-        x = torch.cat((c, x), dim=1).long().to(self.device)
+        x_prefix = x.long().to(self.device)  # returned in front of the samples: the reference returns x[:, c.shape[1]:] (:247)
+        x = torch.cat((c.to(self.device), x_prefix), dim=1).long()
         t = self.transformer
         assert x.shape[1] + steps - 1 <= t.get_block_size()  # "make sure model can see conditioning"
         if self.pkeep <= 0.0:
@@ -213,7 +214,7 @@ class Net2NetTransformer(nn.Module):
                                 temperature=temperature)
             out.append(nxt)
         t.check_overflow()
-        return torch.stack(out, 1)
+        return torch.cat((x_prefix, torch.stack(out, 1)), dim=1)
 
     def get_input(self, key, batch):
         return batch[key]

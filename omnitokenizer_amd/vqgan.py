@@ -121,7 +121,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         self._engine = None
         self._engine_sig = None
         self._engine_dev = None
-        self._version = getattr(self, "_version", 0)
+        self._weights_epoch = getattr(self, "_weights_epoch", 0)
         self._timing = False
         self._workspace = None  # uint8 tensor of PyTorch's caching allocator lent to the engine (grow-only)
         self._workspace_stream = None
@@ -147,7 +147,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         sd = {k: v for k, v in state_dict.items() if not k.startswith(_OFF_PATH_PREFIXES)}
         out = super().load_state_dict(sd, strict=bool(strict), assign=assign)
         self._engine_sig = None
-        self._version += 1
+        self._weights_epoch += 1
         if out.missing_keys:
             msg = (f"state_dict lacks {len(out.missing_keys)} tensors of the encode/decode path, e.g. "
                    f"{out.missing_keys[:4]}")
@@ -204,21 +204,24 @@ class OmniTokenizer_VQGAN(nn.Module):
         return nc
 
     def _signature(self):
-        """Cheap change detector for the engine's weight copies: a version counter bumped by
-        load_state_dict / _apply (.to(), .cuda(), .float()), plus the storage pointer and in-place version of
-        ONE sentinel tensor per sub-module group.  Walking the whole state_dict on every encode/decode cost
-        more host time than a single-image encode's launches; in-place edits of individual parameters after
-        the first encode need mark_weights_changed()."""
-        sent = (self.encoder.enc_spatial_transformer.norm_out.gamma, self.decoder.dec_spatial_transformer.norm_out.gamma)
-        return (self._version,) + tuple((t.data_ptr(), t._version) for t in sent)
+        """Change detector for the engine's weight copies: an epoch counter bumped by load_state_dict / _apply (.to(),
+        .cuda(), .float()) plus the storage pointer and in-place version of EVERY parameter and buffer on the path
+        (p.data.copy_(), an EMA swap, partial weight surgery after the first encode are all seen).  The tensor list is
+        cached per epoch: reading ~300 (data_ptr, _version) pairs costs tens of microseconds, the state_dict() walk that
+        used to be here cost more host time than a single-image encode's launches."""
+        cached = getattr(self, "_sig_tensors", None)
+        if cached is None or cached[0] != self._weights_epoch:
+            cached = (self._weights_epoch, [t for t in list(self.parameters()) + list(self.buffers())])
+            self._sig_tensors = cached
+        return (self._weights_epoch,) + tuple((t.data_ptr(), t._version) for t in cached[1])
 
     def mark_weights_changed(self):
         """Call after editing parameters in place so that the next encode/decode re-uploads them."""
-        self._version += 1
+        self._weights_epoch += 1
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
-        self._version = getattr(self, "_version", 0) + 1
+        self._weights_epoch = getattr(self, "_weights_epoch", 0) + 1
         return out
 
     def _sync_engine(self):
@@ -265,13 +268,20 @@ class OmniTokenizer_VQGAN(nn.Module):
         if self._workspace is not None and self._workspace.numel() >= need:
             # used from a stream other than the one it was allocated on: tell the caching allocator, so that it
             # does not recycle the block under a running kernel once the module is gone
-            if cur != self._workspace_stream and not torch.cuda.is_current_stream_capturing():
+            if torch.cuda.is_current_stream_capturing():
+                self._workspace_captured = True  # a HIP graph now holds this block's addresses
+            elif cur != self._workspace_stream:
                 self._workspace.record_stream(cur)
             return
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("the engine workspace has to grow for this shape, which needs a synchronisation: run "
                                "one eager encode/decode of the same shape before capturing a HIP graph")
         cur.synchronize()  # kernels of earlier calls may still read the old block
+        if getattr(self, "_workspace_captured", False):
+            # a captured graph replays with the old block's addresses baked in: keep it alive for the module's lifetime
+            # instead of returning it to the caching allocator (a later replay would read and write recycled memory)
+            self._retired_workspaces = getattr(self, "_retired_workspaces", []) + [self._workspace]
+            self._workspace_captured = False
         self._workspace = None
         self._workspace = torch.empty(int(need * 1.02) + 256, dtype=torch.uint8, device=self.device)
         self._workspace_stream = cur

@@ -194,9 +194,10 @@ def test_error_behaviour(models):
     assert m.encode(torch.zeros(0, 3, 5, 64, 64, device="cuda"), False).shape == (0, 2, 8, 8)
 
 
-def test_in_place_weight_edit_needs_mark_weights_changed(models):
-    """The engine holds its own copies of the weights; the change detector is a version counter (load_state_dict,
-    .to()) plus a sentinel, not a walk over the state_dict on every call."""
+def test_in_place_weight_edits_are_seen(models):
+    """The engine holds its own copies of the weights; the change detector reads the (storage pointer, in-place version)
+    of every parameter and buffer (cached tensor list, no state_dict() walk per call): an in-place edit of ANY tensor
+    after the first encode re-uploads the weights without mark_weights_changed()."""
     from omnitokenizer_amd import OmniTokenizer_VQGAN
     c = GoldenCase("s2_sdpa_r64_img")
     m = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
@@ -205,8 +206,7 @@ def test_in_place_weight_edit_needs_mark_weights_changed(models):
     x = c.x.cuda()
     ids0 = m.encode(x, True)
     with torch.no_grad():
-        getattr(m.pre_vq_conv, "1").weight.mul_(-1.0)
-    m.mark_weights_changed()
+        getattr(m.pre_vq_conv, "1").weight.mul_(-1.0)   # not one of the old sentinel tensors
     ids1 = m.encode(x, True)
     assert not torch.equal(ids0, ids1)
     m.load_state_dict(c.sd)                 # reloading bumps the version by itself
@@ -517,6 +517,17 @@ def test_hip_graph_capture_and_side_stream(models):
     torch.cuda.synchronize()
     assert torch.equal(ids_g, ids2) and torch.equal(rec_g, rec2)
     assert torch.equal(ids2.cpu(), torch.roll(c.ids, 1, dims=0))
+    # a LARGER eager call afterwards makes the workspace grow; the captured graph still holds the old block's addresses,
+    # so that block is kept alive (not handed back to the caching allocator) and a replay stays correct
+    big = torch.cat([x2] * 4).contiguous()
+    ids_big = m.encode(big, False)
+    m.decode(ids_big, False)
+    scratch = [torch.full((1 << 22,), 7.0, device="cuda") for _ in range(8)]  # would land in a recycled block
+    x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(ids_g, ids2) and torch.equal(rec_g, rec2)
+    del scratch
 
 
 # ---- --use_external_codebook: VectorQuantize / cosine similarity -----------------

@@ -461,6 +461,13 @@ def test_net2net_transformer_forward_and_sample(starts_with_sos, class_first):
         nxt = go.forward(gsd, seq, H)[:, -1].argmax(-1, keepdim=True)
         seq = torch.cat((seq, nxt), 1)
     assert torch.equal(got.cpu(), seq[:, prefix + 1:])
+    # a non-empty x prefix (half-conditioned completion): the reference returns x[:, c.shape[1]:], i.e. the given prefix
+    # followed by the samples (lm_transformer.py:247)
+    got2 = net.sample(zi[:, :3].cuda(), cz[:, :prefix + 1].cuda(), steps, temperature=1.0, sample=False, top_k=20)
+    seq2 = torch.cat((cz[:, :prefix + 1], zi[:, :3]), 1)
+    for _ in range(steps):
+        seq2 = torch.cat((seq2, go.forward(gsd, seq2, H)[:, -1].argmax(-1, keepdim=True)), 1)
+    assert tuple(got2.shape) == (cz.shape[0], 3 + steps) and torch.equal(got2.cpu(), seq2[:, prefix + 1:])
     # and the sampled ids decode through the tokenizer like transformer_eval.py:68-69
     index = torch.clamp(got - n_cls - (1 if starts_with_sos else 0), min=0, max=net.first_stage_model.n_codes - 1)
     pix = net.first_stage_model.decode(torch.cat((index, index[:, :2].repeat(1, 29)), 1)[:, :64], is_image=True)

@@ -64,6 +64,10 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--h2dbg")) h2dbg = argv[++i];  // ablation builds of the h2 kernel (plain shapes only)
         else if (!strcmp(argv[i], "--pp")) with_pp = true;        // the r02 measurement kernel gemm_pp
         else if (!strcmp(argv[i], "--rows")) L = atoll(argv[++i]);
+        else if (!strcmp(argv[i], "--opt")) {  // --opt name value: omnitok_set_option
+            const char *n = argv[++i];
+            OK(omnitok_set_option(n, atoi(argv[++i])));
+        }
     }
     printf("%s\n", omnitok_version());
     hipStream_t st;
