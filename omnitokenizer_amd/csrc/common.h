@@ -44,6 +44,11 @@ int set_max_dynamic_lds(const void *kernel, int bytes);
 // multiprocessor count of the current device (cached per device)
 int current_device_cus(int *n_cu);
 
+// fills n 32-bit words with `value` by a kernel.  Used instead of hipMemsetAsync on every path that may be captured into a
+// HIP graph: a replayed graph's memset nodes were observed to stop taking effect once an eager call had run between two
+// replays (ROCm 7.2, tests/test_gpu_e2e.py::test_hip_graph_capture_and_side_stream), kernel nodes do not.
+int device_fill_u32(void *ptr, unsigned value, int64_t n_words, hipStream_t stream);
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -101,6 +101,7 @@ struct omnitok_engine {
     std::map<std::string, std::vector<int64_t>> spec;  // required key -> shape
     std::map<std::string, DevTensor> w;
     std::vector<void *> owned;  // derived buffers
+    std::vector<void *> retired;  // outgrown blocks a captured graph may still address (freed with the engine)
     bool finalized = false;
     int inner_pad = 0;
     TransformerW enc_s, enc_t, dec_s, dec_t;
@@ -1055,14 +1056,17 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
 // range slots of the fp16-split GEMMs: per clip, zeroed once per encode / decode (atomic max targets)
 static int reset_bounds(omnitok_engine *e, int B, hipStream_t stream) {
     if (B > e->bound_cap) {
-        if (e->bounds) OT_HIP(hipFree(e->bounds));
+        // grow-only, and the old block stays allocated until the engine dies: a HIP graph captured at a smaller batch has
+        // its address baked in (freeing it would hand the replay recycled memory).  512 B per clip: sized generously.
+        if (e->bounds) e->retired.push_back(e->bounds);
         e->bounds = nullptr;
-        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->bounds), (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float)));
-        e->bound_cap = B;
+        const int cap = B > 1024 ? B : 1024;
+        OT_HIP(hipMalloc(reinterpret_cast<void **>(&e->bounds), (size_t)2 * cap * N_BOUND_LAUNCHES * sizeof(float)));
+        e->bound_cap = cap;
     }
     e->bound_clips = B;
     e->bound_next = 0;
-    OT_HIP(hipMemsetAsync(e->bounds, 0, (size_t)2 * B * N_BOUND_LAUNCHES * sizeof(float), stream));
+    if (int rc = device_fill_u32(e->bounds, 0u, (int64_t)2 * B * N_BOUND_LAUNCHES, stream)) return rc;
     return OMNITOK_OK;
 }
 
@@ -1254,6 +1258,7 @@ extern "C" void omnitok_engine_destroy(omnitok_engine *e) {
             if (b->p) (void)hipFree(b->p);
     if (e->err_flag) (void)hipFree(e->err_flag);
     if (e->bounds) (void)hipFree(e->bounds);
+    for (void *p : e->retired) (void)hipFree(p);
     if (e->range_scratch) (void)hipFree(e->range_scratch);
     for (auto &r : e->recs) {
         (void)hipEventDestroy(r.a);
@@ -1583,7 +1588,7 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
 
     if (kind == LatentKind::Ids) {
         // the out-of-range flag reports on THIS decode only (omnitok_engine_check_ids)
-        OT_HIP(hipMemsetAsync(e->err_flag, 0, sizeof(int), stream));
+        if (int rc = device_fill_u32(e->err_flag, 0u, 1, stream)) return rc;
     }
     // ids straight into the temporal stage's '(b h w) t' order when nothing sits between (no deferred up-sampling)
     const bool fuse_first_transpose = kind == LatentKind::Ids && !g.defer_t && !g.defer_s && T > 1;
@@ -1748,7 +1753,7 @@ extern "C" int omnitok_engine_check_ids(omnitok_engine *e, omnitok_stream_t stre
     OT_HIP(hipMemcpyAsync(&flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     OT_HIP(hipStreamSynchronize(stream));
     if (flag) {
-        OT_HIP(hipMemsetAsync(e->err_flag, 0, sizeof(int), stream));
+        if (int rc = device_fill_u32(e->err_flag, 0u, 1, stream)) return rc;
         set_error("decode: token id out of range [0, %d)", e->cfg.n_codes);
         return OMNITOK_ERR_INVALID;
     }

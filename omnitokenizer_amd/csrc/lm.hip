@@ -886,7 +886,8 @@ extern "C" int omnitok_lm_overflowed(omnitok_lm *lm, omnitok_stream_t stream_) {
     int h = 0;
     OT_HIP(hipMemcpyAsync(&h, lm->err_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     OT_HIP(hipStreamSynchronize(stream));
-    if (h) OT_HIP(hipMemsetAsync(lm->err_flag, 0, sizeof(int), stream));
+    if (h)
+        if (int rc = device_fill_u32(lm->err_flag, 0u, 1, stream)) return rc;
     return h ? 1 : 0;
 }
 

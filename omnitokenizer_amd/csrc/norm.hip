@@ -244,6 +244,19 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const f32x4 *__re
     }
 }
 
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned *__restrict__ p, unsigned value, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = value;
+}
+
+int device_fill_u32(void *ptr, unsigned value, int64_t n_words, hipStream_t stream) {
+    if (n_words <= 0) return OMNITOK_OK;
+    int64_t blocks = (n_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, static_cast<unsigned *>(ptr), value, n_words);
+    OT_LAUNCH_CHECK("fill_u32");
+    return OMNITOK_OK;
+}
+
 }  // namespace omnitok
 
 using namespace omnitok;

@@ -507,7 +507,7 @@ extern "C" int omnitok_vq_stats(const int64_t *ids, int64_t n, int n_codes, int 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(ids && counts_scratch && batch_usage && codebook_usage && out2 && n > 0 && n_codes > 0,
                  "vq_stats: bad arguments");
-    OT_HIP(hipMemsetAsync(counts_scratch, 0, (size_t)n_codes * sizeof(int), stream));
+    if (int rc = device_fill_u32(counts_scratch, 0u, n_codes, stream)) return rc;
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(vq_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, ids, n, n_codes, counts_scratch);
@@ -567,7 +567,7 @@ static int launch_vq(const float *z, const float *packed, const float *ee, int64
         OT_LAUNCH_CHECK("vq_argmin");
         return OMNITOK_OK;
     }
-    OT_HIP(hipMemsetAsync(ids, 0xFF, (size_t)n * 8, stream));
+    if (int rc = device_fill_u32(ids, 0xFFFFFFFFu, n * 2, stream)) return rc;
     hipLaunchKernelGGL((vq_argmin_kernel<true, MODE>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
     OT_LAUNCH_CHECK("vq_argmin");
     hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n);

@@ -340,6 +340,55 @@ def test_select_kernel_vs_reference_semantics(V, top_k, top_p, temp):
     assert int(err.item()) == 0
 
 
+@pytest.mark.parametrize("top_k", [0, 17000])
+def test_select_more_survivors_than_the_sort_buffer(top_k):
+    """More than 16384 surviving logits (top_k = 0 keeps everything, top_k > 16384 on a large vocabulary -- the vtokens
+    models have V = 16384 + class_cond_dim): without a nucleus cut the draw needs no sort and must stay a draw from the
+    filtered softmax (it used to return the argmax silently); with a nucleus cut it raises."""
+    from omnitokenizer_amd import gpt as og
+    B, V = 4, 20000
+    lg = rnd(B, V, seed=77, scale=2.0)
+    d = lg.cuda()
+    lib = __import__("omnitokenizer_amd")._lib.load()
+    out = torch.empty(B, dtype=torch.int64, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    from omnitokenizer_amd._lib import check
+    vals = lg.double()
+    keep = torch.ones_like(vals, dtype=torch.bool)
+    if top_k:
+        kth = vals.topk(top_k, dim=-1).values[:, -1:]
+        keep = vals >= kth
+    pr = torch.where(keep, torch.exp(vals - vals.max(-1, keepdim=True).values), torch.zeros_like(vals))
+    cdf = pr.cumsum(-1)  # index order: what a draw without a sort walks
+    g = torch.Generator().manual_seed(5)
+    agree = total = 0
+    seen = set()
+    for _ in range(25):
+        u = torch.rand(B, generator=g, dtype=torch.float64).float()
+        check(lib.omnitok_lm_select(_p(d), None, B, V, 1.0, 1.0, 0.0, top_k, 1.0, 1, _p(u.cuda()), _p(out), None, _p(err),
+                                    torch.cuda.current_stream().cuda_stream), "lm_select")
+        got = out.cpu()
+        for b in range(B):
+            tgt = float(u[b]) * float(cdf[b, -1])
+            want = int((cdf[b] > tgt).nonzero()[0])
+            edge = (cdf[b] - tgt).abs().min().item() < 1e-5 * float(cdf[b, -1])
+            assert bool(keep[b, got[b]])
+            seen.add(int(got[b]))
+            if not edge:
+                total += 1
+                agree += int(got[b]) == want
+    assert agree == total and len(seen) > 50, (agree, total, len(seen))  # a draw, not the argmax
+    assert int(err.item()) == 0
+    # the same filter with a nucleus cut cannot be evaluated: reported, never silently greedy
+    with pytest.raises(NotImplementedError, match="nucleus"):
+        og.select_tokens(d, sample_logits=True, top_k=top_k, top_p=0.9)
+    # ... and a sampling loop reads the flag once at its end through the shared err tensor
+    e2 = torch.zeros(1, dtype=torch.int32, device="cuda")
+    og.select_tokens(d, sample_logits=True, top_k=top_k, top_p=0.9, err=e2)
+    with pytest.raises(NotImplementedError):
+        og.check_select_overflow(e2)
+
+
 def test_select_kernel_cfg_blend_and_errors():
     from omnitokenizer_amd import gpt as og
     B, V = 3, 1000
