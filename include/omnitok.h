@@ -39,36 +39,23 @@ enum omnitok_status {
     OMNITOK_ERR_UNSUPPORTED = -4  /* configuration outside the built path  */
 };
 
-/* Measurement kernel (csrc/gemm_pp.hip): c[M, N] = a . w^T with BOTH operands as packed fp16 hi|lo planes
- * (omnitok_h2_pack_weight layout and row scales), staged by LDS-DMA only.  M % 128 == 0, N % 256 == 0, K % 32 == 0. */
-int omnitok_gemm_pp(const void *a_planes, const float *a_scale, const void *w_planes, const float *w_scale,
-                    float *c, int64_t ldc, int64_t M, int N, int K, omnitok_stream_t stream);
-
 const char *omnitok_last_error(void);
 /* "omnitok <version> gfx950 ..." */
 const char *omnitok_version(void);
-/* Switches (process-global).  Arithmetic modes -- every mode holds the parity bars of tests/:
- *   "gemm_mode"  2 (default) fp32 operands as 2 fp16 planes, 3 fp16-MFMA products (gemm_h2.hip) | 1 three bf16 planes, 6
- *                products (gemm_x3.hip) | 0 fp32-input MFMA (gemm.hip)
+/* Process-wide DEFAULTS of the arithmetic / data-flow modes (an engine follows them unless omnitok_engine_set_option gave
+ * it its own value: two engines of one process can run different modes) -- every mode holds the parity bars of tests/:
+ *   "gemm_mode"  2 (default) fp32 operands as 2 fp16 planes, 3 fp16-MFMA products (gemm_h2.hip, gemm_pl.h) | 1 three bf16
+ *                planes, 6 products (gemm_x3.hip) | 0 fp32-input MFMA (gemm.hip)
  *   "attn_mode"  1 (default) spatial attention on the fp16 matrix cores from split operands (attn_h2.hip) | 0 fp32 MFMA
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
- * Tuning knobs for A/B measurements (not part of the functional contract): "gemm_variant" (0 one tile per workgroup |
- * 1 persistent 128x128 | 2 persistent 256x128, +4 forces it whatever the size), "gemm_small" (1: 64x128 tiles when the
- * 128x128 tiling has fewer workgroups than CUs), "gemm_gn", "gemm_lds_pad_kb", "x3_tile", "h2_tile" (0 auto | 1 256x256
- * | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "attn_h2_variant" (1 LDS-DMA pipelined | 0 register staged),
- * "vq_split", "peg_variant", "lm_wide_u" (2 | 4 chunks per register buffer of the wide LM GEMVs); "x3_dbg" / "h2_dbg"
- * select the wrong-result ablation builds of tools/x3_ablate.py and tools/h2_bench.py.
- * Unknown names return OMNITOK_ERR_INVALID. */
+ *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
+ *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
+ * Tuning knobs of the stand-alone kernel entry points for A/B measurements (process-wide; results do not depend on them --
+ * tests check bitwise independence of the tile shape): "gemm_variant", "gemm_small", "gemm_gn", "gemm_lds_pad_kb",
+ * "x3_tile", "h2_tile" (0 auto | 1 256x256 | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "pl_cfg" (0 auto | 1 256x256 |
+ * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "peg_variant", "lm_wide_u"; "x3_dbg" / "h2_dbg" select
+ * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
-/* Measurement only: device buffer of 4 x 96 int64; workgroup 0 of the persistent GEMM stores
- * s_memtime stamps (3 per K-step per wave: stream start, stream end, loop end). NULL = off. */
-int omnitok_debug_set_gemm_trace(long long *dev_ptr);
-/* Measurement only: pure v_mfma_f32_32x32x2_f32 stream (4 accumulators per wave, operands from
- * `in`[4096]) to find the sustained fp32-MFMA ceiling of the chip. out[blocks*256]. */
-int omnitok_debug_mfma_peak(const float *in, float *out, int blocks, int iters, int lds_bytes,
-                            long long *clk, omnitok_stream_t stream);
-
-
 /* ------------------------------------------------------------------------------------------
  * Per-operator entry points (each is one HIP kernel family; the engine below chains them).
  * They are exported so that every operator is parity-tested against the oracle on its own.
@@ -531,6 +518,8 @@ int omnitok_engine_set_workspace(omnitok_engine *e, void *dev_ptr, int64_t bytes
 /* Per-kernel timing: when enabled, every launch made by encode/decode is bracketed with HIP
  * events on its stream; omnitok_engine_timing_report fills a '\n'-separated
  * "name calls total_ms" list (synchronises). */
+/* Per-engine value of "gemm_mode" | "attn_mode" | "attn_vpack" | "gemm_pl" (value -1: follow the process default again). */
+int omnitok_engine_set_option(omnitok_engine *e, const char *name, int value);
 int omnitok_engine_set_timing(omnitok_engine *e, int enabled);
 int omnitok_engine_timing_report(omnitok_engine *e, char *buf, int buflen);
 

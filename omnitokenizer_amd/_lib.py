@@ -111,6 +111,7 @@ _PROTOS = {
     "omnitok_engine_workspace_need_decode": [P, c_int, c_int, c_int, c_int],
     "omnitok_engine_set_workspace": [P, P, I64],
     "omnitok_engine_set_timing": [P, c_int],
+    "omnitok_engine_set_option": [P, c_char_p, c_int],
     "omnitok_engine_timing_report": [P, c_char_p, c_int],
     # include/omnitok_lm.h
     "omnitok_lm_create": [POINTER(OmnitokLmConfig), POINTER(P)],
@@ -127,7 +128,6 @@ _PROTOS = {
     "omnitok_lm_select": [P, P, c_int, c_int, c_float, c_float, c_float, c_int, c_float, c_int, P, P, P, P, P],
     "omnitok_lm_gemv": [P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P],
     "omnitok_lm_attn_decode": [P, P, P, P, c_int, c_int, c_int, c_int, P, P, P],
-    "omnitok_gemm_pp": [P, P, P, P, P, I64, I64, c_int, c_int, P],
     "omnitok_pl_planes_bytes": [I64, c_int, c_int],
     "omnitok_pl_unscale": [c_float],
     "omnitok_pl_pack_weight": [P, I64, c_int, c_int, c_int, P, P, P],

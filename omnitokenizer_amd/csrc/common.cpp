@@ -1,5 +1,6 @@
 // Error reporting shared by all C-ABI entry points.
 #include "common.h"
+#include "../../include/omnitok_debug.h"
 #include <string.h>
 
 namespace omnitok {

@@ -1,6 +1,7 @@
 // Measurement-only kernels (not on the product path): practical fp32-MFMA ceiling of this chip under
 // sustained load on non-trivial data, to put the GEMM / attention numbers in context.
 #include "common.h"
+#include "../../include/omnitok_debug.h"
 
 namespace omnitok {
 

@@ -102,6 +102,9 @@ struct omnitok_engine {
     std::map<std::string, DevTensor> w;
     std::vector<void *> owned;  // derived buffers
     std::vector<void *> retired;  // outgrown blocks a captured graph may still address (freed with the engine)
+    // arithmetic / data-flow modes of THIS engine: -1 = follow the process default (omnitok_set_option), else the value
+    // given to omnitok_engine_set_option.  Two engines of one process can run different modes.
+    int opt_gemm_mode = -1, opt_attn_mode = -1, opt_attn_vpack = -1, opt_gemm_pl = -1;
     bool finalized = false;
     int inner_pad = 0;
     TransformerW enc_s, enc_t, dec_s, dec_t;
@@ -677,8 +680,13 @@ int g_attn_vpack = 1;
 // r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
 int g_gemm_pl = 1;
 
-static bool x3_ok(int N, int K, int flags) {
-    return g_gemm_mode >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
+static int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->opt_gemm_mode : g_gemm_mode; }
+static int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
+static int attn_vpack_of(const omnitok_engine *e) { return e->opt_attn_vpack >= 0 ? e->opt_attn_vpack : g_attn_vpack; }
+static int gemm_pl_of(const omnitok_engine *e) { return e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl; }
+
+static bool x3_ok(const omnitok_engine *e, int N, int K, int flags) {
+    return gemm_mode_of(e) >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
            (!(flags & OMNITOK_GEMM_GEGLU) || N % 64 == 0);
 }
 
@@ -697,7 +705,7 @@ static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *
                    const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
                    int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0,
                    const VPack *vpk = nullptr, bool *vpacked = nullptr) {
-    if (g_gemm_mode == 2 && ab.stat > 0.0f && x3_ok(N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
+    if (gemm_mode_of(e) == 2 && ab.stat > 0.0f && x3_ok(e, N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
         (!ab.dev || (ab.rpc > 0 && ab.rpc % 64 == 0 && rpg == 0))) {
         auto it = e->h2w.find(w);
         if (it != e->h2w.end() && ldw == K) {
@@ -713,7 +721,7 @@ static int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *
                                    ln_bound, c2, ldc2, split_col, stream);
         }
     }
-    if (x3_ok(N, K, flags))
+    if (x3_ok(e, N, K, flags))
         return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
                                ln_stats, ln_g, ln_b, ln_cols, c2, ldc2, split_col, stream);
     if (ln_stats) {
@@ -748,11 +756,11 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
     int S = gh * gw;
     double gemm_f = 2.0 * (double)L * D;
     // split-operand GEMMs apply the LayerNorm while staging their A operand (no LN pass over HBM)
-    const bool fused = x3_ok(3 * D, D, 0) && D <= 512;
+    const bool fused = x3_ok(e, 3 * D, D, 0) && D <= 512;
     // Plane data flow (gemm_pl.h): attention output -> planes (AO) -> to_out / proj with the residual add and the
     // FeedForward's LayerNorm in its epilogue (x in place, LN(x) planes -> Y) -> FF-in with the GEGLU hidden as planes
     // (HD) -> FF-out (+ residual).  Needs full-row tiles for the LayerNorm epilogue (dim 512 = the reference's only width).
-    const bool pl = g_gemm_pl && g_gemm_mode == 2 && fused && D == 512 && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    const bool pl = gemm_pl_of(e) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
     bool ln_planes_ready = false;  // Y holds the planes of the FeedForward's LayerNorm(x) for the current x
     // producers that cannot write planes themselves: fp32 rows -> planes with one power-of-two scale per row
     auto pack_rows = [&](const float *src, void *planes, float *scales) -> int {
@@ -856,7 +864,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 // (causal or not, with or without ALiBi), so the attention output is V bit for bit:
                 // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
                 // half and the attention kernel drop out.  Identical results to the general path.
-                if (bs && g_gemm_mode == 2)  // only the ranges are needed here
+                if (bs && gemm_mode_of(e) == 2)  // only the ranges are needed here
                     OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
                        eg_gemm(e, e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D, 0, 0,
@@ -876,7 +884,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             // fp16-split spatial attention (attn_h2.hip): Q, K (RoPE + l2norm + scales applied) and V as hi|lo planes
             // in MFMA fragment order (Y, HD are free here); |V| <= ||x_row|| ||Wv_j|| per clip from the row statistics
             const float qb = 1.01f * 8.0f * ly.t.q_amax, kb = 1.01f * ly.t.k_amax;
-            const bool attn_h2 = spatial && g_attn_mode == 1 && bs && S % 64 == 0 && qb > 0.0f && kb > 0.0f &&
+            const bool attn_h2 = spatial && attn_mode_of(e) == 1 && bs && S % 64 == 0 && qb > 0.0f && kb > 0.0f &&
                                  ly.t.vnorm > 0.0f && qb < 1e30f && kb < 1e30f;
             unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
             unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
@@ -893,7 +901,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
                 // kernels read rows of D / 2D floats (with a [L, 3D] row pitch spatial attention ran 15 % slower)
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
                        eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, Q, D, L, 3 * D, D, 0, 0, 0, 0, stream, ab_x,
-                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D, attn_h2 && g_attn_vpack ? &vpk : nullptr,
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D, attn_h2 && attn_vpack_of(e) ? &vpk : nullptr,
                                &vpacked));
             } else if (fused) {
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
@@ -1020,7 +1028,7 @@ static int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int
             h.N = D;
             h.K = e->inner_pad;
             OT_RUN("gemm_ff_out", gemm_f * c.ff_inner, eg_gemm_pl(e, h, ly.ff.w2p, stream));
-        } else if (fused && x3_ok(2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
+        } else if (fused && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
             OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
             OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
                    eg_gemm(e, e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
@@ -1738,6 +1746,26 @@ extern "C" int64_t omnitok_engine_workspace_bytes(omnitok_engine *e) {
     int64_t n = 0;
     for (Buf *b : {&e->X, &e->X2, &e->Y, &e->QKV, &e->AO, &e->HD, &e->Z, &e->ST}) n += b->cap * 4;
     return n;
+}
+
+extern "C" int omnitok_engine_set_option(omnitok_engine *e, const char *name, int value) {
+    OT_CHECK_ARG(e && name, "engine_set_option: null pointer");
+    OT_CHECK_ARG(value >= -1, "engine_set_option: value %d (-1 = follow the process default)", value);
+    const std::string n(name);
+    if (n == "gemm_mode") {
+        OT_CHECK_ARG(value <= 2, "engine_set_option: gemm_mode %d", value);
+        e->opt_gemm_mode = value;
+    } else if (n == "attn_mode") {
+        e->opt_attn_mode = value;
+    } else if (n == "attn_vpack") {
+        e->opt_attn_vpack = value;
+    } else if (n == "gemm_pl") {
+        e->opt_gemm_pl = value;
+    } else {
+        set_error("engine_set_option: %s is not a per-engine option (gemm_mode, attn_mode, attn_vpack, gemm_pl)", name);
+        return OMNITOK_ERR_INVALID;
+    }
+    return OMNITOK_OK;
 }
 
 extern "C" int omnitok_engine_set_timing(omnitok_engine *e, int enabled) {

@@ -150,16 +150,6 @@ def h2_pack_weight(weight):
     return planes, scale
 
 
-def linear_pp(a_packed, w_packed, M, N):
-    """c [M, N] = a . w^T with BOTH operands as the packed fp16 hi|lo planes of h2_pack_weight (measurement kernel of
-    csrc/gemm_pp.hip: M % 128 == 0, N % 256 == 0)."""
-    (ap, asc), (wp, wsc) = a_packed, w_packed
-    K = ap.shape[1] * 32
-    c = torch.empty(M, N, device=ap.device, dtype=torch.float32)
-    check(_lib.load().omnitok_gemm_pp(_p(ap), _p(asc), _p(wp), _p(wsc), _p(c), N, M, N, K, _stream()), "gemm_pp")
-    return c
-
-
 def linear_h2(x, packed, a_bound, bias=None, residual=None, geglu=False, a_bound_dev=None, ln=None, ln_cols=None,
               ln_bound=0.0, a_bound_stride=1, rows_per_clip=0):
     """y = x @ weight.T (+epilogue) from 2-way fp16 splits of both operands (three fp16 MFMA products, fp32

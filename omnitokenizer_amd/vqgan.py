@@ -215,6 +215,12 @@ class OmniTokenizer_VQGAN(nn.Module):
             self._sig_tensors = cached
         return (self._weights_epoch,) + tuple((t.data_ptr(), t._version) for t in cached[1])
 
+    def set_option(self, name: str, value: int):
+        """Arithmetic / data-flow mode of THIS module's engine ("gemm_mode", "attn_mode", "attn_vpack", "gemm_pl"; -1 =
+        follow the process default of _lib.set_option again): modules of one process can run different modes."""
+        self._sync_engine()
+        check(_lib.load().omnitok_engine_set_option(self._engine, name.encode(), int(value)), "engine_set_option")
+
     def mark_weights_changed(self):
         """Call after editing parameters in place so that the next encode/decode re-uploads them."""
         self._weights_epoch += 1

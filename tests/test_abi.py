@@ -18,8 +18,9 @@ def lib():
 
 def test_header_symbols_exported(lib):
     from omnitokenizer_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "omnitok.h")).read() + \
-        open(os.path.join(ROOT, "include", "omnitok_lm.h")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("omnitok.h", "omnitok_lm.h", "omnitok_debug.h"))
+    # the measurement-only entry points live in their own header, outside the drop-in boundary
+    assert "omnitok_debug_" not in open(os.path.join(ROOT, "include", "omnitok.h")).read()
     declared = set(re.findall(r"\b(omnitok_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"omnitok_stream_t"}
     assert len(declared) >= 30
@@ -265,4 +266,15 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
     assert lib.omnitok_layernorm_transposed(one, one, None, one, 2, 3, 4, 512, f(1e-5), None) == -1
     # set_workspace: pointer / size mismatch and alignment are rejected on a null engine too
     assert lib.omnitok_engine_set_workspace(None, None, 0) == -1
-    assert lib.omnitok_gemm_pp(one, one, one, one, one, 256, 100, 256, 64, None) == -1
+    # plane GEMM: null argument block / null operands, the LayerNorm epilogue's full-row rule; per-engine options
+    from omnitokenizer_amd._lib import OmnitokPlGemm
+    assert lib.omnitok_gemm_pl(None, None) == -1
+    g = OmnitokPlGemm()
+    g.a = g.w = g.w_scale = g.c = g.out_planes = g.ln_gamma = 256
+    g.M, g.N, g.K, g.ldc, g.epilogue, g.out_planes_k, g.out_bound = 64, 256, 512, 256, 2, 256, 30.0
+    assert lib.omnitok_gemm_pl(C.byref(g), None) == -1 and b"512" in lib.omnitok_last_error()
+    g.epilogue, g.N = 7, 512
+    assert lib.omnitok_gemm_pl(C.byref(g), None) == -1
+    assert lib.omnitok_pl_pack_weight(one, 512, 500, 512, 512, one, one, None) == -1   # N % 32
+    assert lib.omnitok_pl_planes_bytes(1000, 512, 256) == 1024 * 512 * 4 and lib.omnitok_pl_planes_bytes(10, 500, 256) == -1
+    assert lib.omnitok_engine_set_option(None, b"gemm_mode", 1) == -1

@@ -126,6 +126,50 @@ def test_heavy_statistics_vs_reference_golden(models, name, modes):
     assert torch.isfinite(recon).all()
 
 
+def test_two_engines_with_different_modes_in_one_process():
+    """The arithmetic / data-flow modes are per-engine fields (omnitok_engine_set_option): two modules of one process run
+    different modes side by side, each bit-identical to a run of that mode selected process-wide."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib
+    c = GoldenCase("s2_sdpa_r64_vid")
+
+    def build():
+        m = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
+        m.load_state_dict(c.sd, strict=True)
+        return m.cuda().eval()
+    a, b = build(), build()
+    x = c.x.cuda()
+    a.set_option("gemm_mode", 0)     # fp32-input MFMA GEMMs ...
+    a.set_option("attn_mode", 0)
+    b.set_option("gemm_pl", 0)       # ... next to the fp16-split GEMMs with fp32 activations between the kernels
+    za = a.encode(x, False, return_latents=True)[1]
+    zb = b.encode(x, False, return_latents=True)[1]
+    zd = build().encode(x, False, return_latents=True)[1]   # a third engine on the process defaults, interleaved
+    za2 = a.encode(x, False, return_latents=True)[1]
+    assert torch.equal(za, za2) and not torch.equal(za, zb) and not torch.equal(zb, zd)
+    ref = build()
+    try:
+        _lib.set_option("gemm_mode", 0)
+        _lib.set_option("attn_mode", 0)
+        assert torch.equal(ref.encode(x, False, return_latents=True)[1], za)
+        _lib.set_option("gemm_mode", 2)
+        _lib.set_option("attn_mode", 1)
+        _lib.set_option("gemm_pl", 0)
+        assert torch.equal(ref.encode(x, False, return_latents=True)[1], zb)
+        # a per-engine value wins over the process default; -1 hands the engine back to it
+        assert torch.equal(a.encode(x, False, return_latents=True)[1], za)
+        a.set_option("gemm_mode", -1)
+        a.set_option("attn_mode", -1)
+        assert torch.equal(a.encode(x, False, return_latents=True)[1], zb)
+    finally:
+        _lib.set_option("gemm_mode", 2)
+        _lib.set_option("attn_mode", 1)
+        _lib.set_option("gemm_pl", 1)
+    with pytest.raises(ValueError):
+        a.set_option("h2_tile", 3)   # a tuning knob of the stand-alone kernels, not an engine mode
+    for m in (za, zb, zd):
+        assert (m.cpu() - c.z).abs().max().item() < Z_TOL
+
+
 def test_flat_ids_and_embeddings(models):
     c = GoldenCase("s2_sdpa_r64_vid")
     m = models(c)

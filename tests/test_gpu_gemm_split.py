@@ -317,16 +317,3 @@ def test_engine_gemm_modes_vs_golden(mode, name):
         assert (c.strided(rec.cpu()) - c.recon).abs().max().item() < 1e-4
     finally:
         _lib.set_option("gemm_mode", 2)
-
-
-def test_gemm_pp_measurement_kernel(ops):
-    """csrc/gemm_pp.hip (both operands as packed fp16 hi|lo planes, LDS-DMA staging only): the VALU-free kernel of
-    the power-limit experiment (profiles/r02_gemm_pp_experiment.txt) computes the same product."""
-    g = torch.Generator().manual_seed(5)
-    for M, N, K in ((256, 256, 32), (512, 512, 512), (384, 256, 1408)):
-        x, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.05
-        out = ops.linear_pp(ops.h2_pack_weight(x.cuda()), ops.h2_pack_weight(w.cuda()), M, N)
-        ref = x.double() @ w.double().T
-        assert (out.double().cpu() - ref).abs().max().item() < 2e-6 * K ** 0.5 * 4
-    with pytest.raises(Exception):
-        ops.linear_pp(ops.h2_pack_weight(torch.randn(100, 64).cuda()), ops.h2_pack_weight(torch.randn(256, 64).cuda()), 100, 256)

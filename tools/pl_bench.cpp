@@ -54,7 +54,6 @@ int main(int argc, char **argv) {
     int iters = 10;
     bool check = false;
     std::string only, cfgs = "1,2", h2dbg;
-    bool with_pp = false;
     int64_t L = 32 * 5120;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--iters")) iters = atoi(argv[++i]);
@@ -62,7 +61,6 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--cfg")) cfgs = argv[++i];
         else if (!strcmp(argv[i], "--check")) check = true;
         else if (!strcmp(argv[i], "--h2dbg")) h2dbg = argv[++i];  // ablation builds of the h2 kernel (plain shapes only)
-        else if (!strcmp(argv[i], "--pp")) with_pp = true;        // the r02 measurement kernel gemm_pp
         else if (!strcmp(argv[i], "--rows")) L = atoll(argv[++i]);
         else if (!strcmp(argv[i], "--opt")) {  // --opt name value: omnitok_set_option
             const char *n = argv[++i];
@@ -158,16 +156,6 @@ int main(int argc, char **argv) {
                 const float ms = time_it(run_h2);
                 OK(omnitok_set_option("h2_dbg", 0));
                 printf("   h2 ablation build dbg=%-2d        %.4f ms  %6.1f TF\n", dbg, ms, flops / ms / 1e9);
-            }
-            if (with_pp && N % 256 == 0) {
-                void *ap_pp;
-                CK(hipMalloc(&ap_pp, (size_t)Lp * K * 4));
-                float *asc_pp = dmalloc_f(L);
-                OK(omnitok_h2_pack_weight(x, K, (int)L, K, ap_pp, asc_pp, st));
-                const float ms = time_it([&] { OK(omnitok_gemm_pp(ap_pp, asc_pp, wp_h2, wsc_h2, c_h2, Nout, L, N, K, st)); });
-                printf("   pp (r02 DMA measurement kernel) %.4f ms  %6.1f TF\n", ms, flops / ms / 1e9);
-                CK(hipFree(ap_pp));
-                CK(hipFree(asc_pp));
             }
         }
         for (size_t pos = 0; pos < cfgs.size();) {
