@@ -1,0 +1,404 @@
+// Engine, one Transformer: the block walk (PEG, attention / window attention, pooling / Up blocks, FeedForward; residual
+// order and grid tracking of reference attention.py:655-689) and the dispatch of its nn.Linear layers onto the GEMM kernels
+// of the engine's mode (plane data flow gemm_pl.h | fp16 split gemm_h2.hip | bf16 split gemm_x3.hip | fp32 MFMA gemm.hip).
+#include "engine.h"
+
+namespace omnitok {
+
+// arithmetic of each kernel is independent of the problem / tile size (batch-size independence).
+int g_gemm_mode = 2;
+// Spatial attention arithmetic.  "attn_mode"
+//   1 (default): fp16-split operands on the fp16 MFMA (attn_h2.hip) wherever the per-clip ranges of the row
+//      statistics pass exist (the split-operand GEMM path) and the q/k scales are usable;
+//   0: the fp32-input MFMA kernel of attn_spatial.hip.
+int g_attn_mode = 1;
+// "attn_vpack" 1 (default): the merged q|k|v launch writes V straight into the attention kernel's fp16 planes
+int g_attn_vpack = 1;
+// "gemm_pl" 1 (default): to_out / proj, FF-in and FF-out run as plane x plane GEMMs (gemm_pl.h) whose activation operands
+// are written as fp16 hi|lo planes by their producers (attention kernels, the LayerNorm epilogue of to_out, the GEGLU
+// epilogue of FF-in): no row-statistics pass and no in-loop LayerNorm / split in front of the FeedForward.  0: the
+// r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
+int g_gemm_pl = 1;
+
+int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->opt_gemm_mode : g_gemm_mode; }
+int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
+int attn_vpack_of(const omnitok_engine *e) { return e->opt_attn_vpack >= 0 ? e->opt_attn_vpack : g_attn_vpack; }
+int gemm_pl_of(const omnitok_engine *e) { return e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl; }
+
+bool x3_ok(const omnitok_engine *e, int N, int K, int flags) {
+    return gemm_mode_of(e) >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
+           (!(flags & OMNITOK_GEMM_GEGLU) || N % 64 == 0);
+}
+
+float *next_bounds(omnitok_engine *e) {  // [n_clips][2] slots of one row-statistics launch
+    if (e->bound_next >= N_BOUND_LAUNCHES) return nullptr;
+    return e->bounds + (int64_t)2 * e->bound_clips * (e->bound_next++);
+}
+
+
+
+int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int64_t ldw, const float *bias,
+                   const float *residual, int64_t ldr, float *c, int64_t ldc, int64_t M, int N, int K, int flags,
+                   int64_t rpg, int64_t gstride, int64_t goff, hipStream_t stream, ABound ab,
+                   const float *ln_stats, const float *ln_g, const float *ln_b,
+                   int ln_cols, float ln_bound, float *c2, int64_t ldc2, int split_col,
+                   const VPack *vpk, bool *vpacked) {
+    if (gemm_mode_of(e) == 2 && ab.stat > 0.0f && x3_ok(e, N, K, flags) && (!ln_stats || ln_bound > 0.0f) &&
+        (!ab.dev || (ab.rpc > 0 && ab.rpc % 64 == 0 && rpg == 0))) {
+        auto it = e->h2w.find(w);
+        if (it != e->h2w.end() && ldw == K) {
+            if (vpk && ab.dev && ab.rpc % 128 == 0) {  // V columns straight into the attention kernel's fp16 planes
+                *vpacked = true;
+                return omnitok_gemm_h2_vpack(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K,
+                                             flags, rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b,
+                                             ln_cols, ln_bound, c2, ldc2, split_col, vpk->planes, vpk->col0, vpk->n_tokens,
+                                             vpk->heads, vpk->bound, vpk->bound_dev, 2, stream);
+            }
+            return omnitok_gemm_h2(a, lda, it->second.pl, it->second.sc, bias, residual, ldr, c, ldc, M, N, K, flags,
+                                   rpg, gstride, goff, ab.stat, ab.dev, 2, ab.rpc, ln_stats, ln_g, ln_b, ln_cols,
+                                   ln_bound, c2, ldc2, split_col, stream);
+        }
+    }
+    if (x3_ok(e, N, K, flags))
+        return omnitok_gemm_x3(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff,
+                               ln_stats, ln_g, ln_b, ln_cols, c2, ldc2, split_col, stream);
+    if (ln_stats) {
+        set_error("eg_gemm: fused LayerNorm needs the x3 / h2 kernel");
+        return OMNITOK_ERR_STATE;
+    }
+    return omnitok_gemm(a, lda, w, ldw, bias, residual, ldr, c, ldc, M, N, K, flags, rpg, gstride, goff, stream);
+}
+
+// plane x plane GEMM of the engine: the weight is looked up by its fp32 pointer
+static int eg_gemm_pl(omnitok_engine *e, omnitok_pl_gemm g, const float *w, hipStream_t stream) {
+    auto it = e->plw.find(w);
+    if (it == e->plw.end()) {
+        set_error("eg_gemm_pl: weight was not packed for the plane GEMM");
+        return OMNITOK_ERR_STATE;
+    }
+    g.w = it->second.pl;
+    g.w_scale = it->second.sc;
+    return omnitok_gemm_pl(&g, stream);
+}
+
+// One Transformer (reference attention.py:655-689). X holds the tokens on entry and on exit.
+// Pooling blocks shrink the token grid (attention.py:683-684): *ghp / *gwp are updated.
+// transpose_out: the final LayerNorm stores its rows in the OTHER stage's token order ('(b t)(h w)' <-> '(b h w) t'),
+// i.e. the rearrange that follows every Transformer on the path is fused into the norm_out store.
+int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
+                           hipStream_t stream, bool transpose_out) {
+    const omnitok_config &c = e->cfg;
+    const int D = c.dim, heads = c.heads;
+    int gh = *ghp, gw = *gwp;
+    int64_t L = (int64_t)B * T * gh * gw;
+    int S = gh * gw;
+    double gemm_f = 2.0 * (double)L * D;
+    // split-operand GEMMs apply the LayerNorm while staging their A operand (no LN pass over HBM)
+    const bool fused = x3_ok(e, 3 * D, D, 0) && D <= 512;
+    // Plane data flow (gemm_pl.h): attention output -> planes (AO) -> to_out / proj with the residual add and the
+    // FeedForward's LayerNorm in its epilogue (x in place, LN(x) planes -> Y) -> FF-in with the GEGLU hidden as planes
+    // (HD) -> FF-out (+ residual).  Needs full-row tiles for the LayerNorm epilogue (dim 512 = the reference's only width).
+    const bool pl = gemm_pl_of(e) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    bool ln_planes_ready = false;  // Y holds the planes of the FeedForward's LayerNorm(x) for the current x
+    // producers that cannot write planes themselves: fp32 rows -> planes with one power-of-two scale per row
+    auto pack_rows = [&](const float *src, void *planes, float *scales) -> int {
+        const int64_t Lp = (L + 255) / 256 * 256;
+        OT_RUN("pack_rows", 2.0 * L * D * 4.0, omnitok_pl_pack_rows(src, D, L, D, Lp, planes, scales, 0.0f, stream));
+        return OMNITOK_OK;
+    };
+    // to_out / proj as a plane GEMM: x += a . w^T (+ bias), and the planes of LN_ff(x) -> Y
+    auto gemm_out_pl = [&](const Layer &ly, const void *a_planes, const float *a_scale, float a_const, const float *w,
+                           const float *bias) -> int {
+        omnitok_pl_gemm g{};
+        g.a = a_planes;
+        g.a_scale = a_scale;
+        g.a_scale_const = a_const;
+        g.bias = bias;
+        g.residual = e->X.p;
+        g.ldr = D;
+        g.c = e->X.p;
+        g.ldc = D;
+        g.out_planes = e->Y.p;
+        g.out_planes_k = D;
+        g.out_bound = ly.ff.ln_bound;
+        g.ln_gamma = ly.ff.lw;
+        g.ln_beta = ly.ff.lb;
+        g.ln_eps = 1e-5f;
+        g.epilogue = 2;
+        g.M = L;
+        g.N = D;
+        g.K = D;
+        OT_RUN("gemm_out", gemm_f * D, eg_gemm_pl(e, g, w, stream));
+        ln_planes_ready = true;
+        return OMNITOK_OK;
+    };
+    for (const Layer &ly : tw.layers) {
+        ln_planes_ready = false;
+        if (ly.kind == 'a' || ly.kind == 'm' || ly.kind == 'l') {
+            // Pooling (reference attention.py:83-113), no residual (:674); then FF (+residual) on the
+            // quarter-size sequence
+            if (!spatial || gh % 2 || gw % 2) {
+                set_error("pooling block '%c' on a %dx%d grid", ly.kind, gh, gw);
+                return OMNITOK_ERR_INVALID;
+            }
+            if (ly.kind == 'l')  // Linear(4D -> D) on four consecutive tokens: x.view(B, N/4, 4C)
+                OT_RUN("pool", 2.0 * (double)L * D * D,
+                       eg_gemm(e, e->X.p, 4 * D, ly.pool_w, 4 * D, ly.pool_b, nullptr, 0, e->X2.p, D, L / 4, D, 4 * D,
+                               OMNITOK_GEMM_BIAS, 0, 0, 0, stream));
+            else
+                OT_RUN("pool", 1.25 * L * D * 4.0,
+                       omnitok_token_resample(e->X.p, e->X2.p, ly.kind == 'a' ? 0 : 1, (int64_t)B * T, 1, gh, gw, D,
+                                              stream));
+            std::swap(e->X, e->X2);
+            gh /= 2;
+            gw /= 2;
+            S = gh * gw;
+            L = (int64_t)B * T * S;
+            gemm_f = 2.0 * (double)L * D;
+            goto feed_forward;
+        }
+        if (ly.kind == 'n' || ly.kind == 'r') {
+            // Up (reference attention.py:116-150): nearest 2x2 up-sampling of the token grid, no residual (:674),
+            // 'r' adds Linear(D, D).  A row-wise Linear commutes with the row duplication bit for bit, so it
+            // runs on the L source rows (a quarter of the work) and the result is up-sampled.
+            if (!spatial) {
+                set_error("Up block '%c' in a temporal transformer", ly.kind);
+                return OMNITOK_ERR_INVALID;
+            }
+            const float *src = e->X.p;
+            if (ly.kind == 'r') {
+                OT_RUN("pool", 2.0 * (double)L * D * D,
+                       eg_gemm(e, e->X.p, D, ly.pool_w, D, ly.pool_b, nullptr, 0, e->Y.p, D, L, D, D, OMNITOK_GEMM_BIAS, 0,
+                               0, 0, stream));
+                src = e->Y.p;
+            }
+            OT_RUN("pool", 1.25 * 4.0 * L * D * 4.0,
+                   omnitok_token_resample(src, e->X2.p, 2, (int64_t)B * T, 1, gh, gw, D, stream));
+            std::swap(e->X, e->X2);
+            gh *= 2;
+            gw *= 2;
+            S = gh * gw;
+            L = (int64_t)B * T * S;
+            gemm_f = 2.0 * (double)L * D;
+            goto feed_forward;
+        }
+        if (ly.kind == 't') {
+            OT_RUN("peg3d", 2.0 * L * D * 4.0,
+                   omnitok_peg3d(e->X.p, ly.t.peg_w27, ly.t.peg_b, e->X2.p, B, T, gh, gw, D, c.causal_peg, stream));
+            std::swap(e->X, e->X2);
+            // device-side ranges of this layer's x (filled by the row-statistics pass): bs[0] >= max |x|,
+            // bs[1] >= max ||x_row||; |V_j| <= ||x|| ||Wv_j|| bounds the attention output (a convex
+            // combination of V rows) -- what the fp16-split GEMMs need (gemm_h2.hip)
+            float *bs = fused ? next_bounds(e) : nullptr;
+            if (fused && !bs) {
+                set_error("run_transformer: out of range slots");
+                return OMNITOK_ERR_STATE;
+            }
+            const int64_t rpc = L / B;  // both token orders keep a clip's rows contiguous (b is the outermost index)
+            const ABound ab_x = bs ? ABound{1.01f, bs, rpc} : ABound();
+            const ABound ab_ao = bs ? ABound{1.01f * ly.t.vnorm, bs + 1, rpc} : ABound();
+            if (!spatial && T == 1) {
+                // Images: a temporal sequence of one token.  softmax over a single key is exactly 1
+                // (causal or not, with or without ALiBi), so the attention output is V bit for bit:
+                // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
+                // half and the attention kernel drop out.  Identical results to the general path.
+                if (bs && gemm_mode_of(e) == 2)  // only the ranges are needed here
+                    OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       eg_gemm(e, e->X.p, D, ly.t.wkv + (int64_t)D * D, D, nullptr, nullptr, 0, e->AO.p, D, L, D, D, 0, 0,
+                               0, 0, stream, ab_x));
+                if (pl) {
+                    if (int rc = pack_rows(e->AO.p, e->QKV.p, e->ST.p)) return rc;
+                    if (int rc = gemm_out_pl(ly, e->QKV.p, e->ST.p, 1.0f, ly.t.wo, nullptr)) return rc;
+                    goto feed_forward;
+                }
+                OT_RUN("gemm_out", gemm_f * D,
+                       eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
+                               0, 0, 0, stream, ab_ao));
+                goto feed_forward;
+            }
+            float *Q = e->QKV.p, *KV = e->QKV.p + L * D;
+            int64_t ldq = D, ldkv = 2 * D;
+            // fp16-split spatial attention (attn_h2.hip): Q, K (RoPE + l2norm + scales applied) and V as hi|lo planes
+            // in MFMA fragment order (Y, HD are free here); |V| <= ||x_row|| ||Wv_j|| per clip from the row statistics
+            const float qb = 1.01f * 8.0f * ly.t.q_amax, kb = 1.01f * ly.t.k_amax;
+            const bool attn_h2 = spatial && attn_mode_of(e) == 1 && bs && S % 64 == 0 && qb > 0.0f && kb > 0.0f &&
+                                 ly.t.vnorm > 0.0f && qb < 1e30f && kb < 1e30f;
+            unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
+            unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
+            unsigned char *vp = kp + (size_t)L * D * 4;
+            const VPack vpk{vp, 2 * D, S, heads, ab_ao.stat, ab_ao.dev};
+            bool vpacked = false;  // the q|k|v launch wrote the V planes itself (no fp32 V round trip)
+            bool ao_planes = false;  // the attention kernel wrote its output as planes (AO) with row scales (ST)
+            // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
+            if (fused && D % 256 == 0) {
+                // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
+                // for the Q columns only; QKV rows are [q | k | v]
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
+                // ... and the two column ranges land in two dense tensors (Q [L, D], K|V [L, 2D]): the attention
+                // kernels read rows of D / 2D floats (with a [L, 3D] row pitch spatial attention ran 15 % slower)
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e, e->X.p, D, ly.t.wqkv, D, nullptr, nullptr, 0, Q, D, L, 3 * D, D, 0, 0, 0, 0, stream, ab_x,
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound, KV, 2 * D, D, attn_h2 && attn_vpack_of(e) ? &vpk : nullptr,
+                               &vpacked));
+            } else if (fused) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       eg_gemm(e, e->X.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream, ab_x,
+                               e->ST.p, ly.t.ng, ly.t.nb, D, ly.t.ln_bound));
+                OT_RUN("gemm_qkv", gemm_f * 2 * D,
+                       eg_gemm(e, e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0, stream,
+                               ab_x));
+            } else {
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.t.ng, ly.t.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * D,
+                       eg_gemm(e, e->Y.p, D, ly.t.wq, D, nullptr, nullptr, 0, Q, D, L, D, D, 0, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * 2 * D,
+                       eg_gemm(e, e->X.p, D, ly.t.wkv, D, nullptr, nullptr, 0, KV, 2 * D, L, 2 * D, D, 0, 0, 0, 0,
+                               stream));
+            }
+            if (spatial) {
+                const float *cosp = nullptr, *sinp = nullptr;
+                if (c.spatial_rope)
+                    if (int rc = get_rope(e, S, &cosp, &sinp, stream)) return rc;
+                const float *bias = nullptr;
+                if (!ly.t.bias_prefix.empty())
+                    if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
+                if (attn_h2) {
+                    OT_RUN("qk_prep", (vpacked ? 4.0 : 6.0) * L * D * 4.0,
+                           omnitok_attn_pack(Q, ldq, KV, vpacked ? nullptr : KV + D, ldkv, L, S, heads, cosp, sinp,
+                                             ly.t.q_scale, ly.t.k_scale, 8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp,
+                                             vpacked ? nullptr : vp, stream));
+                    OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
+                           omnitok_attn_spatial_h2_planes(qp, kp, vp, e->AO.p, D, pl ? e->AO.p : nullptr, pl ? e->ST.p : nullptr,
+                                                          B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev, 2, T, bias, gh, gw,
+                                                          stream));
+                    ao_planes = pl;
+                } else {
+                    OT_RUN("qk_prep", 4.0 * L * D * 4.0,
+                           omnitok_qk_prep(Q, ldq, KV, ldkv, L, S, heads, cosp, sinp, ly.t.q_scale, ly.t.k_scale, 8.0f,
+                                           stream));
+                    OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
+                           omnitok_attn_spatial(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, B * T, S, heads, bias, gh, gw,
+                                                stream));
+                }
+            } else {
+                const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
+                const bool tp = pl && bs && T <= 17 && S % 16 == 0;
+                OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
+                       omnitok_attn_temporal_planes(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, tp ? e->AO.p : nullptr,
+                                                    tp ? e->ST.p : nullptr, ab_ao.stat, ab_ao.dev, 2, S, (int64_t)B * S, T,
+                                                    heads, ly.t.q_scale, ly.t.k_scale, 8.0f, c.causal_temporal, alibi,
+                                                    stream));
+                ao_planes = tp;
+            }
+            if (pl) {
+                const void *ap = e->AO.p;
+                if (!ao_planes) {  // fp32 attention output (fp32-MFMA attention kernel, long temporal sequences): pack it
+                    if (int rc = pack_rows(e->AO.p, e->QKV.p, e->ST.p)) return rc;
+                    ap = e->QKV.p;
+                }
+                if (int rc = gemm_out_pl(ly, ap, e->ST.p, 1.0f, ly.t.wo, nullptr)) return rc;
+                goto feed_forward;
+            }
+            OT_RUN("gemm_out", gemm_f * D,
+                   eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL, 0, 0,
+                           0, stream, ab_ao));
+        } else {
+            if (fused) {
+                OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e, e->X.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream, ABound{1.0f, nullptr, 0}, e->ST.p, ly.w.ng, ly.w.nb, 3 * D, ly.w.ln_bound));
+            } else {
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.w.ng, ly.w.nb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("gemm_qkv", gemm_f * 3 * D,
+                       eg_gemm(e, e->Y.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,
+                               stream));
+            }
+            if (pl && ly.w.ao_bound > 0.0f) {
+                OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
+                       omnitok_attn_window_planes(e->QKV.p, 3 * D, ly.w.bias_dense, nullptr, 0, e->AO.p, ly.w.ao_bound, B * T, gh,
+                                                  gw, heads, stream));
+                if (int rc = gemm_out_pl(ly, e->AO.p, nullptr, omnitok_pl_unscale(ly.w.ao_bound), ly.w.wproj, ly.w.bproj))
+                    return rc;
+                goto feed_forward;
+            }
+            OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
+                   omnitok_attn_window(e->QKV.p, 3 * D, ly.w.bias_dense, e->AO.p, D, B * T, gh, gw, heads, stream));
+            OT_RUN("gemm_out", gemm_f * D,
+                   eg_gemm(e, e->AO.p, D, ly.w.wproj, D, ly.w.bproj, e->X.p, D, e->X.p, D, L, D, D,
+                           OMNITOK_GEMM_BIAS | OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream,
+                           fused ? ABound{ly.w.ao_bound, nullptr, 0} : ABound()));
+        }
+    feed_forward:
+        // FeedForward (reference attention.py:153-168)
+        if (pl) {
+            if (!ln_planes_ready) {  // after pooling / Up blocks: LayerNorm pass, then planes
+                const int64_t Lp = (L + 255) / 256 * 256;
+                OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                       omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->AO.p, L, D, 1e-5f, 0, 0, 0, stream));
+                OT_RUN("pack_rows", 2.0 * L * D * 4.0,
+                       omnitok_pl_pack_rows(e->AO.p, D, L, D, Lp, e->Y.p, nullptr, ly.ff.ln_bound, stream));
+            }
+            omnitok_pl_gemm g{};
+            g.a = e->Y.p;
+            g.a_scale_const = omnitok_pl_unscale(ly.ff.ln_bound);
+            g.out_planes = e->HD.p;
+            g.out_planes_k = e->inner_pad;
+            g.out_bound = ly.ff.h_bound;
+            g.epilogue = 1;
+            g.M = L;
+            g.N = 2 * e->inner_pad;
+            g.K = D;
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner, eg_gemm_pl(e, g, ly.ff.w1p, stream));
+            omnitok_pl_gemm h{};
+            h.a = e->HD.p;
+            h.a_scale_const = omnitok_pl_unscale(ly.ff.h_bound);
+            h.residual = e->X.p;
+            h.ldr = D;
+            h.c = e->X.p;
+            h.ldc = D;
+            h.epilogue = 0;
+            h.M = L;
+            h.N = D;
+            h.K = e->inner_pad;
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner, eg_gemm_pl(e, h, ly.ff.w2p, stream));
+        } else if (fused && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
+            OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
+                   eg_gemm(e, e->X.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad, D,
+                           OMNITOK_GEMM_GEGLU, 0, 0, 0, stream, ABound{1.0f, nullptr, 0}, e->ST.p, ly.ff.lw, ly.ff.lb,
+                           2 * e->inner_pad, ly.ff.ln_bound));
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
+                   eg_gemm(e, e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+                           e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream, ABound{ly.ff.h_bound, nullptr, 0}));
+        } else {
+            OT_RUN("layernorm", 2.0 * L * D * 4.0,
+                   omnitok_layernorm(e->X.p, ly.ff.lw, ly.ff.lb, e->Y.p, L, D, 1e-5f, 0, 0, 0, stream));
+            OT_RUN("gemm_ff_in", gemm_f * 2 * c.ff_inner,
+                   eg_gemm(e, e->Y.p, D, ly.ff.w1p, D, nullptr, nullptr, 0, e->HD.p, e->inner_pad, L, 2 * e->inner_pad,
+                           D, OMNITOK_GEMM_GEGLU, 0, 0, 0, stream));
+            OT_RUN("gemm_ff_out", gemm_f * c.ff_inner,
+                   eg_gemm(e, e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
+                           e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
+        }
+    }
+    if (transpose_out && T > 1)  // rows (b, t, s) -> (b, s, t) after a spatial stage, (b, s, t) -> (b, t, s) after a temporal one
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm_transposed(e->X.p, tw.og, tw.ob, e->X2.p, B, spatial ? T : S, spatial ? S : T, D, 1e-5f,
+                                            stream));
+    else
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm(e->X.p, tw.og, tw.ob, e->X2.p, L, D, 1e-5f, 0, 0, 0, stream));
+    std::swap(e->X, e->X2);
+    *ghp = gh;
+    *gwp = gw;
+    return OMNITOK_OK;
+}
+
+// range slots of the fp16-split GEMMs: per clip, zeroed once per encode / decode (atomic max targets)
+
+}  // namespace omnitok
