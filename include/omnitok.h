@@ -185,7 +185,32 @@ typedef struct omnitok_pl_gemm {
     const float *ln_gamma;      /* epilogue 2: LayerNorm over the N output columns (two-pass statistics)        */
     const float *ln_beta;       /* or NULL                                                                      */
     float ln_eps;
-    int epilogue;               /* 0 fp32 | 1 GEGLU -> planes | 2 fp32 AND LayerNorm -> planes (N == 512)       */
+    int epilogue;               /* 0 fp32 | 1 GEGLU -> planes | 2 fp32 AND LayerNorm -> planes (N == 512) |     */
+                                /* 3 packed V planes of omnitok_attn_spatial_h2 | 4 packed Q | K planes           */
+    /* LayerNorm folded into the weight (epilogues 0, 3, 4): the operand a holds the CENTRED rows x - mean(x)
+     * (omnitok_stats_pack), the weight rows n < fold_cols were multiplied by gamma before packing, and the epilogue finishes
+     *   n <  fold_cols:  LayerNorm(x) . W^T = rstd_m ((x - mean_m) . (W o gamma)^T) + b_n     (b = W beta, or NULL)
+     *   n >= fold_cols:  x . W^T           = (x - mean_m) . W^T + mean_m u_n                  (u_n = sum_k W[n][k])   */
+    const float *fold_stats;    /* [M][2] (mean, rstd) or NULL                                                  */
+    const float *fold_b;
+    const float *fold_u;        /* [N]; may be NULL when fold_cols >= N                                          */
+    int fold_cols;
+    /* epilogues 3 / 4: the attention operands (reference attention.py:417-437).  4: columns [0, qk_k0) are Q, the rest
+     * K; per 64-column head RoPE (cos / sin [n_tokens][32] or NULL), l2norm, q_scale / k_scale [64], q_mul (the SDPA
+     * scale) and the power-of-two scales of q_bound / k_bound, written as the packed planes omnitok_attn_pack writes.
+     * 3: N = heads * 64 columns of V scaled per clip by v_bound (x v_bound_dev[v_bound_stride * clip]).             */
+    void *qp;
+    void *kp;
+    void *vp;
+    int qk_k0, n_tokens, heads;
+    const float *rope_cos;
+    const float *rope_sin;
+    const float *q_scale;
+    const float *k_scale;
+    float q_mul, q_bound, k_bound, v_bound;
+    const float *v_bound_dev;
+    int v_bound_stride;
+    int64_t rows_per_clip;
     int64_t M;
     int N, K;
     int cfg;                    /* 0 auto | 1 256x256 tiles, one workgroup per CU | 2 128x256, two per CU        */
@@ -201,6 +226,13 @@ int omnitok_pl_pack_weight(const float *w, int64_t ldw, int N, int K, int n_pad,
 int omnitok_pl_pack_rows(const float *x, int64_t ldx, int64_t M, int K, int64_t m_pad, void *planes, float *a_scale,
                          float static_bound, omnitok_stream_t stream);
 int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream);
+/* Row statistics AND planes in one pass over x[rows, dim] (dim % 256 == 0): stats[m] = (mean, 1/sqrt(var + eps)) like
+ * omnitok_row_stats, planes = the rows of x (center == 0) or the CENTRED rows x - mean (center != 0) with one power-of-two
+ * scale per row (a_scale[m] undoes it), bounds as omnitok_row_stats.  The centred form is the operand of the q|k|v plane
+ * GEMM, whose epilogue finishes LayerNorm(x) . Wq^T and x . Wkv^T from it (omnitok_pl_gemm.fold_*; reference
+ * attention.py:404-412). */
+int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                       float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of

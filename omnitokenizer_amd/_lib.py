@@ -40,6 +40,11 @@ class OmnitokPlGemm(Structure):
         ("c", c_void_p), ("ldc", c_int64), ("c2", c_void_p), ("ldc2", c_int64), ("c_split_n", c_int),
         ("out_planes", c_void_p), ("out_planes_k", c_int), ("out_bound", c_float),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float), ("epilogue", c_int),
+        ("fold_stats", c_void_p), ("fold_b", c_void_p), ("fold_u", c_void_p), ("fold_cols", c_int),
+        ("qp", c_void_p), ("kp", c_void_p), ("vp", c_void_p), ("qk_k0", c_int), ("n_tokens", c_int), ("heads", c_int),
+        ("rope_cos", c_void_p), ("rope_sin", c_void_p), ("q_scale", c_void_p), ("k_scale", c_void_p),
+        ("q_mul", c_float), ("q_bound", c_float), ("k_bound", c_float), ("v_bound", c_float),
+        ("v_bound_dev", c_void_p), ("v_bound_stride", c_int), ("rows_per_clip", c_int64),
         ("M", c_int64), ("N", c_int), ("K", c_int), ("cfg", c_int), ("debug_cycles", c_void_p),
     ]
 
@@ -133,6 +138,7 @@ _PROTOS = {
     "omnitok_pl_pack_weight": [P, I64, c_int, c_int, c_int, P, P, P],
     "omnitok_pl_pack_rows": [P, I64, I64, c_int, I64, P, P, c_float, P],
     "omnitok_gemm_pl": [POINTER(OmnitokPlGemm), P],
+    "omnitok_stats_pack": [P, I64, c_int, c_float, c_int, P, I64, P, P, P, I64, P],
     "omnitok_attn_spatial_h2_planes": [P, P, P, P, I64, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P, c_int,
                                        c_int, P, c_int, c_int, P],
     "omnitok_attn_window_planes": [P, I64, P, P, I64, P, c_float, c_int, c_int, c_int, c_int, P],

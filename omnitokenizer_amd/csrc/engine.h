@@ -37,6 +37,10 @@ struct LayerT {  // 't' block (+ FF)
     const float *ng, *nb;
     const float *wq, *wkv, *wo;
     const float *wqkv;  // [3D, D] = to_q | to_kv rows (one launch: Q from LN(x), K/V from x)
+    // plane data flow: [to_q o gamma | to_kv] (the LayerNorm gain folded into the Q rows; key of the gemm_pl packing),
+    // b = to_q beta, u = row sums of to_kv: with the centred operand xc = x - mean,  LN(x) . Wq^T = rstd (xc . (Wq o gamma)^T) + b
+    // and x . Wkv^T = xc . Wkv^T + mean u   (gemm_pl.h fold_*)
+    const float *wqkv_fold = nullptr, *fold_b = nullptr, *fold_u = nullptr;
     const float *q_scale, *k_scale;
     float ln_bound = 0.0f;  // >= max |LN(x)|            (ranges for the fp16-split GEMM, gemm_h2.hip)
     float vnorm = 0.0f;     // max_j ||Wv_j||_2: |attention output| <= max_rows ||x||_2 * vnorm
@@ -45,6 +49,7 @@ struct LayerT {  // 't' block (+ FF)
 };
 struct LayerW {  // 'w' block
     const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;
+    const float *wqkv_fold = nullptr, *fold_b = nullptr, *fold_u = nullptr;  // all 3D rows folded (q, k, v from LN(x))
     float ln_bound = 0.0f, ao_bound = 0.0f;  // >= max |LN(x)|, >= max |window attention output|
 };
 struct LayerFF {

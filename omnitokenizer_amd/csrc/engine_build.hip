@@ -210,6 +210,46 @@ static int pack_pl(omnitok_engine *e, const float *w, int64_t ld, int N, int K, 
     return OMNITOK_OK;
 }
 
+// LayerNorm folded into a Linear whose operand is the centred row x - mean: rows [0, rows_fold) of w are multiplied by
+// gamma and get b[n] = sum_k w[n][k] beta[k]; the other rows are copied and get u[n] = sum_k w[n][k] (fp64 accumulation).
+// One wave per row.
+__global__ __launch_bounds__(256) void fold_ln_weight_kernel(const float *__restrict__ w, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, int rows_fold, int rows, int K,
+                                                             float *__restrict__ wout, float *__restrict__ b,
+                                                             float *__restrict__ u) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    const bool f = n < rows_fold;
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float v = w[(int64_t)n * K + k];
+        wout[(int64_t)n * K + k] = f ? v * gamma[k] : v;
+        acc += f ? (beta ? (double)v * (double)beta[k] : 0.0) : (double)v;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) {
+        b[n] = f ? (float)acc : 0.0f;
+        u[n] = f ? 0.0f : (float)acc;
+    }
+}
+
+static int fold_ln_weight(omnitok_engine *e, const float *w, const float *gamma, const float *beta, int rows_fold, int rows, int K,
+                          const float **wout, const float **b, const float **u, hipStream_t stream) {
+    float *wo, *bb, *uu;
+    if (int rc = alloc_f(e, &wo, (int64_t)rows * K)) return rc;
+    if (int rc = alloc_f(e, &bb, rows)) return rc;
+    if (int rc = alloc_f(e, &uu, rows)) return rc;
+    hipLaunchKernelGGL(fold_ln_weight_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, w, gamma, beta, rows_fold, rows, K, wo, bb,
+                       uu);
+    OT_LAUNCH_CHECK("fold_ln_weight");
+    if (int rc = pack_pl(e, wo, K, rows, K, stream)) return rc;
+    *wout = wo;
+    *b = bb;
+    *u = uu;
+    return OMNITOK_OK;
+}
+
 int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &prefix, const std::string &block,
                              bool spatial, hipStream_t stream) {
     const omnitok_config &c = e->cfg;
@@ -247,6 +287,10 @@ int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &pr
             }
             if (int rc = pack_h2(e, L.t.wo, c.dim, c.dim, c.dim, stream)) return rc;
             if (int rc = pack_pl(e, L.t.wo, c.dim, c.dim, c.dim, stream)) return rc;
+            if (c.dim % 256 == 0)
+                if (int rc = fold_ln_weight(e, L.t.wqkv, L.t.ng, L.t.nb, c.dim, 3 * c.dim, c.dim, &L.t.wqkv_fold, &L.t.fold_b,
+                                            &L.t.fold_u, stream))
+                    return rc;
             if (int rc = ln_range(e, L.t.ng, L.t.nb, c.dim, &L.t.ln_bound, nullptr, stream)) return rc;
             if (int rc = weight_range(e, L.t.wkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &L.t.vnorm, nullptr, stream))
                 return rc;
@@ -281,6 +325,10 @@ int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &pr
             if (int rc = pack_h2(e, L.w.wqkv, c.dim, 3 * c.dim, c.dim, stream)) return rc;
             if (int rc = pack_h2(e, L.w.wproj, c.dim, c.dim, c.dim, stream)) return rc;
             if (int rc = pack_pl(e, L.w.wproj, c.dim, c.dim, c.dim, stream)) return rc;
+            if (c.dim % 256 == 0)
+                if (int rc = fold_ln_weight(e, L.w.wqkv, L.w.ng, L.w.nb, 3 * c.dim, 3 * c.dim, c.dim, &L.w.wqkv_fold, &L.w.fold_b,
+                                            &L.w.fold_u, stream))
+                    return rc;
             {
                 float l2 = 0, vn = 0;
                 if (int rc = ln_range(e, L.w.ng, L.w.nb, c.dim, &L.w.ln_bound, &l2, stream)) return rc;

@@ -19,6 +19,12 @@ int g_attn_vpack = 1;
 // epilogue of FF-in): no row-statistics pass and no in-loop LayerNorm / split in front of the FeedForward.  0: the
 // r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
 int g_gemm_pl = 1;
+// "qkv_pl" 1 (default, with gemm_pl): the q|k|v projection as a plane GEMM too -- one pass writes the row statistics and
+// the centred rows x - mean as planes (omnitok_stats_pack), the LayerNorm of the Q columns is folded into the weight and finished in the
+// epilogue, which for spatial attention also does RoPE + l2norm + scales and writes Q and K straight into the attention
+// kernel's packed planes (no fp32 Q / K, no attn_pack pass); V by a swapped-orientation launch.  0: gemm_h2 with the
+// LayerNorm fused into its A loader (r02 form).
+int g_qkv_pl = 1;
 
 int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->opt_gemm_mode : g_gemm_mode; }
 int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
@@ -231,7 +237,75 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
             bool vpacked = false;  // the q|k|v launch wrote the V planes itself (no fp32 V round trip)
             bool ao_planes = false;  // the attention kernel wrote its output as planes (AO) with row scales (ST)
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
-            if (fused && D % 256 == 0) {
+            bool qk_packed = false;  // the q|k launch wrote the packed Q / K planes itself (no attn_pack pass)
+            const bool qkv_pl = pl && g_qkv_pl && ly.t.wqkv_fold && e->plw.count(ly.t.wqkv_fold) && bs;
+            if (qkv_pl) {
+                const int64_t Lp = (L + 255) / 256 * 256;
+                float *a_sc = e->Z.p;  // [L] row scales of the raw planes (Z is free inside a Transformer)
+                OT_RUN("row_stats", 3.0 * L * D * 4.0,
+                       omnitok_stats_pack(e->X.p, L, D, 1e-5f, 1, e->X2.p, Lp, a_sc, e->ST.p, bs, rpc, stream));
+                const H2W &wf = e->plw[ly.t.wqkv_fold];
+                omnitok_pl_gemm g{};
+                g.a = e->X2.p;
+                g.a_scale = a_sc;
+                g.w = wf.pl;
+                g.w_scale = wf.sc;
+                g.fold_stats = e->ST.p;
+                g.fold_b = ly.t.fold_b;
+                g.fold_u = ly.t.fold_u;
+                g.fold_cols = D;
+                g.M = L;
+                g.K = D;
+                if (attn_h2 && rpc % 256 == 0) {
+                    // spatial attention on packed operands: Q | K through the packing epilogue, V through the swapped launch
+                    const float *cosp = nullptr, *sinp = nullptr;
+                    if (c.spatial_rope)
+                        if (int rc = get_rope(e, S, &cosp, &sinp, stream)) return rc;
+                    omnitok_pl_gemm q = g;
+                    q.N = 2 * D;
+                    q.epilogue = 4;
+                    q.qp = qp;
+                    q.kp = kp;
+                    q.qk_k0 = D;
+                    q.n_tokens = S;
+                    q.heads = heads;
+                    q.rope_cos = cosp;
+                    q.rope_sin = sinp;
+                    q.q_scale = ly.t.q_scale;
+                    q.k_scale = ly.t.k_scale;
+                    q.q_mul = 8.0f;
+                    q.q_bound = qb;
+                    q.k_bound = kb;
+                    OT_RUN("gemm_qkv", gemm_f * 2 * D, omnitok_gemm_pl(&q, stream));
+                    omnitok_pl_gemm v = g;
+                    v.fold_cols = 0;                 // every V column: xc . Wv^T + mean u
+                    v.fold_b = nullptr;
+                    v.fold_u = ly.t.fold_u + 2 * D;
+                    v.w = static_cast<const char *>(wf.pl) + (int64_t)(2 * D / 64) * (D / 32) * 8192;
+                    v.w_scale = wf.sc + 2 * D;
+                    v.N = D;
+                    v.epilogue = 3;
+                    v.vp = vp;
+                    v.n_tokens = S;
+                    v.heads = heads;
+                    v.v_bound = ab_ao.stat;
+                    v.v_bound_dev = ab_ao.dev;
+                    v.v_bound_stride = 2;
+                    v.rows_per_clip = rpc;
+                    OT_RUN("gemm_qkv", gemm_f * D, omnitok_gemm_pl(&v, stream));
+                    vpacked = true;
+                    qk_packed = true;
+                } else {
+                    g.N = 3 * D;
+                    g.epilogue = 0;
+                    g.c = Q;
+                    g.ldc = D;
+                    g.c2 = KV;
+                    g.ldc2 = 2 * D;
+                    g.c_split_n = D;
+                    OT_RUN("gemm_qkv", gemm_f * 3 * D, omnitok_gemm_pl(&g, stream));
+                }
+            } else if (fused && D % 256 == 0) {
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
                 // for the Q columns only; QKV rows are [q | k | v]
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
@@ -266,10 +340,11 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                 if (!ly.t.bias_prefix.empty())
                     if (int rc = get_bias_table(e, ly.t.bias_prefix, gh, gw, &bias, stream)) return rc;
                 if (attn_h2) {
-                    OT_RUN("qk_prep", (vpacked ? 4.0 : 6.0) * L * D * 4.0,
-                           omnitok_attn_pack(Q, ldq, KV, vpacked ? nullptr : KV + D, ldkv, L, S, heads, cosp, sinp,
-                                             ly.t.q_scale, ly.t.k_scale, 8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp,
-                                             vpacked ? nullptr : vp, stream));
+                    if (!qk_packed)
+                        OT_RUN("qk_prep", (vpacked ? 4.0 : 6.0) * L * D * 4.0,
+                               omnitok_attn_pack(Q, ldq, KV, vpacked ? nullptr : KV + D, ldkv, L, S, heads, cosp, sinp,
+                                                 ly.t.q_scale, ly.t.k_scale, 8.0f, qb, kb, ab_ao.stat, ab_ao.dev, 2, rpc, qp, kp,
+                                                 vpacked ? nullptr : vp, stream));
                     OT_RUN("attn_spatial", 4.0 * (double)B * T * heads * (double)S * S * 64.0,
                            omnitok_attn_spatial_h2_planes(qp, kp, vp, e->AO.p, D, pl ? e->AO.p : nullptr, pl ? e->ST.p : nullptr,
                                                           B * T, S, heads, qb, kb, ab_ao.stat, ab_ao.dev, 2, T, bias, gh, gw,
@@ -306,7 +381,27 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                    eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL, 0, 0,
                            0, stream, ab_ao));
         } else {
-            if (fused) {
+            if (pl && g_qkv_pl && ly.w.wqkv_fold && e->plw.count(ly.w.wqkv_fold)) {
+                // q, k, v all from LN(x) (reference attention.py:262-272): the gain folded into every weight row
+                const int64_t Lp = (L + 255) / 256 * 256;
+                OT_RUN("row_stats", 3.0 * L * D * 4.0,
+                       omnitok_stats_pack(e->X.p, L, D, 1e-5f, 1, e->X2.p, Lp, e->Z.p, e->ST.p, nullptr, 0, stream));
+                const H2W &wf = e->plw[ly.w.wqkv_fold];
+                omnitok_pl_gemm g{};
+                g.a = e->X2.p;
+                g.a_scale = e->Z.p;
+                g.w = wf.pl;
+                g.w_scale = wf.sc;
+                g.fold_stats = e->ST.p;
+                g.fold_b = ly.w.fold_b;
+                g.fold_cols = 3 * D;
+                g.c = e->QKV.p;
+                g.ldc = 3 * D;
+                g.M = L;
+                g.N = 3 * D;
+                g.K = D;
+                OT_RUN("gemm_qkv", gemm_f * 3 * D, omnitok_gemm_pl(&g, stream));
+            } else if (fused) {
                 OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));
                 OT_RUN("gemm_qkv", gemm_f * 3 * D,
                        eg_gemm(e, e->X.p, D, ly.w.wqkv, D, nullptr, nullptr, 0, e->QKV.p, 3 * D, L, 3 * D, D, 0, 0, 0, 0,

@@ -33,6 +33,7 @@ enum PlEpi {
     PL_GEGLU = 1,       // GEGLU of (value | gate) 32-column pairs -> fp16 planes of the hidden (next GEMM's operand)
     PL_ROWLN = 2,       // full-row tiles (TN == N): fp32 output (+ bias, + residual) AND LayerNorm(out) as planes
     PL_VPACK = 3,       // SWAP only: V columns into the attention kernel's packed fp16 planes (attn_h2.hip)
+    PL_QKPACK = 4,      // Q | K columns (one head per wave): RoPE + l2norm + scales -> the attention kernel's packed planes
 };
 
 struct PlParams {
@@ -58,6 +59,22 @@ struct PlParams {
     float cp_scale;                   // power of two applied before the split (from a static bound)
     const float *ln_gamma, *ln_beta;  // PL_ROWLN
     float ln_eps;
+    // LayerNorm folded into the weight (PL_F32, PL_QKPACK, PL_VPACK): the operand holds the CENTRED rows x - mean(x)
+    // (omnitok_stats_pack), the weight rows of the columns n < fold_cols were multiplied by gamma, and the epilogue finishes
+    //   n <  fold_cols:  LayerNorm(x) . W^T = rstd_m ((x - mean_m) . (W o gamma)^T) + b_n,      b = W beta
+    //   n >= fold_cols:  x . W^T           = (x - mean_m) . W^T + mean_m u_n,                   u_n = sum_k W[n][k]
+    // -- the reference's own order for Q (attention.py:73-80: centre first), and no cancellation for K / V (reference
+    // attention.py:404-412: Q from LN(x), K / V from the raw x)
+    const float *fold_stats;          // [M][2] (mean, rstd), or null
+    const float *fold_b;              // [fold_cols] or null
+    const float *fold_u;              // [N] row sums of the weight (used for n >= fold_cols), or null when fold_cols >= N
+    int fold_cols;
+    // PL_QKPACK (reference attention.py:417-437): columns [0, qk_k0) are Q, [qk_k0, N) are K; 64 columns = one head
+    unsigned char *qp, *kp;
+    int qk_k0, qk_ntok, qk_heads;
+    const float *cosT, *sinT;         // [n_tokens][32] or null
+    const float *q_scale, *k_scale;   // [64]
+    float q_mul, sq, sk;              // SDPA scale folded into q; power-of-two operand scales of q and k
     // PL_VPACK
     unsigned char *vp;
     int v_ntok, v_heads;
@@ -319,6 +336,20 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         sa[mi] = ascl_c * (av * has + (1.0f - has));  // exact: av (has = 1) or 1 (has = 0, av finite)
                     }
                 }
+                // row statistics of the folded LayerNorm (unconditional loads from a valid address, see above)
+                float fmu[MI], frs[MI];
+                {
+                    const float *sbase = p.fold_stats ? p.fold_stats : p.w_scale;
+                    int64_t mmax = p.fold_stats ? p.M - 1 : 0;
+                    asm volatile("" : "+v"(sbase), "+v"(mmax));
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const int64_t m = m_w0 + mi * 32 + r32;
+                        const float *sp = sbase + 2 * (m < mmax ? m : mmax);
+                        fmu[mi] = sp[0];
+                        frs[mi] = sp[p.fold_stats ? 1 : 0];
+                    }
+                }
                 if constexpr (EPI == PL_F32) {
                     float *cb = p.c;
                     int64_t ldc = p.ldc;
@@ -341,44 +372,50 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         if (ni * 32 >= vc) break;
-                        f32x4 sw[2][2], bv[2][2];
+                        const bool fold = p.fold_stats && n_w0 + ni * 32 < p.fold_cols;  // wave-uniform
+                        const bool unfold = p.fold_stats && !fold && p.fold_u;             // centred operand, plain column
 #pragma unroll
-                        for (int c = 0; c < 2; ++c)
+                        for (int c = 0; c < 2; ++c) {
+                            // 8 columns at a time: their constants (24 registers) and the residual of the wave's MI row blocks
+                            // (8 MI registers, all loads in flight together) -- the accumulators leave ~100 registers
+                            __builtin_amdgcn_sched_barrier(0);
+                            f32x4 sw[2], fg[2], fbv[2];
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const int n = n_w0 + ni * 32 + c * 16 + hi * 8 + h * 4;
-                                sw[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
-                                bv[c][h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                                sw[h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
+                                fg[h] = unfold ? *reinterpret_cast<const f32x4 *>(p.fold_u + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                                fbv[h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                                if (fold && p.fold_b) fbv[h] += *reinterpret_cast<const f32x4 *>(p.fold_b + n);
                             }
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            __builtin_amdgcn_sched_barrier(0);  // one block at a time: bounds the live copies of accumulators
-                            const int row = mi * 32 + r32;
-                            const int c_off = (row * (int)ldc + ni * 32 + hi * 8) * 4;
-                            u32x4 res[2][2];
+                            u32x4 res[MI][2];
                             if (p.residual) {
-                                const int r_off = (row * (int)p.ldr + ni * 32 + hi * 8) * 4;
 #pragma unroll
-                                for (int c = 0; c < 2; ++c)
+                                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                                     for (int h = 0; h < 2; ++h)
-                                        res[c][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_off + (c * 16 + h * 4) * 4, 0, 0);
+                                        res[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(
+                                            r_rs, (((mi * 32 + r32) * (int)p.ldr + ni * 32 + hi * 8) + c * 16 + h * 4) * 4, 0, 0);
                             }
 #pragma unroll
-                            for (int c = 0; c < 2; ++c)
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int c_off = ((mi * 32 + r32) * (int)ldc + ni * 32 + hi * 8) * 4;
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
                                     f32x4 v;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[c][h][e]);
-                                        t += bv[c][h][e];
-                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[c][h][e]);
+                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e]);
+                                        if (fold) t = frs[mi] * t;
+                                        if (unfold) t += fmu[mi] * fg[h][e];
+                                        t += fbv[h][e];
+                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[mi][h][e]);
                                         v[e] = t;
                                     }
                                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs,
                                                                            c_off + (c * 16 + h * 4) * 4, 0, 0);
                                 }
+                            }
                         }
                     }
                 } else if constexpr (EPI == PL_GEGLU) {
@@ -559,9 +596,156 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                             }
                         }
                     }
+                } else if constexpr (EPI == PL_QKPACK) {
+                    // One head of Q or K per wave (64 columns = blocks 0 .. 1 of the wave tile; NI == 2): a lane holds 32 of
+                    // the 64 channels of token m (block ni, run c: d = 32 ni + 16 c + 8 hi + j), its partner lane (hi ^ 1)
+                    // the other 32.  RoPE pairs (2 p, 2 p + 1) are adjacent registers, the l2 norm is a lane-local sum plus
+                    // one exchange with the partner, and run (ni, c) IS the 16-byte chunk (k-step 2 ni + c, half hi) of the
+                    // packed attention operand: no cross-lane traffic, no fp32 Q / K in memory, no attn_pack pass.
+                    static_assert(NI == 2 || EPI != PL_QKPACK, "one head (64 columns) per wave");
+                    const bool is_k = n_w0 >= p.qk_k0;                     // wave-uniform
+                    const int head = ((is_k ? n_w0 - p.qk_k0 : n_w0) >> 6);
+                    unsigned char *outp = is_k ? p.kp : p.qp;
+                    const float *svec = is_k ? p.k_scale : p.q_scale;
+                    const float mul = is_k ? 1.0f : p.q_mul, so = is_k ? p.sk : p.sq;
+                    const bool fold = p.fold_stats && n_w0 < p.fold_cols;
+                    const bool unfold = p.fold_stats && !fold && p.fold_u;
+                    const int nblk = p.qk_ntok >> 5;
+                    if (n_w0 < p.N) {
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int64_t m = m_w0 + mi * 32 + r32;
+                            const int64_t mc = m < p.M ? m : p.M - 1;
+                            const int64_t seq = mc / p.qk_ntok;
+                            const int tok = (int)(mc - seq * p.qk_ntok);
+                            // pass 1: values of the row's 32 channels (column constants are re-read per group from L1: the
+                            // accumulators leave too few registers to hold four 32-wide constant vectors), RoPE, sum of squares
+                            f32x4 val[2][2][2];
+                            float ss = 0.0f;
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        const int dl = ni * 32 + c * 16 + hi * 8 + h * 4;
+                                        const f32x4 sw = *reinterpret_cast<const f32x4 *>(p.w_scale + n_w0 + dl);
+                                        f32x4 v;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[e]);
+                                        if (fold) {
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) v[e] = frs[mi] * v[e];
+                                            if (p.fold_b) v += *reinterpret_cast<const f32x4 *>(p.fold_b + n_w0 + dl);
+                                        } else if (unfold) {
+                                            const f32x4 fu = *reinterpret_cast<const f32x4 *>(p.fold_u + n_w0 + dl);
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) v[e] += fmu[mi] * fu[e];
+                                        }
+                                        if (p.cosT) {  // (a + ib)(c + is) on the pairs (d, d + 1), reference attention.py:65-69
+                                            const float2 cs = *reinterpret_cast<const float2 *>(p.cosT + tok * 32 + (dl >> 1));
+                                            const float2 sn = *reinterpret_cast<const float2 *>(p.sinT + tok * 32 + (dl >> 1));
+                                            const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
+                                            v[0] = a0 * cs.x - b0 * sn.x; v[1] = a0 * sn.x + b0 * cs.x;
+                                            v[2] = a1 * cs.y - b1 * sn.y; v[3] = a1 * sn.y + b1 * cs.y;
+                                        }
+                                        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                                        val[ni][c][h] = v;
+                                    }
+                            ss += swap32(ss);
+                            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, attention.py:24-25
+                            unsigned char *blkp = outp + ((seq * p.qk_heads + head) * nblk + (tok >> 5)) * 8192 + hi * 512 + (tok & 31) * 16;
+                            // pass 2: l2norm, learned scale, SDPA scale, operand scale, split, store
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) {
+                                    const int dl = ni * 32 + c * 16 + hi * 8;
+                                    const f32x4 s0 = *reinterpret_cast<const f32x4 *>(svec + dl);
+                                    const f32x4 s1 = *reinterpret_cast<const f32x4 *>(svec + dl + 4);
+                                    f32x4 va, vb;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        va[e] = (val[ni][c][0][e] * inv * s0[e] * mul) * so;
+                                        vb[e] = (val[ni][c][1][e] * inv * s1[e] * mul) * so;
+                                    }
+                                    const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb, f16x4);
+                                    const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
+                                    const f16x4 lb = __builtin_convertvector(vb - __builtin_convertvector(hb, f32x4), f16x4);
+                                    unsigned char *dst = blkp + (ni * 2 + c) * 1024;  // k-step 2 ni + c; plane 1 at + 4096
+                                    if (m < p.M) {
+                                        *reinterpret_cast<u32x4 *>(dst) =
+                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                        *reinterpret_cast<u32x4 *>(dst + 4096) =
+                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    }
+                                }
+                        }
+                    }
+                }
+            } else {
+                // SWAP: accumulator block [ni][mi] holds out[m][n] with lane = weight row position r32 of block ni (logical
+                // column pl_perm(r32)) and registers = 16 token rows in the MFMA C order, register r -> row (r & 3) +
+                // 8 (r >> 2) + 4 hi: registers 8 j .. 8 j + 7 are exactly one 16-byte chunk (16-key step j, half hi) of the
+                // attention kernel's packed V operand (attn_h2.hip: [plane][j][d half][h][d 32][8 halfs]).
+                static_assert(EPI == PL_VPACK || !SWAP, "the swapped orientation exists for the packed-V epilogue");
+                if (n_w0 < p.N) {
+                    const int nblk = p.v_ntok >> 5;
+                    float vb = p.v_bound;
+                    if (p.v_bound_dev) vb *= p.v_bound_dev[(p.v_rpc > 0 ? (bm * TM) / p.v_rpc : 0) * p.v_bound_stride];
+                    const float sv = h2_scale_of_bound(vb);
+                    const float *abase = ascl ? ascl : p.w_scale;
+                    float has = ascl ? 1.0f : 0.0f;
+                    int64_t mmax = ascl ? p.M - 1 : 0;
+                    asm volatile("" : "+v"(abase), "+v"(has), "+v"(mmax));
+                    const float *mbase = p.fold_stats ? p.fold_stats : p.w_scale;   // row means (times un = 0 without a fold)
+                    int64_t mumax = p.fold_stats ? p.M - 1 : 0;
+                    asm volatile("" : "+v"(mbase), "+v"(mumax));
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int vcol = n_w0 + ni * 32 + pl_perm(r32);    // column inside V: head vcol / 64, d half (vcol / 32) & 1
+                        const float swn = p.w_scale[vcol] * ascl_c * sv;
+                        const float un = (p.fold_stats && p.fold_u) ? p.fold_u[vcol] * sv : 0.0f;  // centred operand: + mean u
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int64_t row = m_w0 + mi * 32;               // first token of this 32-token block
+                            const int64_t seq = (row < p.M ? row : p.M - 1) / p.v_ntok;
+                            const int blk = (int)((row < p.M ? row : p.M - 1) - seq * p.v_ntok) >> 5;
+                            unsigned char *dst = p.vp + ((seq * p.v_heads + (vcol >> 6)) * nblk + blk) * 8192 +
+                                                 ((((vcol >> 5) & 1) * 2 + hi) * 32 + (vcol & 31)) * 16;
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                f32x4 pa, pb;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int64_t ra = row + 16 * j + 4 * hi + e, rb = ra + 8;
+                                    const float sa_a = abase[ra < mmax ? ra : mmax] * has + (1.0f - has);
+                                    const float sa_b = abase[rb < mmax ? rb : mmax] * has + (1.0f - has);
+                                    pa[e] = acc[ni][mi][8 * j + e] * (sa_a * swn) + mbase[2 * (ra < mumax ? ra : mumax)] * un;
+                                    pb[e] = acc[ni][mi][8 * j + 4 + e] * (sa_b * swn) + mbase[2 * (rb < mumax ? rb : mumax)] * un;
+                                }
+                                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                                const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                                const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                                if (row < p.M) {
+                                    *reinterpret_cast<u32x4 *>(dst + j * 2048) =
+                                        __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    *reinterpret_cast<u32x4 *>(dst + 4096 + j * 2048) =
+                                        __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
+        // Every memory operation of the epilogue is complete before the next tile's K loop: a load that the compiler's
+        // waitcnt pass still sees "pending" on some path (e.g. one issued inside a wave-uniform branch) would otherwise
+        // make it drain vmcnt -- and with it the LDS-DMA ring -- in front of the fragment reads of EVERY K step.  The wait
+        // costs the store latency once per tile; the kernel is power-bound, not stall-bound (profiles/r03_gemm_limiter_probe.txt).
+        PL_WAIT_VM(0);
         zero_acc();
     }
     if (p.cycles && blockIdx.x == 0 && tid == 0) {

@@ -116,7 +116,11 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
 
 template <int EPI>
 static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
-    if constexpr (EPI == PL_ROWLN) {
+    if constexpr (EPI == PL_VPACK) {
+        return launch_pl_cfg<EPI, true, PlCfg<4, 2, 4>>(p, stream);
+    } else if constexpr (EPI == PL_QKPACK) {
+        return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+    } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
     } else {
         switch (cfg) {
@@ -202,6 +206,16 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
     p.N = g->N;
     p.K = g->K;
     p.cycles = g->debug_cycles;
+    if (g->fold_stats) {
+        OT_CHECK_ARG(g->fold_cols >= 0 && g->fold_cols % 64 == 0 && (g->fold_cols >= g->N || g->fold_u) &&
+                         (g->epilogue == PL_F32 || g->epilogue == PL_QKPACK || g->epilogue == PL_VPACK),
+                     "gemm_pl: a centred operand needs fold_cols %% 64 == 0, the row sums fold_u for the columns >= fold_cols, "
+                     "and epilogue 0, 3 or 4");
+        p.fold_stats = g->fold_stats;
+        p.fold_b = g->fold_b;
+        p.fold_u = g->fold_u;
+        p.fold_cols = g->fold_cols;
+    }
     const int cfg = g->cfg > 0 ? g->cfg : (g_pl_cfg > 0 ? g_pl_cfg : 1);
     OT_CHECK_ARG(p.a_split_n % 256 == 0 && p.c_split_n % 256 == 0, "gemm_pl: split columns must be multiples of 256");
     switch (g->epilogue) {
@@ -213,6 +227,40 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             OT_CHECK_ARG(g->out_planes && g->N % 64 == 0 && g->out_planes_k == g->N / 2 && g->out_bound > 0.0f,
                          "gemm_pl: GEGLU needs out_planes with out_planes_k == N / 2 and a bound of the hidden");
             return launch_pl<PL_GEGLU>(p, cfg, stream);
+        case PL_VPACK:
+            OT_CHECK_ARG(g->vp && aligned16(g->vp) && g->heads > 0 && g->N == g->heads * 64 && g->n_tokens > 0 &&
+                             g->n_tokens % 32 == 0 && g->M % g->n_tokens == 0 && g->v_bound > 0.0f && !g->a2 &&
+                             (!g->v_bound_dev || (g->rows_per_clip > 0 && g->rows_per_clip % 256 == 0)),
+                         "gemm_pl: packed V needs vp, N == heads * 64, whole sequences of n_tokens %% 32 == 0 rows, a bound and "
+                         "rows_per_clip %% 256 == 0");
+            p.vp = static_cast<unsigned char *>(g->vp);
+            p.v_ntok = g->n_tokens;
+            p.v_heads = g->heads;
+            p.v_bound = g->v_bound;
+            p.v_bound_dev = g->v_bound_dev;
+            p.v_bound_stride = g->v_bound_stride > 0 ? g->v_bound_stride : 1;
+            p.v_rpc = g->v_bound_dev ? g->rows_per_clip : 0;
+            return launch_pl<PL_VPACK>(p, cfg, stream);
+        case PL_QKPACK:
+            OT_CHECK_ARG(g->qp && g->kp && aligned16(g->qp) && aligned16(g->kp) && g->heads > 0 && g->qk_k0 == g->heads * 64 &&
+                             g->N == 2 * g->qk_k0 && g->n_tokens > 0 && g->n_tokens % 32 == 0 && g->M % g->n_tokens == 0 &&
+                             g->q_scale && g->k_scale && g->q_bound > 0.0f && g->k_bound > 0.0f &&
+                             (g->rope_cos == nullptr) == (g->rope_sin == nullptr),
+                         "gemm_pl: packed Q | K needs qp, kp, N == 2 * heads * 64, whole sequences of n_tokens %% 32 == 0 rows, "
+                         "the q / k scale vectors and bounds");
+            p.qp = static_cast<unsigned char *>(g->qp);
+            p.kp = static_cast<unsigned char *>(g->kp);
+            p.qk_k0 = g->qk_k0;
+            p.qk_ntok = g->n_tokens;
+            p.qk_heads = g->heads;
+            p.cosT = g->rope_cos;
+            p.sinT = g->rope_sin;
+            p.q_scale = g->q_scale;
+            p.k_scale = g->k_scale;
+            p.q_mul = g->q_mul;
+            p.sq = h2_scale_of_bound(g->q_bound);
+            p.sk = h2_scale_of_bound(g->k_bound);
+            return launch_pl<PL_QKPACK>(p, cfg, stream);
         case PL_ROWLN:
             OT_CHECK_ARG(g->N == 512 && g->c && g->ldc % 4 == 0 && aligned16(g->c) && g->out_planes && g->out_planes_k == g->N &&
                              g->out_bound > 0.0f && g->ln_gamma && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))) &&

@@ -1,6 +1,7 @@
 // HBM-bound row kernels: LayerNorm, patch gather + LayerNorm, un-patchify scatter and the
 // token-order transpose.  One wave64 per row, 16-byte accesses, no LDS.
 #include "common.h"
+#include "planes.h"
 
 namespace omnitok {
 
@@ -244,6 +245,93 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const f32x4 *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stats + pack: the row statistics of x (mean, rstd: what row_stats_kernel computes) AND x itself as fp16 hi|lo planes
+// with one power-of-two scale per row -- the raw-activation operand of the q|k|v plane GEMM (gemm_pl.h; reference
+// attention.py:404-412: K and V are projected from the un-normalised x, Q from LayerNorm(x), which the GEMM epilogue
+// recovers from the same planes with the statistics).  Replaces the row-statistics pass in front of the attention GEMMs.
+// Workgroup = 64 rows (one row block of planes), wave = 16 rows held in registers (H float4 per lane and row, lanes along
+// k: coalesced loads); the chunks go through LDS so that every global store instruction writes 4 runs of 256 bytes
+// (16 consecutive rows x 16 B of one (k block, plane, k group)).
+constexpr int SP_CSTRIDE = 16 * 16 + 16;  // LDS stride of a 16-row chunk column (16 B pad: bank spread)
+
+template <int H>
+__global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restrict__ x, int64_t rows, float eps, int center,
+                                                            unsigned char *__restrict__ planes, float *__restrict__ a_scale,
+                                                            float *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
+    constexpr int K = 256 * H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
+    unsigned char *lds = sp_lds + wave * (2 * 32 * SP_CSTRIDE);  // [plane][32 chunks][16 rows][16 B] (padded)
+    f32x4 v[16][H];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + r;
+        const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (row < rows ? row : rows - 1) * K);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            v[r][h] = __builtin_nontemporal_load(xr + lane + 64 * h);
+            if (row >= rows) v[r][h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // pad rows of the plane block are zero
+        }
+    }
+    float scl[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) s += (v[r][h][0] + v[r][h][1]) + (v[r][h][2] + v[r][h][3]);
+        s = wave_allsum(s);
+        const float mean = s / (float)K;
+        float q = 0.0f;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const float a = v[r][h][0] - mean, b = v[r][h][1] - mean, c = v[r][h][2] - mean, d = v[r][h][3] - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+            if (center) v[r][h] = f32x4{a, b, c, d};  // x - mean, rounded once like LayerNorm's own first step
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[r][h][0]), fabsf(v[r][h][1])), fmaxf(fabsf(v[r][h][2]), fabsf(v[r][h][3]))));
+        }
+        q = wave_allsum(q);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const float sc = h2_scale_of_bound(mx);
+        scl[r] = sc;
+        const int64_t row = row0 + r;
+        if (lane == 0 && row < rows) {
+            if (stats) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, 1.0f / sqrtf(q / (float)K + eps));
+            a_scale[row] = 1.0f / sc;
+        }
+    }
+    const int kblocks = K >> 5;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        // this half's 32 chunks of 8 k: lane pair (2 j, 2 j + 1) holds chunk j
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const f32x4 t = v[r][h] * scl[r];  // exact (power of two)
+            const f16x4 hh = __builtin_convertvector(t, f16x4);
+            const f16x4 ll = __builtin_convertvector(t - __builtin_convertvector(hh, f32x4), f16x4);
+            unsigned char *dst = lds + (lane >> 1) * SP_CSTRIDE + r * 16 + (lane & 1) * 8;
+            *reinterpret_cast<u32x2 *>(dst) = __builtin_bit_cast(u32x2, hh);
+            *reinterpret_cast<u32x2 *>(dst + 32 * SP_CSTRIDE) = __builtin_bit_cast(u32x2, ll);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes (no other wave touches this region)
+        __builtin_amdgcn_wave_barrier();
+        // stores: lane -> (chunk column cc = lane / 16, row r = lane % 16); 4 chunk columns per instruction
+        const int cc = lane >> 4, r = lane & 15;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int c0 = 0; c0 < 32; c0 += 4) {
+                const int c = c0 + cc;             // chunk inside this half
+                const int cg = h * 32 + c;         // chunk of the row: k block cg / 4, k group cg % 4
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(lds + (p * 32 + c) * SP_CSTRIDE + r * 16);
+                *reinterpret_cast<u32x4 *>(planes + pl_chunk_offset(row0 + r, cg >> 2, cg & 3, kblocks) + p * 4096) = w;
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned *__restrict__ p, unsigned value, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = value;
 }
@@ -308,6 +396,43 @@ extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float ep
                            rows, rpc, dim, bounds);
     }
     OT_LAUNCH_CHECK("row_stats");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                                  float *a_scale, float *stats, float *bounds, int64_t rows_per_clip,
+                                  omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && planes && a_scale, "stats_pack: null pointer");
+    OT_CHECK_ARG(dim > 0 && dim % 256 == 0 && dim <= 1024, "stats_pack: dim=%d (multiples of 256 up to 1024)", dim);
+    OT_CHECK_ARG(m_pad >= rows && m_pad % 64 == 0 && aligned16(x) && aligned16(planes) &&
+                     (!stats || (reinterpret_cast<uintptr_t>(stats) & 7) == 0) && (!bounds || stats),
+                 "stats_pack: m_pad %% 64, alignment, bounds need stats");
+    if (m_pad == 0) return OMNITOK_OK;
+    const int lds = 4 * 2 * 32 * SP_CSTRIDE;
+    const dim3 grid((unsigned)(m_pad / 64));
+#define OT_SP(Hh)                                                                                                      \
+    do {                                                                                                               \
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh>), lds)) return rc;       \
+        hipLaunchKernelGGL(stats_pack_kernel<Hh>, grid, dim3(256), lds, stream, x, rows, eps, center,                  \
+                           static_cast<unsigned char *>(planes), a_scale, stats);                                      \
+    } while (0)
+    switch (dim / 256) {
+        case 1: OT_SP(1); break;
+        case 2: OT_SP(2); break;
+        case 3: OT_SP(3); break;
+        default: OT_SP(4); break;
+    }
+#undef OT_SP
+    OT_LAUNCH_CHECK("stats_pack");
+    if (bounds && rows > 0) {
+        const int64_t rpc = rows_per_clip > 0 ? rows_per_clip : rows;
+        const int64_t n_clips = (rows + rpc - 1) / rpc;
+        OT_CHECK_ARG(n_clips <= 65535, "stats_pack: %lld clips (max 65535)", (long long)n_clips);
+        hipLaunchKernelGGL(range_from_stats_kernel, dim3(RANGE_SPLIT, (unsigned)n_clips), dim3(256), 0, stream, stats, rows, rpc,
+                           dim, bounds);
+        OT_LAUNCH_CHECK("range_from_stats");
+    }
     return OMNITOK_OK;
 }
 

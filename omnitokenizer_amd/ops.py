@@ -245,11 +245,42 @@ def pl_unpack_planes(planes, M, K):
     return v[:M]
 
 
+def stats_pack(x, eps=1e-5, center=False):
+    """Row statistics and planes of x [M, K] in one pass (K % 256 == 0): (planes, row scales, stats [M, 2] = mean, rstd).
+    center: the planes hold x - mean (the operand of linear_pl(fold=...))."""
+    x = _req(x, "x")
+    M, K = x.shape
+    planes = torch.empty(_pad256(M) * K, device=x.device, dtype=torch.int32)
+    scales = torch.empty(max(M, 1), device=x.device, dtype=torch.float32)
+    stats = torch.empty(max(M, 1), 2, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_stats_pack(_p(x), M, K, eps, int(bool(center)), _p(planes), _pad256(M), _p(scales), _p(stats), None,
+                                         0, _stream()), "stats_pack")
+    return planes, scales, stats
+
+
+def fold_layernorm_weight(weight, gamma, beta=None, rows_fold=None):
+    """(w', b, u) for linear_pl(fold=...) on a centred operand: rows < rows_fold of w multiplied by gamma with b = w beta,
+    u = row sums of the other rows (what the engine prepares once per layer)."""
+    rows_fold = weight.shape[0] if rows_fold is None else rows_fold
+    w2 = weight.clone()
+    w2[:rows_fold] = weight[:rows_fold] * gamma[None, :]
+    b = torch.zeros(weight.shape[0], device=weight.device)
+    if beta is not None:
+        b[:rows_fold] = (weight[:rows_fold].double() @ beta.double()).float()
+    u = torch.zeros(weight.shape[0], device=weight.device)
+    u[rows_fold:] = weight[rows_fold:].double().sum(1).float()
+    return w2.contiguous(), b.contiguous(), u.contiguous()
+
+
 def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias=None, residual=None, epilogue=0,
-              out_bound=0.0, ln=None, a2=None, a_split_n=0, c_split_n=0, cfg=0):
+              out_bound=0.0, ln=None, a2=None, a_split_n=0, c_split_n=0, cfg=0, fold=None, attn=None):
     """c = a . w^T from plane operands.  epilogue 0: fp32 [M, N] (+ bias, + residual; c_split_n: two outputs);
     1: GEGLU -> hidden planes [M, N / 2]; 2: (fp32, planes of LayerNorm(c)) with ln = (gamma, beta or None, eps).
-    a2 = (planes, scales or None, const): second activation operand for output columns >= a_split_n."""
+    a2 = (planes, scales or None, const): second activation operand for output columns >= a_split_n.
+    fold = (stats, b or None, u or None, fold_cols): LayerNorm folded into the weight, operand = centred planes of
+    stats_pack(center=True): columns < fold_cols get rstd * acc + b, the others acc + mean * u (epilogues 0, 3, 4).
+    epilogue 4 (packed Q | K) and 3 (packed V, N = heads * 64) take attn = dict(n_tokens, heads, q_scale, k_scale, cos, sin,
+    q_mul, q_bound, k_bound, v_bound) and return int32 buffers in the layout of attn_pack."""
     g = _lib.OmnitokPlGemm()
     dev = a_planes.device
     g.a = a_planes.data_ptr()
@@ -281,6 +312,27 @@ def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias
         op = torch.empty(_pad256(M) * ko, device=dev, dtype=torch.int32)
         g.out_planes, g.out_planes_k, g.out_bound = op.data_ptr(), ko, float(out_bound)
         outs.append(op)
+    if fold is not None:
+        g.fold_stats = fold[0].data_ptr()
+        g.fold_b = fold[1].data_ptr() if fold[1] is not None else None
+        g.fold_u = fold[2].data_ptr() if fold[2] is not None else None
+        g.fold_cols = int(fold[3])
+    if epilogue in (3, 4):
+        heads, nt = attn["heads"], attn["n_tokens"]
+        g.n_tokens, g.heads = nt, heads
+        if epilogue == 4:
+            qp = torch.empty(M * heads * 64, device=dev, dtype=torch.int32)
+            kp = torch.empty(M * heads * 64, device=dev, dtype=torch.int32)
+            g.qp, g.kp, g.qk_k0 = qp.data_ptr(), kp.data_ptr(), heads * 64
+            g.q_scale, g.k_scale = attn["q_scale"].data_ptr(), attn["k_scale"].data_ptr()
+            if attn.get("cos") is not None:
+                g.rope_cos, g.rope_sin = attn["cos"].data_ptr(), attn["sin"].data_ptr()
+            g.q_mul, g.q_bound, g.k_bound = float(attn["q_mul"]), float(attn["q_bound"]), float(attn["k_bound"])
+            outs = [qp, kp]
+        else:
+            vp = torch.empty(M * heads * 64, device=dev, dtype=torch.int32)
+            g.vp, g.v_bound = vp.data_ptr(), float(attn["v_bound"])
+            outs = [vp]
     if epilogue == 2:
         g.ln_gamma = ln[0].data_ptr()
         g.ln_beta = ln[1].data_ptr() if ln[1] is not None else None

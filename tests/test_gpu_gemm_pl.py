@@ -142,6 +142,79 @@ def test_pl_gemm_layernorm_epilogue(ops, M, with_beta):
     assert torch.equal(ops.pl_unpack_planes(lnp1, 128, 512), ops.pl_unpack_planes(lnp, 128, 512))
 
 
+def test_stats_pack_matches_row_stats_and_pack_rows(ops):
+    x = rnd(1000, 512, seed=40) * torch.logspace(-2, 2, 1000).cuda()[:, None] + 0.3
+    planes, scales, stats = ops.stats_pack(x)
+    ref_planes, ref_scales = ops.pl_pack_rows(x)
+    assert torch.equal(scales, ref_scales)
+    # centred form: the planes of x - mean (fp32 subtraction of the mean the kernel reports)
+    cpl, csc, cst = ops.stats_pack(x, center=True)
+    assert torch.equal(cst, stats)
+    xc = x - stats[:, :1]
+    rpl, rsc = ops.pl_pack_rows(xc.contiguous())
+    assert torch.equal(csc, rsc) and torch.equal(ops.pl_unpack_planes(cpl, 1000, 512), ops.pl_unpack_planes(rpl, 1000, 512))
+    assert torch.equal(ops.pl_unpack_planes(planes, 1000, 512), ops.pl_unpack_planes(ref_planes, 1000, 512))
+    st = ops.row_stats(x)
+    assert maxerr(stats[:, 0], st[:, 0]) < 1e-6 * float(x.abs().max()) and ((stats[:, 1] - st[:, 1]).abs() <= 1e-6 * st[:, 1]).all()
+    assert (ops.pl_unpack_planes(planes, 1024, 512)[1000:] == 0).all()  # pad rows of the last block are zero
+
+
+@pytest.mark.parametrize("with_beta", [False, True])
+def test_pl_gemm_folded_layernorm(ops, with_beta):
+    # merged q | k | v from the planes of the CENTRED rows: Q = LayerNorm(x) . Wq^T (gain folded into the weight, rstd and
+    # b = Wq beta in the epilogue), K | V = x . Wkv^T = (x - mean) . Wkv^T + mean u (reference attention.py:404-412);
+    # rows with a large mean: no cancellation anywhere
+    M, D = 1300, 512
+    x = rnd(M, D, seed=41, scale=2.0) + torch.linspace(-3, 3, M).cuda()[:, None]
+    w = rnd(3 * D, D, seed=42, scale=0.05)
+    gamma = 1.0 + 0.2 * rnd(D, seed=43)
+    beta = 0.1 * rnd(D, seed=44) if with_beta else None
+    planes, scales, stats = ops.stats_pack(x, center=True)
+    w2, b, u = ops.fold_layernorm_weight(w, gamma, beta, rows_fold=D)
+    q, kv = ops.linear_pl(planes, ops.pl_pack_weight(w2), M, 3 * D, D, a_scale=scales, fold=(stats, b, u, D), c_split_n=D)
+    ln = F.layer_norm(x.double(), (D,), gamma.double(), beta.double() if with_beta else None, 1e-5)
+    assert maxerr(q, ln @ w[:D].double().t()) < 2e-5
+    assert maxerr(kv, x.double() @ w[D:].double().t()) < 2e-5
+
+
+@pytest.mark.parametrize("rope", [True, False])
+def test_pl_gemm_packs_attention_operands(ops, rope):
+    """The q | k launch with the packing epilogue and the swapped-orientation V launch write what attn_pack writes
+    (RoPE + l2norm + scales; reference attention.py:417-437): spatial attention on them equals the fp32 route."""
+    Bn, N, heads, D = 3, 256, 8, 512
+    M = Bn * N
+    x = rnd(M, D, seed=45, scale=1.5) + 0.2
+    w = rnd(3 * D, D, seed=46, scale=0.05)
+    gamma = 1.0 + 0.2 * rnd(D, seed=47)
+    qs, ks = 1.0 + 0.1 * rnd(64, seed=48), 1.0 + 0.1 * rnd(64, seed=49)
+    cos, sin = (t.cuda() for t in ops.rope_table(N)) if rope else (None, None)
+    # fp32 route: LN -> projections -> attn_pack -> attention
+    ln = F.layer_norm(x, (D,), gamma, None, 1e-5)
+    q = (ln.double() @ w[:D].double().t()).float()
+    k = (x.double() @ w[D:2 * D].double().t()).float()
+    v = (x.double() @ w[2 * D:].double().t()).float()
+    packed, bounds = ops.attn_pack(q, k, v, N, heads, qs, ks, cos=cos, sin=sin)
+    o_ref = ops.attn_spatial_h2(packed, bounds, Bn, N, heads)
+    # plane route
+    planes, scales, stats = ops.stats_pack(x, center=True)
+    w2, b, u = ops.fold_layernorm_weight(w, gamma, None, rows_fold=D)
+    wp = ops.pl_pack_weight(w2)
+    attn = dict(n_tokens=N, heads=heads, q_scale=qs, k_scale=ks, cos=cos, sin=sin, q_mul=8.0, q_bound=bounds[0],
+                k_bound=bounds[1], v_bound=bounds[2])
+    qp, kp = ops.linear_pl(planes, wp, M, 2 * D, D, a_scale=scales, fold=(stats, b, u, D), epilogue=4, attn=attn)
+    wv = ops.pl_pack_weight(w2[2 * D:].contiguous())
+    vp = ops.linear_pl(planes, wv, M, D, D, a_scale=scales, fold=(stats, None, u[2 * D:].contiguous(), 0), epilogue=3, attn=attn)
+
+    def unpack(buf):   # hi + lo of every packed element, position by position
+        h = buf.view(torch.float16).view(-1, 2, 4096 // 2)  # [32-token block of a head][plane][2048 halfs]
+        return h[:, 0].double() + h[:, 1].double()
+    for name, got, ref in (("q", qp, packed[0]), ("k", kp, packed[1]), ("v", vp, packed[2])):
+        d = (unpack(got) - unpack(ref)).abs().max().item()
+        assert d <= 2.0 ** 15 * 2e-5, (name, d)   # operands are scaled to <= 2^15: 2e-5 relative to the bound
+    o = ops.attn_spatial_h2(torch.stack([qp, kp, vp]), bounds, Bn, N, heads)
+    assert maxerr(o, o_ref) < 3e-5 * float(v.abs().max())
+
+
 def test_pl_gemm_argument_errors(ops):
     x, w = rnd(64, 512, seed=21), rnd(500, 512, seed=22)
     with pytest.raises(ValueError):
