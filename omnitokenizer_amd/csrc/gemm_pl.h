@@ -612,76 +612,97 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     const bool unfold = p.fold_stats && !fold && p.fold_u;
                     const int nblk = p.qk_ntok >> 5;
                     if (n_w0 < p.N) {
+                        // rows of this lane: token index inside its sequence and the 32-token block it belongs to
+                        int tok[MI];
+                        unsigned char *blkp[MI];
+                        bool live[MI];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
-                            __builtin_amdgcn_sched_barrier(0);
                             const int64_t m = m_w0 + mi * 32 + r32;
                             const int64_t mc = m < p.M ? m : p.M - 1;
                             const int64_t seq = mc / p.qk_ntok;
-                            const int tok = (int)(mc - seq * p.qk_ntok);
-                            // pass 1: values of the row's 32 channels (column constants are re-read per group from L1: the
-                            // accumulators leave too few registers to hold four 32-wide constant vectors), RoPE, sum of squares
-                            f32x4 val[2][2][2];
-                            float ss = 0.0f;
+                            tok[mi] = (int)(mc - seq * p.qk_ntok);
+                            live[mi] = m < p.M;
+                            blkp[mi] = outp + ((seq * p.qk_heads + head) * nblk + (tok[mi] >> 5)) * 8192 + hi * 512 + (tok[mi] & 31) * 16;
+                        }
+                        // phase A: projected values (scales, folded LayerNorm / mean add-back, RoPE) written back INTO the
+                        // accumulators, sums of squares per row.  Column constants are loaded once per 8 columns and reused
+                        // for the MI row blocks.
+                        float ss[MI];
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni)
+                        for (int mi = 0; mi < MI; ++mi) ss[mi] = 0.0f;
 #pragma unroll
-                                for (int c = 0; c < 2; ++c)
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                f32x4 sw[2], fx[2];
+#pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    const int dl = ni * 32 + c * 16 + hi * 8 + h * 4;
+                                    sw[h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n_w0 + dl);
+                                    fx[h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                                    if (fold && p.fold_b) fx[h] = *reinterpret_cast<const f32x4 *>(p.fold_b + n_w0 + dl);
+                                    if (unfold) fx[h] = *reinterpret_cast<const f32x4 *>(p.fold_u + n_w0 + dl);
+                                }
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi) {
+                                    const float ra = fold ? frs[mi] : 1.0f, rb = fold ? 1.0f : (unfold ? fmu[mi] : 0.0f);
 #pragma unroll
                                     for (int h = 0; h < 2; ++h) {
-                                        const int dl = ni * 32 + c * 16 + hi * 8 + h * 4;
-                                        const f32x4 sw = *reinterpret_cast<const f32x4 *>(p.w_scale + n_w0 + dl);
                                         f32x4 v;
 #pragma unroll
-                                        for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[e]);
-                                        if (fold) {
-#pragma unroll
-                                            for (int e = 0; e < 4; ++e) v[e] = frs[mi] * v[e];
-                                            if (p.fold_b) v += *reinterpret_cast<const f32x4 *>(p.fold_b + n_w0 + dl);
-                                        } else if (unfold) {
-                                            const f32x4 fu = *reinterpret_cast<const f32x4 *>(p.fold_u + n_w0 + dl);
-#pragma unroll
-                                            for (int e = 0; e < 4; ++e) v[e] += fmu[mi] * fu[e];
-                                        }
+                                        for (int e = 0; e < 4; ++e)
+                                            v[e] = ra * (acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e])) + rb * fx[h][e];
                                         if (p.cosT) {  // (a + ib)(c + is) on the pairs (d, d + 1), reference attention.py:65-69
-                                            const float2 cs = *reinterpret_cast<const float2 *>(p.cosT + tok * 32 + (dl >> 1));
-                                            const float2 sn = *reinterpret_cast<const float2 *>(p.sinT + tok * 32 + (dl >> 1));
+                                            const int pr = (ni * 32 + c * 16 + hi * 8 + h * 4) >> 1;
+                                            const float2 cs = *reinterpret_cast<const float2 *>(p.cosT + tok[mi] * 32 + pr);
+                                            const float2 sn = *reinterpret_cast<const float2 *>(p.sinT + tok[mi] * 32 + pr);
                                             const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
                                             v[0] = a0 * cs.x - b0 * sn.x; v[1] = a0 * sn.x + b0 * cs.x;
                                             v[2] = a1 * cs.y - b1 * sn.y; v[3] = a1 * sn.y + b1 * cs.y;
                                         }
-                                        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                                        val[ni][c][h] = v;
+                                        ss[mi] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc[ni][mi][c * 8 + h * 4 + e] = v[e];
                                     }
-                            ss += swap32(ss);
-                            const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps, attention.py:24-25
-                            unsigned char *blkp = outp + ((seq * p.qk_heads + head) * nblk + (tok >> 5)) * 8192 + hi * 512 + (tok & 31) * 16;
-                            // pass 2: l2norm, learned scale, SDPA scale, operand scale, split, store
+                                }
+                            }
+                        float inv[MI];
 #pragma unroll
-                            for (int ni = 0; ni < 2; ++ni)
+                        for (int mi = 0; mi < MI; ++mi) {
+                            const float t = ss[mi] + swap32(ss[mi]);
+                            inv[mi] = mul * so / fmaxf(sqrtf(t), 1e-12f);  // F.normalize eps (attention.py:24-25), SDPA scale,
+                        }                                                   // power-of-two operand scale
+                        // phase B: l2norm, learned scale, split, store
 #pragma unroll
-                                for (int c = 0; c < 2; ++c) {
-                                    const int dl = ni * 32 + c * 16 + hi * 8;
-                                    const f32x4 s0 = *reinterpret_cast<const f32x4 *>(svec + dl);
-                                    const f32x4 s1 = *reinterpret_cast<const f32x4 *>(svec + dl + 4);
+                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const int dl = ni * 32 + c * 16 + hi * 8;
+                                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(svec + dl);
+                                const f32x4 s1 = *reinterpret_cast<const f32x4 *>(svec + dl + 4);
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi) {
                                     f32x4 va, vb;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        va[e] = (val[ni][c][0][e] * inv * s0[e] * mul) * so;
-                                        vb[e] = (val[ni][c][1][e] * inv * s1[e] * mul) * so;
+                                        va[e] = acc[ni][mi][c * 8 + e] * s0[e] * inv[mi];
+                                        vb[e] = acc[ni][mi][c * 8 + 4 + e] * s1[e] * inv[mi];
                                     }
                                     const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb, f16x4);
                                     const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
                                     const f16x4 lb = __builtin_convertvector(vb - __builtin_convertvector(hb, f32x4), f16x4);
-                                    unsigned char *dst = blkp + (ni * 2 + c) * 1024;  // k-step 2 ni + c; plane 1 at + 4096
-                                    if (m < p.M) {
+                                    unsigned char *dst = blkp[mi] + (ni * 2 + c) * 1024;  // k-step 2 ni + c; plane 1 at + 4096
+                                    if (live[mi]) {
                                         *reinterpret_cast<u32x4 *>(dst) =
                                             __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
                                         *reinterpret_cast<u32x4 *>(dst + 4096) =
                                             __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
                                     }
                                 }
-                        }
+                            }
                     }
                 }
             } else {
@@ -702,29 +723,43 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     const float *mbase = p.fold_stats ? p.fold_stats : p.w_scale;   // row means (times un = 0 without a fold)
                     int64_t mumax = p.fold_stats ? p.M - 1 : 0;
                     asm volatile("" : "+v"(mbase), "+v"(mumax));
+                    float swn[NI], un[NI];
+                    int vcol[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        const int vcol = n_w0 + ni * 32 + pl_perm(r32);    // column inside V: head vcol / 64, d half (vcol / 32) & 1
-                        const float swn = p.w_scale[vcol] * ascl_c * sv;
-                        const float un = (p.fold_stats && p.fold_u) ? p.fold_u[vcol] * sv : 0.0f;  // centred operand: + mean u
+                        vcol[ni] = n_w0 + ni * 32 + pl_perm(r32);    // column inside V: head vcol / 64, d half (vcol / 32) & 1
+                        swn[ni] = p.w_scale[vcol[ni]] * ascl_c * sv;
+                        un[ni] = (p.fold_stats && p.fold_u) ? p.fold_u[vcol[ni]] * sv : 0.0f;  // centred operand: + mean u
+                    }
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int64_t row = m_w0 + mi * 32;               // first token of this 32-token block
-                            const int64_t seq = (row < p.M ? row : p.M - 1) / p.v_ntok;
-                            const int blk = (int)((row < p.M ? row : p.M - 1) - seq * p.v_ntok) >> 5;
-                            unsigned char *dst = p.vp + ((seq * p.v_heads + (vcol >> 6)) * nblk + blk) * 8192 +
-                                                 ((((vcol >> 5) & 1) * 2 + hi) * 32 + (vcol & 31)) * 16;
+                    for (int mi = 0; mi < MI; ++mi) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int64_t row = m_w0 + mi * 32;               // first token of this 32-token block
+                        // row factors: lane r32 loads those of row + r32 (coalesced), registers pick theirs by lane shuffles
+                        const int64_t rl = row + r32;
+                        const float sa_l = abase[rl < mmax ? rl : mmax] * has + (1.0f - has);
+                        const float mu_l = mbase[2 * (rl < mumax ? rl : mumax)];
+                        float sa_r[16], mu_r[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int src = (r & 3) + 8 * (r >> 2) + 4 * hi;  // row of accumulator register r inside the block
+                            sa_r[r] = __shfl(sa_l, src);
+                            mu_r[r] = __shfl(mu_l, src);
+                        }
+                        const int64_t rc = row < p.M ? row : p.M - 1;
+                        const int64_t seq = rc / p.v_ntok;
+                        const int blk = (int)(rc - seq * p.v_ntok) >> 5;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            unsigned char *dst = p.vp + ((seq * p.v_heads + (vcol[ni] >> 6)) * nblk + blk) * 8192 +
+                                                 ((((vcol[ni] >> 5) & 1) * 2 + hi) * 32 + (vcol[ni] & 31)) * 16;
 #pragma unroll
                             for (int j = 0; j < 2; ++j) {
                                 f32x4 pa, pb;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    const int64_t ra = row + 16 * j + 4 * hi + e, rb = ra + 8;
-                                    const float sa_a = abase[ra < mmax ? ra : mmax] * has + (1.0f - has);
-                                    const float sa_b = abase[rb < mmax ? rb : mmax] * has + (1.0f - has);
-                                    pa[e] = acc[ni][mi][8 * j + e] * (sa_a * swn) + mbase[2 * (ra < mumax ? ra : mumax)] * un;
-                                    pb[e] = acc[ni][mi][8 * j + 4 + e] * (sa_b * swn) + mbase[2 * (rb < mumax ? rb : mumax)] * un;
+                                    pa[e] = acc[ni][mi][8 * j + e] * (sa_r[8 * j + e] * swn[ni]) + mu_r[8 * j + e] * un[ni];
+                                    pb[e] = acc[ni][mi][8 * j + 4 + e] * (sa_r[8 * j + 4 + e] * swn[ni]) + mu_r[8 * j + 4 + e] * un[ni];
                                 }
                                 const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
                                 const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
