@@ -25,6 +25,8 @@ HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), 
            os.path.join(os.path.dirname(HERE), "include", "omnitok_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
          "-Wno-unused-result"]
+# measurement builds only (e.g. OMNITOK_EXTRA_FLAGS=-DOMNITOK_PL_MEASUREMENT_BUILDS for tools/pl_bench's ablation arms)
+FLAGS += os.environ.get("OMNITOK_EXTRA_FLAGS", "").split()
 
 
 def _hipcc() -> str:

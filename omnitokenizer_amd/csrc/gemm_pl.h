@@ -86,6 +86,7 @@ struct PlParams {
     int N, K;
     int nbm, nbn, ntiles, gn;
     long long *cycles;                // measurement: s_memtime span of workgroup 0 (null = off)
+    int stagger;                      // start delay step in ~1 us units ("pl_stagger"); workgroup phase = (id / 8) % 8
 };
 
 // logical row (inside a group of 32) stored at physical position i: the MFMA a-slot row i lands in lane half
@@ -103,7 +104,7 @@ __host__ __device__ __forceinline__ int64_t pl_offset(int64_t row, int k, int pl
 #define PL_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
 // D = how many K steps the DMA cursor runs ahead (D < R).  DBG (measurement builds, wrong results): 1 no vmcnt wait in
-// front of the barrier, 2 no barrier, 4 no DMA in the K loop
+// front of the barrier, 2 no barrier, 4 no DMA in the K loop, 8 no epilogue
 // Wave tile = NI x MI accumulator blocks of 32 x 32 (n x m): 2 x 4 at two waves per SIMD (256 registers), 4 x 4 at one
 // wave per SIMD (512 registers; a third fewer fragment bytes read from LDS per MFMA -- the kernel is power-bound, so
 // bytes moved per flop, not stalls, set its rate: profiles/r03_pl_ablation.txt).
@@ -117,10 +118,16 @@ struct PlCfg {
     static constexpr int NPA = 4 * (TM / 64), NPW = 4 * (TN / 64), NP = NPA + NPW;
     static constexpr int PPW = NP / NW;  // DMA pieces (1 KiB) per wave per step
     static constexpr int LDS = R * STAGE;
+    static constexpr bool EPI_T = NW == 8;  // fp32 epilogues go through a 4 KiB LDS block per wave (row-major global accesses)
     static_assert(NP % NW == 0, "pieces per wave");
     static_assert(PPW <= 8 && (D_ - 1) * PPW < 48, "vmcnt bookkeeping");
     static_assert(D_ >= 2 && D_ <= 3 && D_ < R_, "prefetch distance");
 };
+
+// value of lane (src_bytes / 4) (ds_bpermute: a lane crossbar, no memory)
+__device__ __forceinline__ float lane_bcast(float v, int src_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_bytes, __builtin_bit_cast(int, v)));
+}
 
 template <int EPI, bool SWAP, typename C>
 __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_kernel(PlParams p) {
@@ -138,6 +145,11 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     const int total = my_tiles * nk;
     long long t_start = 0;
     if (p.cycles && blockIdx.x == 0 && tid == 0) t_start = __builtin_amdgcn_s_memtime();
+    if (p.stagger > 0) {
+        // de-phase the persistent workgroups: started together they all reach their (HBM-heavy) epilogues together
+        const int n_sleep = (((int)blockIdx.x >> 3) & 7) * p.stagger;
+        for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(32);
+    }
 
     // ---- DMA pieces of this wave: piece q = wave + NW * j ------------------------------------------------------
     unsigned pv_off[PPW];   // byte offset inside the tile's operand panel (+ lane * 16)
@@ -318,7 +330,17 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             const float ascl_c = second ? p.a2_scale_const : p.a_scale_const;
             const int n_w0 = bn * TN + wn * (32 * NI);      // first column of this wave
             const int64_t m_w0 = bm * TM + wm * (32 * MI);  // first row of this wave
-            if constexpr (!SWAP) {
+            if constexpr (DBG & 8) {
+                // measurement build: no epilogue (the accumulators stay live through a store that never happens)
+                float t = 0.0f;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) t += acc[ni][mi][e];
+                if (t == 12345.678f) p.c[lane] = t;
+            } else if constexpr (!SWAP) {
                 // lane = row m_w0 + mi * 32 + r32; run c of block ni: columns n_w0 + ni * 32 + c * 16 + hi * 8 + 0..7
                 // per-row activation scales.  The load is unconditional and branch-free (a dummy address and an
                 // arithmetic select when there is no per-row array): a load on one side of a branch stays "pending" on
@@ -367,51 +389,117 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     int vc = p.N - n_w0;
                     if (vc > 32 * NI) vc = 32 * NI;
                     const auto c_rs = x3_rsrc(cb + m_w0 * ldc + ncol0, vr > 0 && vc > 0 ? ((vr - 1) * (int)ldc + vc) * 4 : 0);
+                    // no residual: a zero-sized descriptor, the loads below return 0 and touch no memory
                     const auto r_rs = x3_rsrc(p.residual ? p.residual + m_w0 * p.ldr + n_w0 : cb,
                                               p.residual && vr > 0 && vc > 0 ? ((vr - 1) * (int)p.ldr + vc) * 4 : 0);
+                    // Column constants: lane l holds the ones of the wave's column l (one load each per tile); a chunk's 8
+                    // columns are fetched from those lanes by ds_bpermute.  With the residual reloaded block by block (the
+                    // next chunk's rows are requested as soon as this chunk's are consumed) the epilogue waits for memory
+                    // ONCE per tile instead of once per 8-column chunk.
+                    const bool has_fold = p.fold_stats != nullptr;
+                    int ncl = n_w0 + lane;
+                    const bool foldl = has_fold && ncl < p.fold_cols;
+                    ncl = ncl < p.N ? ncl : p.N - 1;
+                    const float swl = p.w_scale[ncl];
+                    float fbl = p.bias ? p.bias[ncl] : 0.0f;
+                    if (foldl && p.fold_b) fbl += p.fold_b[ncl];
+                    const float fgl = (has_fold && !foldl && p.fold_u) ? p.fold_u[ncl] : 0.0f;
+                    if constexpr (C::EPI_T) {
+                        // Row-major global accesses through a wave-private 4 KiB LDS block.  In the accumulator layout a
+                        // lane owns 16-byte pieces of ITS row, so one store instruction touches 32 rows x 2 pieces: 32
+                        // partly written 128-byte lines per instruction, and the texture path -- not HBM -- bounded the
+                        // epilogue (15 us per 256 x 256 tile written, 30 us with the residual read the same way;
+                        // profiles/r03_epilogue_probe.txt).  A 32 x 32 block goes through LDS instead (XOR-swizzled 16-byte
+                        // chunks, no bank conflicts either way) and is stored / its residual loaded as 8 full lines per
+                        // instruction: lane -> row i * 8 + lane / 8, chunk lane % 8.
+                        unsigned char *scr = pl_smem + C::LDS + wave * 4096;
+                        const int rrow = hi * 4 + (r32 >> 3), rch = r32 & 7;
+                        const int rd0 = rrow * 128 + ((rch ^ rrow) * 16);
+                        const int wr0 = r32 * 128, wsw = r32 & 7;
+                        // global offsets: one lane part per leading dimension + a wave-uniform (scalar) block part
+                        const int vo_r = (rrow * (int)p.ldr + rch * 4) * 4, vo_c = (rrow * (int)ldc + rch * 4) * 4;
+                        auto so = [&](int blk, int i, int ld) {  // blk = ni * MI + mi
+                            return (((blk % MI) * 32 + i * 8) * ld + (blk / MI) * 32) * 4;
+                        };
+                        u32x4 res[4];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        if (ni * 32 >= vc) break;
-                        const bool fold = p.fold_stats && n_w0 + ni * 32 < p.fold_cols;  // wave-uniform
-                        const bool unfold = p.fold_stats && !fold && p.fold_u;             // centred operand, plain column
+                        for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(0, i, (int)p.ldr), 0);
 #pragma unroll
-                        for (int c = 0; c < 2; ++c) {
-                            // 8 columns at a time: their constants (24 registers) and the residual of the wave's MI row blocks
-                            // (8 MI registers, all loads in flight together) -- the accumulators leave ~100 registers
-                            __builtin_amdgcn_sched_barrier(0);
-                            f32x4 sw[2], fg[2], fbv[2];
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const int n = n_w0 + ni * 32 + c * 16 + hi * 8 + h * 4;
-                                sw[h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
-                                fg[h] = unfold ? *reinterpret_cast<const f32x4 *>(p.fold_u + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                                fbv[h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                                if (fold && p.fold_b) fbv[h] += *reinterpret_cast<const f32x4 *>(p.fold_b + n);
-                            }
-                            u32x4 res[MI][2];
-                            if (p.residual) {
-#pragma unroll
-                                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                                    for (int h = 0; h < 2; ++h)
-                                        res[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(
-                                            r_rs, (((mi * 32 + r32) * (int)p.ldr + ni * 32 + hi * 8) + c * 16 + h * 4) * 4, 0, 0);
-                            }
+                        for (int ni = 0; ni < NI; ++ni) {
+                            if (ni * 32 >= vc) break;
+                            const bool fold = has_fold && n_w0 + ni * 32 < p.fold_cols;  // wave-uniform
+                            const bool unfold = has_fold && !fold && p.fold_u;            // centred operand, plain column
 #pragma unroll
                             for (int mi = 0; mi < MI; ++mi) {
-                                const int c_off = ((mi * 32 + r32) * (int)ldc + ni * 32 + hi * 8) * 4;
+                                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) {
+                                for (int ch = 0; ch < 4; ++ch) {  // piece (c, h) = 4 columns
+                                    const int c = ch >> 1, h = ch & 1;
                                     f32x4 v;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e]);
+                                        const int src = (hi * 8 + ni * 32 + c * 16 + h * 4 + e) * 4;
+                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * lane_bcast(swl, src));
                                         if (fold) t = frs[mi] * t;
-                                        if (unfold) t += fmu[mi] * fg[h][e];
-                                        t += fbv[h][e];
+                                        if (unfold) t += fmu[mi] * lane_bcast(fgl, src);
+                                        v[e] = t + lane_bcast(fbl, src);
+                                    }
+                                    *reinterpret_cast<f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16)) = v;
+                                }
+                                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    f32x4 v = *reinterpret_cast<const f32x4 *>(scr + rd0 + i * 1024);
+                                    if (p.residual) v += __builtin_bit_cast(f32x4, res[i]);
+                                    if (ni * MI + mi + 1 < NI * MI)
+                                        res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs, vo_c,
+                                                                           so(ni * MI + mi, i, (int)ldc), 0);
+                                }
+                                __builtin_amdgcn_wave_barrier();
+                            }
+                        }
+                    } else {
+                        auto res_off = [&](int q, int mi, int h) {
+                            return (((mi * 32 + r32) * (int)p.ldr + (q >> 1) * 32 + hi * 8) + (q & 1) * 16 + h * 4) * 4;
+                        };
+                        u32x4 res[MI][2];
+    #pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+    #pragma unroll
+                            for (int h = 0; h < 2; ++h) res[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, res_off(0, mi, h), 0, 0);
+    #pragma unroll
+                        for (int q = 0; q < 2 * NI; ++q) {
+                            const int ni = q >> 1, c = q & 1;
+                            if (ni * 32 >= vc) break;
+                            const bool fold = has_fold && n_w0 + ni * 32 < p.fold_cols;  // wave-uniform
+                            const bool unfold = has_fold && !fold && p.fold_u;            // centred operand, plain column
+                            __builtin_amdgcn_sched_barrier(0);
+                            float sw[8], fg[8], fbv[8];
+    #pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const int src = (hi * 8 + ni * 32 + c * 16 + j) * 4;
+                                sw[j] = lane_bcast(swl, src);
+                                fbv[j] = lane_bcast(fbl, src);
+                                fg[j] = lane_bcast(fgl, src);
+                            }
+    #pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                const int c_off = ((mi * 32 + r32) * (int)ldc + ni * 32 + hi * 8) * 4;
+    #pragma unroll
+                                for (int h = 0; h < 2; ++h) {
+                                    f32x4 v;
+    #pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h * 4 + e]);
+                                        if (fold) t = frs[mi] * t;
+                                        if (unfold) t += fmu[mi] * fg[h * 4 + e];
+                                        t += fbv[h * 4 + e];
                                         if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[mi][h][e]);
                                         v[e] = t;
                                     }
+                                    if (q + 1 < 2 * NI)
+                                        res[mi][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, res_off(q + 1, mi, h), 0, 0);
                                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs,
                                                                            c_off + (c * 16 + h * 4) * 4, 0, 0);
                                 }
@@ -480,48 +568,64 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     float rsum[MI];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) rsum[mi] = 0.0f;
+                    // column constants by lane (see PL_F32): weight scale, bias, LayerNorm gamma / beta of column n_w0 + lane
+                    const int ncl = n_w0 + lane;
+                    const float swl = p.w_scale[ncl];
+                    const float fbl = p.bias ? p.bias[ncl] : 0.0f;
+                    const float gml = p.ln_gamma[ncl];
+                    const float btl = p.ln_beta ? p.ln_beta[ncl] : 0.0f;
+                    static_assert(C::EPI_T || EPI != PL_ROWLN, "row-major epilogue block");
+                    // residual in and fp32 out both go row-major through the wave's LDS block (see PL_F32): the residual is
+                    // loaded as full lines, re-read in the accumulator layout, and the sum (kept in the accumulators for
+                    // the statistics) takes the same way back out
+                    unsigned char *scr = pl_smem + C::LDS + 2 * C::WN * TM * 4 + wave * 4096;
+                    const int rrow = hi * 4 + (r32 >> 3), rch = r32 & 7;
+                    const int rd0 = rrow * 128 + ((rch ^ rrow) * 16);
+                    const int wr0 = r32 * 128, wsw = r32 & 7;
+                    const int vo_r = (rrow * (int)p.ldr + rch * 4) * 4, vo_c = (rrow * (int)p.ldc + rch * 4) * 4;
+                    auto so = [&](int blk, int i, int ld) {  // blk = ni * MI + mi; wave-uniform (scalar) part of the offset
+                        return (((blk % MI) * 32 + i * 8) * ld + (blk / MI) * 32) * 4;
+                    };
+                    u32x4 res[4];  // zero-sized descriptor without a residual: the loads return 0
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(0, i, (int)p.ldr), 0);
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
-                        f32x4 sw[2][2], bv[2][2];
-#pragma unroll
-                        for (int c = 0; c < 2; ++c)
-#pragma unroll
-                            for (int h = 0; h < 2; ++h) {
-                                const int n = n_w0 + ni * 32 + c * 16 + hi * 8 + h * 4;
-                                sw[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
-                                bv[c][h] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + n) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                            }
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
                             __builtin_amdgcn_sched_barrier(0);
-                            const int row = mi * 32 + r32;
-                            const int c_off = (row * (int)p.ldc + ni * 32 + hi * 8) * 4;
-                            u32x4 res[2][2];
-                            if (p.residual) {
-                                const int r_off = (row * (int)p.ldr + ni * 32 + hi * 8) * 4;
 #pragma unroll
-                                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                                    for (int h = 0; h < 2; ++h)
-                                        res[c][h] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, r_off + (c * 16 + h * 4) * 4, 0, 0);
+                            for (int i = 0; i < 4; ++i) {
+                                *reinterpret_cast<u32x4 *>(scr + rd0 + i * 1024) = res[i];
+                                if (ni * MI + mi + 1 < NI * MI)
+                                    res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
                             }
+                            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                            for (int c = 0; c < 2; ++c)
+                            for (int ch = 0; ch < 4; ++ch) {  // piece (c, h) = 4 columns
+                                const int c = ch >> 1, h = ch & 1;
+                                f32x4 *slot = reinterpret_cast<f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16));
+                                const f32x4 r = *slot;
+                                f32x4 v;
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    f32x4 v;
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[c][h][e]);
-                                        t += bv[c][h][e];
-                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[c][h][e]);
-                                        v[e] = t;
-                                        acc[ni][mi][c * 8 + h * 4 + e] = t;  // kept for the statistics
-                                    }
-                                    rsum[mi] += (v[0] + v[1]) + (v[2] + v[3]);
-                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs,
-                                                                           c_off + (c * 16 + h * 4) * 4, 0, 0);
+                                for (int e = 0; e < 4; ++e) {
+                                    const int src = (hi * 8 + ni * 32 + c * 16 + h * 4 + e) * 4;
+                                    float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * lane_bcast(swl, src));
+                                    t += lane_bcast(fbl, src);
+                                    t += r[e];
+                                    v[e] = t;
+                                    acc[ni][mi][c * 8 + h * 4 + e] = t;  // kept for the statistics
                                 }
+                                rsum[mi] += (v[0] + v[1]) + (v[2] + v[3]);
+                                *slot = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const u32x4 v = *reinterpret_cast<const u32x4 *>(scr + rd0 + i * 1024);
+                                __builtin_amdgcn_raw_buffer_store_b128(v, c_rs, vo_c, so(ni * MI + mi, i, (int)p.ldc), 0);
+                            }
+                            __builtin_amdgcn_wave_barrier();
                         }
                     }
                     // mean
@@ -568,13 +672,14 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         const int kb = (n_w0 >> 5) + ni;
 #pragma unroll
                         for (int c = 0; c < 2; ++c) {
-                            const int n = n_w0 + ni * 32 + c * 16 + hi * 8;
-                            const f32x4 g0 = *reinterpret_cast<const f32x4 *>(p.ln_gamma + n);
-                            const f32x4 g1 = *reinterpret_cast<const f32x4 *>(p.ln_gamma + n + 4);
-                            f32x4 b0 = f32x4{0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0;
-                            if (p.ln_beta) {
-                                b0 = *reinterpret_cast<const f32x4 *>(p.ln_beta + n);
-                                b1 = *reinterpret_cast<const f32x4 *>(p.ln_beta + n + 4);
+                            float g0[4], g1[4], b0[4], b1[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int src = (hi * 8 + ni * 32 + c * 16 + e) * 4;
+                                g0[e] = lane_bcast(gml, src);
+                                g1[e] = lane_bcast(gml, src + 16);
+                                b0[e] = lane_bcast(btl, src);
+                                b1[e] = lane_bcast(btl, src + 16);
                             }
 #pragma unroll
                             for (int mi = 0; mi < MI; ++mi) {

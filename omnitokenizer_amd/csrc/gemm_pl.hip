@@ -4,6 +4,7 @@
 namespace omnitok {
 
 extern int g_gemm_gn;
+int g_pl_stagger = 0;  // "pl_stagger": start delay step of persistent workgroups (~1 us units), 0 = off
 int g_pl_cfg = 0;  // "pl_cfg": 0 auto | 1 256x256 (8 waves, 1 workgroup per CU) | 2 128(n)x256(m) (4 waves, 2 per CU)
 
 // ---- weight rows -> scaled fp16 planes, rows permuted inside groups of 32 (pl_perm) ------------------------------
@@ -90,7 +91,8 @@ template <int EPI, bool SWAP, typename C>
 static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     int n_cu = 0;
     if (int rc = current_device_cus(&n_cu)) return rc;
-    constexpr int LDS = C::LDS + (EPI == PL_ROWLN ? 2 * C::WN * C::TM * 4 : 0);
+    constexpr int LDS = C::LDS + (EPI == PL_ROWLN ? 2 * C::WN * C::TM * 4 : 0) +
+                        ((EPI == PL_ROWLN || EPI == PL_F32) && C::EPI_T ? C::NW * 4096 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), LDS)) return rc;
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
@@ -101,6 +103,7 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     p.nbn = nbn;
     p.ntiles = (int)nt;
     p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
+    p.stagger = g_pl_stagger;
     int wg_per_cu = (160 * 1024) / LDS;
     const int by_waves = (C::NI * C::MI > 8) ? 1 : 8 / C::NW;
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
@@ -133,6 +136,7 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
             case 14: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 4, 4>>(p, stream);
             case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
             case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
+            case 18: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 8>>(p, stream);
 #endif
             default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
         }
