@@ -104,7 +104,7 @@ __host__ __device__ __forceinline__ int64_t pl_offset(int64_t row, int k, int pl
 #define PL_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
 // D = how many K steps the DMA cursor runs ahead (D < R).  DBG (measurement builds, wrong results): 1 no vmcnt wait in
-// front of the barrier, 2 no barrier, 4 no DMA in the K loop, 8 no epilogue
+// front of the barrier, 2 no barrier, 4 no DMA in the K loop, 8 no epilogue, 16 no fp32 stores, 32 no store drain at the tile end
 // Wave tile = NI x MI accumulator blocks of 32 x 32 (n x m): 2 x 4 at two waves per SIMD (256 registers), 4 x 4 at one
 // wave per SIMD (512 registers; a third fewer fragment bytes read from LDS per MFMA -- the kernel is power-bound, so
 // bytes moved per flop, not stalls, set its rate: profiles/r03_pl_ablation.txt).
@@ -123,6 +123,26 @@ struct PlCfg {
     static_assert(PPW <= 8 && (D_ - 1) * PPW < 48, "vmcnt bookkeeping");
     static_assert(D_ >= 2 && D_ <= 3 && D_ < R_, "prefetch distance");
 };
+
+// The fp32 epilogue's arithmetic, in two halves with contraction off: the row factors are applied in the accumulator
+// layout (lane = row), the column constants either there or after the transposition (lane = 4 fixed columns) -- every
+// tile configuration rounds the same way, results do not depend on the tiling.
+__device__ __forceinline__ float pl_row_part(float a, float sa, float frs, bool fold) {
+#pragma clang fp contract(off)
+    float t = a * sa;
+    if (fold) t = frs * t;
+    return t;
+}
+__device__ __forceinline__ float pl_col_part(float t, float sw, float fmu, float fg, bool unfold, float fb) {
+#pragma clang fp contract(off)
+    t = t * sw;
+    if (unfold) t = t + fmu * fg;
+    return t + fb;
+}
+__device__ __forceinline__ float pl_add(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
 
 // value of lane (src_bytes / 4) (ds_bpermute: a lane crossbar, no memory)
 __device__ __forceinline__ float lane_bcast(float v, int src_bytes) {
@@ -397,13 +417,6 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     // next chunk's rows are requested as soon as this chunk's are consumed) the epilogue waits for memory
                     // ONCE per tile instead of once per 8-column chunk.
                     const bool has_fold = p.fold_stats != nullptr;
-                    int ncl = n_w0 + lane;
-                    const bool foldl = has_fold && ncl < p.fold_cols;
-                    ncl = ncl < p.N ? ncl : p.N - 1;
-                    const float swl = p.w_scale[ncl];
-                    float fbl = p.bias ? p.bias[ncl] : 0.0f;
-                    if (foldl && p.fold_b) fbl += p.fold_b[ncl];
-                    const float fgl = (has_fold && !foldl && p.fold_u) ? p.fold_u[ncl] : 0.0f;
                     if constexpr (C::EPI_T) {
                         // Row-major global accesses through a wave-private 4 KiB LDS block.  In the accumulator layout a
                         // lane owns 16-byte pieces of ITS row, so one store instruction touches 32 rows x 2 pieces: 32
@@ -424,6 +437,22 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         u32x4 res[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(0, i, (int)p.ldr), 0);
+                        // column constants of the row-major side: the lane's 4 columns of each 32-column block, once per tile
+                        f32x4 swr[NI], fbr[NI], fgr[NI];
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) {
+                            const int nn = ni * 32 < vc ? n_w0 + ni * 32 + rch * 4 : 0;
+                            const bool fold = has_fold && n_w0 + ni * 32 < p.fold_cols;
+                            swr[ni] = *reinterpret_cast<const f32x4 *>(p.w_scale + nn);
+                            fbr[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nn) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                            if (fold && p.fold_b) {
+                                const f32x4 fb2 = *reinterpret_cast<const f32x4 *>(p.fold_b + nn);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) fbr[ni][e] = pl_add(fbr[ni][e], fb2[e]);
+                            }
+                            fgr[ni] = (has_fold && !fold && p.fold_u) ? *reinterpret_cast<const f32x4 *>(p.fold_u + nn)
+                                                                       : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                        }
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni) {
                             if (ni * 32 >= vc) break;
@@ -437,29 +466,44 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                     const int c = ch >> 1, h = ch & 1;
                                     f32x4 v;
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const int src = (hi * 8 + ni * 32 + c * 16 + h * 4 + e) * 4;
-                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * lane_bcast(swl, src));
-                                        if (fold) t = frs[mi] * t;
-                                        if (unfold) t += fmu[mi] * lane_bcast(fgl, src);
-                                        v[e] = t + lane_bcast(fbl, src);
-                                    }
+                                    for (int e = 0; e < 4; ++e) v[e] = pl_row_part(acc[ni][mi][c * 8 + h * 4 + e], sa[mi], frs[mi], fold);
                                     *reinterpret_cast<f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16)) = v;
                                 }
                                 __builtin_amdgcn_wave_barrier();
+                                float fm[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // row means of the row-major side (centred operand only)
+                                if (unfold) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) fm[i] = lane_bcast(fmu[mi], (i * 8 + rrow) * 4);
+                                }
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
-                                    f32x4 v = *reinterpret_cast<const f32x4 *>(scr + rd0 + i * 1024);
-                                    if (p.residual) v += __builtin_bit_cast(f32x4, res[i]);
+                                    const f32x4 x = *reinterpret_cast<const f32x4 *>(scr + rd0 + i * 1024);
+                                    f32x4 v;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float t = pl_col_part(x[e], swr[ni][e], fm[i], fgr[ni][e], unfold, fbr[ni][e]);
+                                        if (p.residual) t = pl_add(t, __builtin_bit_cast(float, (unsigned)res[i][e]));
+                                        v[e] = t;
+                                    }
                                     if (ni * MI + mi + 1 < NI * MI)
                                         res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
-                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs, vo_c,
-                                                                           so(ni * MI + mi, i, (int)ldc), 0);
+                                    if constexpr (DBG & 16) {
+                                        if (v[0] == 12345.678f) p.c[lane] = v[1];  // measurement build: no stores
+                                    } else
+                                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs, vo_c,
+                                                                               so(ni * MI + mi, i, (int)ldc), 0);
                                 }
                                 __builtin_amdgcn_wave_barrier();
                             }
                         }
                     } else {
+                        int ncl = n_w0 + lane;
+                        const bool foldl = has_fold && ncl < p.fold_cols;
+                        ncl = ncl < p.N ? ncl : p.N - 1;
+                        const float swl = p.w_scale[ncl];
+                        float fbl = p.bias ? p.bias[ncl] : 0.0f;
+                        if (foldl && p.fold_b) fbl += p.fold_b[ncl];
+                        const float fgl = (has_fold && !foldl && p.fold_u) ? p.fold_u[ncl] : 0.0f;
                         auto res_off = [&](int q, int mi, int h) {
                             return (((mi * 32 + r32) * (int)p.ldr + (q >> 1) * 32 + hi * 8) + (q & 1) * 16 + h * 4) * 4;
                         };
@@ -491,11 +535,9 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                     f32x4 v;
     #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h * 4 + e]);
-                                        if (fold) t = frs[mi] * t;
-                                        if (unfold) t += fmu[mi] * fg[h * 4 + e];
-                                        t += fbv[h * 4 + e];
-                                        if (p.residual) t += __builtin_bit_cast(float, (unsigned)res[mi][h][e]);
+                                        float t = pl_row_part(acc[ni][mi][c * 8 + h * 4 + e], sa[mi], frs[mi], fold);
+                                        t = pl_col_part(t, sw[h * 4 + e], fmu[mi], fg[h * 4 + e], unfold, fbv[h * 4 + e]);
+                                        if (p.residual) t = pl_add(t, __builtin_bit_cast(float, (unsigned)res[mi][h][e]));
                                         v[e] = t;
                                     }
                                     if (q + 1 < 2 * NI)
@@ -568,10 +610,8 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     float rsum[MI];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) rsum[mi] = 0.0f;
-                    // column constants by lane (see PL_F32): weight scale, bias, LayerNorm gamma / beta of column n_w0 + lane
+                    // LayerNorm gamma / beta by lane (column n_w0 + lane; a chunk's columns are fetched by ds_bpermute)
                     const int ncl = n_w0 + lane;
-                    const float swl = p.w_scale[ncl];
-                    const float fbl = p.bias ? p.bias[ncl] : 0.0f;
                     const float gml = p.ln_gamma[ncl];
                     const float btl = p.ln_beta ? p.ln_beta[ncl] : 0.0f;
                     static_assert(C::EPI_T || EPI != PL_ROWLN, "row-major epilogue block");
@@ -589,41 +629,52 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     u32x4 res[4];  // zero-sized descriptor without a residual: the loads return 0
 #pragma unroll
                     for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(0, i, (int)p.ldr), 0);
+                    f32x4 swr[NI], fbr[NI];  // weight scale / bias of the lane's 4 columns per block on the row-major side
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int nn = n_w0 + ni * 32 + rch * 4;
+                        swr[ni] = *reinterpret_cast<const f32x4 *>(p.w_scale + nn);
+                        fbr[ni] = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + nn) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
                             __builtin_amdgcn_sched_barrier(0);
+                            // (a) acc * row scale, accumulator layout -> LDS
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                *reinterpret_cast<u32x4 *>(scr + rd0 + i * 1024) = res[i];
-                                if (ni * MI + mi + 1 < NI * MI)
-                                    res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
-                            }
-                            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                            for (int ch = 0; ch < 4; ++ch) {  // piece (c, h) = 4 columns
+                            for (int ch = 0; ch < 4; ++ch) {
                                 const int c = ch >> 1, h = ch & 1;
-                                f32x4 *slot = reinterpret_cast<f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16));
-                                const f32x4 r = *slot;
                                 f32x4 v;
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const int src = (hi * 8 + ni * 32 + c * 16 + h * 4 + e) * 4;
-                                    float t = acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * lane_bcast(swl, src));
-                                    t += lane_bcast(fbl, src);
-                                    t += r[e];
-                                    v[e] = t;
-                                    acc[ni][mi][c * 8 + h * 4 + e] = t;  // kept for the statistics
-                                }
-                                rsum[mi] += (v[0] + v[1]) + (v[2] + v[3]);
-                                *slot = v;
+                                for (int e = 0; e < 4; ++e) v[e] = pl_row_part(acc[ni][mi][c * 8 + h * 4 + e], sa[mi], 1.0f, false);
+                                *reinterpret_cast<f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16)) = v;
                             }
                             __builtin_amdgcn_wave_barrier();
+                            // (b) row-major: column constants, residual, fp32 store; the sum goes back into the block
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                const u32x4 v = *reinterpret_cast<const u32x4 *>(scr + rd0 + i * 1024);
-                                __builtin_amdgcn_raw_buffer_store_b128(v, c_rs, vo_c, so(ni * MI + mi, i, (int)p.ldc), 0);
+                                const f32x4 x = *reinterpret_cast<const f32x4 *>(scr + rd0 + i * 1024);
+                                f32x4 v;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    v[e] = pl_add(pl_col_part(x[e], swr[ni][e], 0.0f, 0.0f, false, fbr[ni][e]),
+                                                  __builtin_bit_cast(float, (unsigned)res[i][e]));
+                                if (ni * MI + mi + 1 < NI * MI)
+                                    res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs, vo_c,
+                                                                       so(ni * MI + mi, i, (int)p.ldc), 0);
+                                *reinterpret_cast<f32x4 *>(scr + rd0 + i * 1024) = v;
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                            // (c) back in the accumulator layout for the statistics and the LayerNorm planes
+#pragma unroll
+                            for (int ch = 0; ch < 4; ++ch) {
+                                const int c = ch >> 1, h = ch & 1;
+                                const f32x4 v = *reinterpret_cast<const f32x4 *>(scr + wr0 + (((c * 4 + hi * 2 + h) ^ wsw) * 16));
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[ni][mi][c * 8 + h * 4 + e] = v[e];
+                                rsum[mi] += (v[0] + v[1]) + (v[2] + v[3]);
                             }
                             __builtin_amdgcn_wave_barrier();
                         }
@@ -885,7 +936,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
         // waitcnt pass still sees "pending" on some path (e.g. one issued inside a wave-uniform branch) would otherwise
         // make it drain vmcnt -- and with it the LDS-DMA ring -- in front of the fragment reads of EVERY K step.  The wait
         // costs the store latency once per tile; the kernel is power-bound, not stall-bound (profiles/r03_gemm_limiter_probe.txt).
-        PL_WAIT_VM(0);
+        if constexpr ((DBG & 32) == 0) PL_WAIT_VM(0);
         zero_acc();
     }
     if (p.cycles && blockIdx.x == 0 && tid == 0) {

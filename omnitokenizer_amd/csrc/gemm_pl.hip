@@ -137,6 +137,8 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
             case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
             case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
             case 18: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 8>>(p, stream);
+            case 19: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 16>>(p, stream);
+            case 20: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 32>>(p, stream);
 #endif
             default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
         }
