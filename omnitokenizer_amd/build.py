@@ -77,5 +77,42 @@ def build(verbose: bool = False) -> str:
     return LIB
 
 
+TORCH_LIB = os.path.join(LIBDIR, "libomnitok_torch.so")
+
+
+def build_torch_binding(verbose: bool = False) -> str:
+    """csrc/torch_binding.cpp -> lib/libomnitok_torch.so: the TORCH_LIBRARY registration of the engine (host C++ only,
+    g++ against this PyTorch's headers; the kernels stay in libomnitok.so, found through $ORIGIN)."""
+    import torch  # only this step needs it
+    from torch.utils import cpp_extension
+
+    src = os.path.join(CSRC, "torch_binding.cpp")
+    tdir = os.path.dirname(torch.__file__)
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+             f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]
+    h = hashlib.sha256()
+    for p in [src] + HEADERS:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update((" ".join(flags) + torch.__version__).encode())
+    stamp = os.path.join(OBJ, "torch_binding.sha")
+    os.makedirs(OBJ, exist_ok=True)
+    if os.path.exists(TORCH_LIB) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest() \
+            and os.path.getmtime(TORCH_LIB) >= os.path.getmtime(LIB):
+        return TORCH_LIB
+    inc = [os.path.join(os.path.dirname(HERE), "include"), "/opt/rocm/include"] + cpp_extension.include_paths()
+    cmd = ["g++", *flags, src, "-o", TORCH_LIB, *[f"-I{i}" for i in inc], f"-L{os.path.join(tdir, 'lib')}", "-ltorch",
+           "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip", f"-L{LIBDIR}", "-lomnitok", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"g++ failed for torch_binding.cpp:\n{r.stdout}\n{r.stderr}")
+    with open(stamp, "w") as f:
+        f.write(h.hexdigest())
+    if verbose:
+        print("built", TORCH_LIB)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     build(verbose=True)
+    build_torch_binding(verbose=True)
