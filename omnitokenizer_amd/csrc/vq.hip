@@ -20,6 +20,14 @@ namespace omnitok {
 constexpr int VQ_ROWS_PER_WAVE = 64;
 constexpr int VQ_ROWS_PER_BLOCK = 256;
 int g_vq_split = 0;  // 0 = automatic
+// "vq_variant" (VQ_CODEBOOK mode; A/B record in profiles/r03_vq_variants.txt):
+//   0  dot on the matrix pipe, (xx - dot) + ee on the VALU, codebook fragments from L2            (rounds 1-2)
+//   1  fifth MFMA step: the chain runs on -2z (exactly -dot), then k = 8: 1 * xx, k = 9: ee * 1 -- the accumulator
+//      ends in fl(fl(xx - dot) + ee), the reference's distance bit for bit, and the epilogue is the min tree alone
+//      (default: 0.268 vs 0.284 ms at C3)
+//   2  like 0 with the split's codebook fragments staged in LDS once per workgroup (1 KiB per 32 codes): 0.32 ms, the
+//      L2-resident fragments (one coalesced 16-byte load per lane and tile, prefetched two tiles ahead) were never the limit
+int g_vq_variant = 1;
 
 __global__ void vq_prepare_kernel(const float *__restrict__ E, int n_codes, float *__restrict__ packed,
                                   float *__restrict__ ee) {
@@ -60,8 +68,8 @@ __device__ __forceinline__ unsigned order_key(float d) {
 //                (distinct squared distances can round to the same root -> tie -> lowest index)
 enum { VQ_CODEBOOK = 0, VQ_COS = 1, VQ_EUCLID = 2 };
 
-template <bool SPLIT, int MODE = VQ_CODEBOOK>
-__global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restrict__ z,
+template <bool SPLIT, int MODE = VQ_CODEBOOK, int VAR = 0>
+__global__ __launch_bounds__(256, VAR == 2 ? 1 : 2) void vq_argmin_kernel(const float *__restrict__ z,
                                                            const float *__restrict__ packed,
                                                            const float *__restrict__ ee_g, int64_t n, int n_codes,
                                                            int64_t *__restrict__ ids) {
@@ -74,11 +82,19 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     const int t1 = SPLIT ? (t0 + tiles_per < ntiles_all ? t0 + tiles_per : ntiles_all) : ntiles_all;
     if (t0 >= t1) return;
     const int c0 = t0 * 32;  // first code of this split; ee_s holds ee[c0 .. t1*32)
+    constexpr bool FIFTH = VAR == 1 && MODE == VQ_CODEBOOK;
+    constexpr bool CB_LDS = VAR == 2;
+    // LDS: ee[c0 .. t1 * 32) and, for VAR 2, the codebook fragments of the same codes behind them
+    f32x4 *cb_s = reinterpret_cast<f32x4 *>(ee_s + (MODE != VQ_COS ? ((t1 - t0) * 32 + 3) / 4 * 4 : 0));
     if (MODE != VQ_COS) {
         for (int i = tid * 4; i < (t1 - t0) * 32; i += 256 * 4)
             *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + c0 + i);
-        __syncthreads();
     }
+    if (CB_LDS) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(packed) + (int64_t)t0 * 64;
+        for (int i = tid; i < (t1 - t0) * 64; i += 256) cb_s[i] = src[i];
+    }
+    if (MODE != VQ_COS || CB_LDS) __syncthreads();
 
     const int64_t row_base = (int64_t)blockIdx.x * VQ_ROWS_PER_BLOCK + wave * VQ_ROWS_PER_WAVE;
     float xb[2][4], xx[2], best[2];
@@ -98,14 +114,21 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         xx[g] = MODE == VQ_COS ? 0.0f : acc;
         zlo[g] = lo * 2.0f;  // exact
         zhi[g] = hi4 * 2.0f;
-        // k = 2s + hi for MFMA step s
-        xb[g][0] = hi ? zlo[g][1] : zlo[g][0];
-        xb[g][1] = hi ? zlo[g][3] : zlo[g][2];
-        xb[g][2] = hi ? zhi[g][1] : zhi[g][0];
-        xb[g][3] = hi ? zhi[g][3] : zhi[g][2];
+        // k = 2s + hi for MFMA step s.  FIFTH: the chain runs on -2z -- every step is fl(a * (-b) + c) = -fl(a * b - c),
+        // round-to-nearest is sign-symmetric, so the accumulator is exactly -dot
+        const float sg = FIFTH ? -1.0f : 1.0f;
+        xb[g][0] = sg * (hi ? zlo[g][1] : zlo[g][0]);
+        xb[g][1] = sg * (hi ? zlo[g][3] : zlo[g][2]);
+        xb[g][2] = sg * (hi ? zhi[g][1] : zhi[g][0]);
+        xb[g][3] = sg * (hi ? zhi[g][3] : zhi[g][2]);
         best[g] = INFINITY;
         btile[g] = t0;
     }
+    // FIFTH, MFMA step 4 (k = 8 + hi): k = 8 is 1 * xx -> fl(xx - dot), k = 9 is ee[code] * 1 -> fl(fl(xx - dot) + ee)
+    float xb5[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) xb5[g] = hi ? 1.0f : xx[g];
+    auto a5_of = [&](int t) { return hi ? ee_s[t * 32 + r32 - c0] : 1.0f; };
     auto dist = [&](float xxg, float dot, float ee) {
         if (MODE == VQ_EUCLID)  // + 0.0f: sqrt(-0.0) = -0.0 must not order below +0.0 in the split key
             return __fadd_rn(__fsqrt_rn(fmaxf(__fsub_rn(__fadd_rn(xxg, ee), dot), 0.0f)), 0.0f);
@@ -117,7 +140,8 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     // Software pipeline: the 8 MFMAs of tile t + 1 are issued with the epilogue of tile t (two accumulator sets),
     // so a wave's VALU work sits beside its own matrix instructions instead of after them.
     const f32x4 *pk = reinterpret_cast<const f32x4 *>(packed) + lane;
-    auto dots = [&](const f32x4 &a, f32x16 (&acc)[2]) {
+    auto ld_a = [&](int t) -> f32x4 { return CB_LDS ? cb_s[(t - t0) * 64 + lane] : pk[(int64_t)t * 64]; };
+    auto dots = [&](const f32x4 &a, float a5, f32x16 (&acc)[2]) {
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
 #pragma unroll
@@ -125,6 +149,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], xb[g][s], acc[g], 0, 0, 0);
+            if (FIFTH) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, xb5[g], acc[g], 0, 0, 0);
         }
     };
     // one quarter (q) of a tile's epilogue: the lane's 4 codes cbase + 8 q + (0..3) of both row groups
@@ -135,7 +160,9 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             float d0, d1, d2, d3;
-            if constexpr (MODE == VQ_EUCLID) {
+            if constexpr (FIFTH) {  // the accumulators ARE the distances
+                d0 = acc[g][q * 4 + 0]; d1 = acc[g][q * 4 + 1]; d2 = acc[g][q * 4 + 2]; d3 = acc[g][q * 4 + 3];
+            } else if constexpr (MODE == VQ_EUCLID) {
                 d0 = dist(xx[g], acc[g][q * 4 + 0], e4[0]); d1 = dist(xx[g], acc[g][q * 4 + 1], e4[1]);
                 d2 = dist(xx[g], acc[g][q * 4 + 2], e4[2]); d3 = dist(xx[g], acc[g][q * 4 + 3], e4[3]);
             } else {
@@ -169,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
     // MFMA step s of the NEXT tile (both row groups) followed by quarter s of the CURRENT tile's epilogue; the
     // scheduling barriers pin that issue order (the wave issues in order: eight MFMAs back to back would hold the
     // VALU work behind the matrix pipe, and the compiler otherwise groups them)
-    auto fused = [&](const f32x4 &a, f32x16 (&nxt)[2], int t, const f32x16 (&cur)[2]) {
+    auto fused = [&](const f32x4 &a, float a5, f32x16 (&nxt)[2], int t, const f32x16 (&cur)[2]) {
         float tmin[2] = {INFINITY, INFINITY};
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -179,6 +206,10 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         for (int sq = 0; sq < 4; ++sq) {
             nxt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sq], xb[0][sq], nxt[0], 0, 0, 0);
             nxt[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sq], xb[1][sq], nxt[1], 0, 0, 0);
+            if (FIFTH && sq == 3) {
+                nxt[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, xb5[0], nxt[0], 0, 0, 0);
+                nxt[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a5, xb5[1], nxt[1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             epi_quarter(t, sq, cur, tmin);
             __builtin_amdgcn_sched_barrier(0);
@@ -186,18 +217,19 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float *__restri
         commit(t, tmin);
     };
     f32x16 accA[2], accB[2];
-    f32x4 a_cur = pk[(int64_t)t0 * 64];
-    dots(a_cur, accA);
+    f32x4 a_cur = ld_a(t0);
+    dots(a_cur, FIFTH ? a5_of(t0) : 0.0f, accA);
     int t = t0;
     for (; t + 2 < t1; t += 2) {   // tiles t, t + 1 complete here; t + 2 is in flight at the end
-        const f32x4 a1 = pk[(int64_t)(t + 1) * 64];
-        const f32x4 a2 = pk[(int64_t)(t + 2) * 64];
-        fused(a1, accB, t, accA);
-        fused(a2, accA, t + 1, accB);
+        const f32x4 a1 = ld_a(t + 1);
+        const f32x4 a2 = ld_a(t + 2);
+        const float e1 = FIFTH ? a5_of(t + 1) : 0.0f, e2 = FIFTH ? a5_of(t + 2) : 0.0f;
+        fused(a1, e1, accB, t, accA);
+        fused(a2, e2, accA, t + 1, accB);
     }
     if (t + 1 < t1) {              // two tiles left: t (in flight) and t + 1
-        const f32x4 a1 = pk[(int64_t)(t + 1) * 64];
-        fused(a1, accB, t, accA);
+        const f32x4 a1 = ld_a(t + 1);
+        fused(a1, FIFTH ? a5_of(t + 1) : 0.0f, accB, t, accA);
         epilogue(t + 1, accB);
     } else {
         epilogue(t, accA);
@@ -543,9 +575,9 @@ extern "C" int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, 
     return OMNITOK_OK;
 }
 
-template <int MODE>
-static int launch_vq(const float *z, const float *packed, const float *ee, int64_t n, int n_codes, int64_t *ids,
-                     hipStream_t stream) {
+template <int MODE, int VAR>
+static int launch_vq_var(const float *z, const float *packed, const float *ee, int64_t n, int n_codes, int64_t *ids,
+                         hipStream_t stream) {
     constexpr bool cosine = MODE == VQ_COS;
     const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
     // code-range splits: aim at >= 2048 workgroups (whole rounds of the chip's 512 two-per-CU slots at the
@@ -555,24 +587,37 @@ static int launch_vq(const float *z, const float *packed, const float *ee, int64
     while (nsplit < 16 && blocks * nsplit < 2048 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
     if (g_vq_split >= 1) nsplit = g_vq_split;  // "vq_split" option: force (tests / A-B)
     if (nsplit > ntiles) nsplit = ntiles;
+    if (VAR == 2)  // the staged fragments (1 KiB per tile) + ee must fit the CU's LDS
+        while ((ntiles + nsplit - 1) / nsplit * (1024 + 128) + 64 > 160 * 1024) nsplit *= 2;
     const int tiles_per = (ntiles + nsplit - 1) / nsplit;
-    const int lds = cosine ? 0 : tiles_per * 32 * 4;
+    const int lds = (cosine ? 0 : (tiles_per * 32 + 3) / 4 * 4 * 4) + (VAR == 2 ? tiles_per * 1024 : 0);
     if (lds > 65536) {
-        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<false, MODE>), lds)) return rc;
-        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<true, MODE>), lds)) return rc;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<false, MODE, VAR>), lds)) return rc;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_argmin_kernel<true, MODE, VAR>), lds)) return rc;
     }
     const dim3 grid((unsigned)blocks, nsplit);
     if (nsplit == 1) {
-        hipLaunchKernelGGL((vq_argmin_kernel<false, MODE>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
+        hipLaunchKernelGGL((vq_argmin_kernel<false, MODE, VAR>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
         OT_LAUNCH_CHECK("vq_argmin");
         return OMNITOK_OK;
     }
     if (int rc = device_fill_u32(ids, 0xFFFFFFFFu, n * 2, stream)) return rc;
-    hipLaunchKernelGGL((vq_argmin_kernel<true, MODE>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
+    hipLaunchKernelGGL((vq_argmin_kernel<true, MODE, VAR>), grid, dim3(256), lds, stream, z, packed, ee, n, n_codes, ids);
     OT_LAUNCH_CHECK("vq_argmin");
     hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n);
     OT_LAUNCH_CHECK("vq_finalize");
     return OMNITOK_OK;
+}
+
+template <int MODE>
+static int launch_vq(const float *z, const float *packed, const float *ee, int64_t n, int n_codes, int64_t *ids,
+                     hipStream_t stream) {
+    if constexpr (MODE == VQ_CODEBOOK) {
+        if (g_vq_variant == 0) return launch_vq_var<MODE, 0>(z, packed, ee, n, n_codes, ids, stream);
+        if (g_vq_variant == 2) return launch_vq_var<MODE, 2>(z, packed, ee, n, n_codes, ids, stream);
+        return launch_vq_var<MODE, 1>(z, packed, ee, n, n_codes, ids, stream);
+    }
+    return launch_vq_var<MODE, 0>(z, packed, ee, n, n_codes, ids, stream);
 }
 
 extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,

@@ -419,29 +419,47 @@ def test_vae_sample_and_post_vq(ops):
                   want) < 1e-5
 
 
+VQ_VARIANTS = pytest.mark.parametrize("variant", [0, 1, 2], ids=["valu_epilogue", "fifth_mfma_step", "lds_codebook"])
+
+
+@VQ_VARIANTS
 @pytest.mark.parametrize("n_codes", [8192, 16384])
-def test_vq_argmin_bit_exact_vs_reference_kat(ops, n_codes):
+def test_vq_argmin_bit_exact_vs_reference_kat(ops, n_codes, variant):
     """ids bit-exact against the reference's own Codebook.forward outputs (golden KAT), including
-    duplicated code rows (ties -> lowest index) and scaled / exact-code inputs."""
+    duplicated code rows (ties -> lowest index) and scaled / exact-code inputs -- for every arm of the search
+    kernel (csrc/vq.hip "vq_variant": the default, the fifth-MFMA-step chain, the LDS-staged codebook)."""
+    from omnitokenizer_amd import _lib
     g = np.load(os.path.join(GOLDEN, f"vq_kat_{n_codes}.npz"))
     z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
-    ids = ops.vq_argmin(dev(z), dev(E)).cpu().numpy()
-    assert np.array_equal(ids, ids_ref), f"{(ids != ids_ref).sum()} of {ids.size} ids differ"
-    assert (ids[4096:4160] == 17).all() and (ids[4160:4200] == 3).all()
-    # ragged sizes (not a multiple of the 256-row workgroup) and the empty input
-    for n in (1, 31, 257, 1000):
-        assert np.array_equal(ops.vq_argmin(dev(z[:n]), dev(E)).cpu().numpy(), ids_ref[:n])
-    assert ops.vq_argmin(dev(z[:0]), dev(E)).numel() == 0
+    _lib.set_option("vq_variant", variant)
+    try:
+        ids = ops.vq_argmin(dev(z), dev(E)).cpu().numpy()
+        assert np.array_equal(ids, ids_ref), f"{(ids != ids_ref).sum()} of {ids.size} ids differ"
+        assert (ids[4096:4160] == 17).all() and (ids[4160:4200] == 3).all()
+        # ragged sizes (not a multiple of the 256-row workgroup) and the empty input
+        for n in (1, 31, 257, 1000):
+            assert np.array_equal(ops.vq_argmin(dev(z[:n]), dev(E)).cpu().numpy(), ids_ref[:n])
+        assert ops.vq_argmin(dev(z[:0]), dev(E)).numel() == 0
+        # un-normalised inputs (|xx - dot| far from the unit sphere's range) against the C oracle
+        rng = np.random.default_rng(11)
+        zz = (rng.standard_normal((3000, 8)) * 3.0).astype(np.float32)
+        EE = rng.standard_normal((2048, 8)).astype(np.float32)
+        got = ops.vq_argmin(dev(torch.from_numpy(zz)), dev(torch.from_numpy(EE))).cpu().numpy()
+        assert np.array_equal(got, c_oracle.vq_argmin(zz, EE))
+    finally:
+        _lib.set_option("vq_variant", 1)  # the default
 
 
+@VQ_VARIANTS
 @pytest.mark.parametrize("split", [1, 2, 4, 16, 3])
-def test_vq_argmin_code_range_splits(ops, split):
+def test_vq_argmin_code_range_splits(ops, split, variant):
     """The load-balancing code-range split (64-bit atomicMin merge of distance key | index) returns
     the same first-minimum ids whatever the number of splits, ties included."""
     from omnitokenizer_amd import _lib
     g = np.load(os.path.join(GOLDEN, "vq_kat_8192.npz"))
     z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
     _lib.set_option("vq_split", split)
+    _lib.set_option("vq_variant", variant)
     try:
         for n in (6144, 1000, 31):
             ids = ops.vq_argmin(dev(z[:n]), dev(E)).cpu().numpy()
@@ -453,6 +471,7 @@ def test_vq_argmin_code_range_splits(ops, split):
         assert ops.vq_argmin(dev(zz), dev(E2)).cpu().tolist() == [100, 100, 100]
     finally:
         _lib.set_option("vq_split", 0)
+        _lib.set_option("vq_variant", 1)
 
 
 @pytest.mark.parametrize("split", [0, 1, 4])
