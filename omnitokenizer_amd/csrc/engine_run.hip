@@ -242,7 +242,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
             if (qkv_pl) {
                 const int64_t Lp = (L + 255) / 256 * 256;
                 float *a_sc = e->Z.p;  // [L] row scales of the raw planes (Z is free inside a Transformer)
-                OT_RUN("row_stats", 3.0 * L * D * 4.0,
+                OT_RUN("stats_pack", 2.0 * L * D * 4.0,
                        omnitok_stats_pack(e->X.p, L, D, 1e-5f, 1, e->X2.p, Lp, a_sc, e->ST.p, bs, rpc, stream));
                 const H2W &wf = e->plw[ly.t.wqkv_fold];
                 omnitok_pl_gemm g{};
@@ -384,7 +384,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
             if (pl && g_qkv_pl && ly.w.wqkv_fold && e->plw.count(ly.w.wqkv_fold)) {
                 // q, k, v all from LN(x) (reference attention.py:262-272): the gain folded into every weight row
                 const int64_t Lp = (L + 255) / 256 * 256;
-                OT_RUN("row_stats", 3.0 * L * D * 4.0,
+                OT_RUN("stats_pack", 2.0 * L * D * 4.0,
                        omnitok_stats_pack(e->X.p, L, D, 1e-5f, 1, e->X2.p, Lp, e->Z.p, e->ST.p, nullptr, 0, stream));
                 const H2W &wf = e->plw[ly.w.wqkv_fold];
                 omnitok_pl_gemm g{};
