@@ -767,24 +767,50 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     const bool fold = p.fold_stats && n_w0 < p.fold_cols;
                     const bool unfold = p.fold_stats && !fold && p.fold_u;
                     const int nblk = p.qk_ntok >> 5;
+                    // RoPE factors of the tile's TM rows, staged ONCE per workgroup in the two ring stages that hold no
+                    // in-flight data at this point (the DMA cursor is D steps ahead: stages st .. st + D - 1 belong to the
+                    // next tile, d_stage and d_stage + 1 are free until its K loop resumes): [row][32 pairs] cos in one,
+                    // sin in the other, 16-byte chunks XOR-swizzled by the row so that the 32 lanes of a block read without
+                    // bank conflicts.  Before: every lane fetched its own 8-byte pieces from the [n_tokens][32] tables in
+                    // global memory, 128 uncoalesced loads per lane and tile, four waves the same rows -- 0.13 ms of the
+                    // 0.66 ms launch.  All waves take part (and meet at the two barriers) whether their columns exist or not.
+                    static_assert(EPI != PL_QKPACK || (C::STAGE >= TM * 128 && R - D >= 2 && TM % (8 * NW) == 0),
+                                  "RoPE rows of a tile fit the two free ring stages");
+                    const bool rope = p.cosT != nullptr;  // kernel-uniform
+                    unsigned char *rope_c = pl_smem + d_stage * C::STAGE;
+                    unsigned char *rope_s = pl_smem + (d_stage + 1 == R ? 0 : d_stage + 1) * C::STAGE;
+                    if (rope) {
+                        const int ln = hi * 32 + r32;
+#pragma unroll
+                        for (int i = 0; i < TM / NW / 8; ++i) {
+                            const int row0 = wave * (TM / NW) + i * 8;  // wave-uniform; this lane: row0 + ln / 8, position ln % 8
+                            const int64_t m = bm * TM + row0 + (ln >> 3);
+                            const int64_t mc = m < p.M ? m : p.M - 1;
+                            const int tokr = (int)(mc % p.qk_ntok);
+                            const int off = (tokr * 32 + (((ln & 7) ^ ((ln >> 3) & 7)) << 2)) * 4;
+                            __builtin_amdgcn_global_load_lds((pl_glob_t *)(reinterpret_cast<const unsigned char *>(p.cosT) + off),
+                                                             (pl_lds_t *)(rope_c + row0 * 128), 16, 0, 0);
+                            __builtin_amdgcn_global_load_lds((pl_glob_t *)(reinterpret_cast<const unsigned char *>(p.sinT) + off),
+                                                             (pl_lds_t *)(rope_s + row0 * 128), 16, 0, 0);
+                        }
+                        PL_WAIT_VM(0);
+                        lds_barrier();
+                    }
+                    // rows of this lane: token index inside its sequence and the 32-token block it belongs to
+                    int tok[MI];
+                    int64_t seqs[MI];
+                    float ss[MI];
                     if (n_w0 < p.N) {
-                        // rows of this lane: token index inside its sequence and the 32-token block it belongs to
-                        int tok[MI];
-                        unsigned char *blkp[MI];
-                        bool live[MI];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
                             const int64_t m = m_w0 + mi * 32 + r32;
                             const int64_t mc = m < p.M ? m : p.M - 1;
-                            const int64_t seq = mc / p.qk_ntok;
-                            tok[mi] = (int)(mc - seq * p.qk_ntok);
-                            live[mi] = m < p.M;
-                            blkp[mi] = outp + ((seq * p.qk_heads + head) * nblk + (tok[mi] >> 5)) * 8192 + hi * 512 + (tok[mi] & 31) * 16;
+                            seqs[mi] = mc / p.qk_ntok;
+                            tok[mi] = (int)(mc - seqs[mi] * p.qk_ntok);
                         }
                         // phase A: projected values (scales, folded LayerNorm / mean add-back, RoPE) written back INTO the
                         // accumulators, sums of squares per row.  Column constants are loaded once per 8 columns and reused
                         // for the MI row blocks.
-                        float ss[MI];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) ss[mi] = 0.0f;
 #pragma unroll
@@ -792,6 +818,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
+                                const int rpos = (wm * (32 * MI) + r32) * 128 + (((ni * 4 + c * 2 + hi) ^ (r32 & 7)) << 4);
                                 f32x4 sw[2], fx[2];
 #pragma unroll
                                 for (int h = 0; h < 2; ++h) {
@@ -810,10 +837,9 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                                         for (int e = 0; e < 4; ++e)
                                             v[e] = ra * (acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e])) + rb * fx[h][e];
-                                        if (p.cosT) {  // (a + ib)(c + is) on the pairs (d, d + 1), reference attention.py:65-69
-                                            const int pr = (ni * 32 + c * 16 + hi * 8 + h * 4) >> 1;
-                                            const float2 cs = *reinterpret_cast<const float2 *>(p.cosT + tok[mi] * 32 + pr);
-                                            const float2 sn = *reinterpret_cast<const float2 *>(p.sinT + tok[mi] * 32 + pr);
+                                        if (rope) {  // (a + ib)(c + is) on the pairs (d, d + 1), reference attention.py:65-69
+                                            const float2 cs = *reinterpret_cast<const float2 *>(rope_c + rpos + mi * 4096 + h * 8);
+                                            const float2 sn = *reinterpret_cast<const float2 *>(rope_s + rpos + mi * 4096 + h * 8);
                                             const float a0 = v[0], b0 = v[1], a1 = v[2], b1 = v[3];
                                             v[0] = a0 * cs.x - b0 * sn.x; v[1] = a0 * sn.x + b0 * cs.x;
                                             v[2] = a1 * cs.y - b1 * sn.y; v[3] = a1 * sn.y + b1 * cs.y;
@@ -824,6 +850,16 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                     }
                                 }
                             }
+                    }
+                    if (rope) lds_barrier();  // every wave is done with the staged rows before the ring takes the stages back
+                    if (n_w0 < p.N) {
+                        unsigned char *blkp[MI];
+                        bool live[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            live[mi] = m_w0 + mi * 32 + r32 < p.M;
+                            blkp[mi] = outp + ((seqs[mi] * p.qk_heads + head) * nblk + (tok[mi] >> 5)) * 8192 + hi * 512 + (tok[mi] & 31) * 16;
+                        }
                         float inv[MI];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
