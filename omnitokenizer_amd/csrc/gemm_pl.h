@@ -776,6 +776,16 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     // 0.66 ms launch.  All waves take part (and meet at the two barriers) whether their columns exist or not.
                     static_assert(EPI != PL_QKPACK || (C::STAGE >= TM * 128 && R - D >= 2 && TM % (8 * NW) == 0),
                                   "RoPE rows of a tile fit the two free ring stages");
+                    // per-column constants by lane (column n_w0 + lane of the wave's 64), requested before the RoPE rows so that
+                    // one memory round trip per tile covers both; chunks fetch theirs with ds_bpermute in one batch
+                    float swl, fxl = 0.0f, svl;
+                    {
+                        const int ln = hi * 32 + r32, ncl = n_w0 < p.N ? n_w0 + ln : 0;
+                        swl = p.w_scale[ncl];
+                        if (fold && p.fold_b) fxl = p.fold_b[ncl];
+                        if (unfold) fxl = p.fold_u[ncl];
+                        svl = svec[ln];
+                    }
                     const bool rope = p.cosT != nullptr;  // kernel-uniform
                     unsigned char *rope_c = pl_smem + d_stage * C::STAGE;
                     unsigned char *rope_s = pl_smem + (d_stage + 1 == R ? 0 : d_stage + 1) * C::STAGE;
@@ -819,15 +829,16 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 const int rpos = (wm * (32 * MI) + r32) * 128 + (((ni * 4 + c * 2 + hi) ^ (r32 & 7)) << 4);
-                                f32x4 sw[2], fx[2];
+                                // the chunk's 8 columns of the per-column constants, from the lanes that hold them
+                                float sw[2][4], fx[2][4];
 #pragma unroll
-                                for (int h = 0; h < 2; ++h) {
-                                    const int dl = ni * 32 + c * 16 + hi * 8 + h * 4;
-                                    sw[h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n_w0 + dl);
-                                    fx[h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                                    if (fold && p.fold_b) fx[h] = *reinterpret_cast<const f32x4 *>(p.fold_b + n_w0 + dl);
-                                    if (unfold) fx[h] = *reinterpret_cast<const f32x4 *>(p.fold_u + n_w0 + dl);
-                                }
+                                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int src = (ni * 32 + c * 16 + hi * 8 + h * 4 + e) * 4;
+                                        sw[h][e] = lane_bcast(swl, src);
+                                        fx[h][e] = lane_bcast(fxl, src);
+                                    }
 #pragma unroll
                                 for (int mi = 0; mi < MI; ++mi) {
                                     const float ra = fold ? frs[mi] : 1.0f, rb = fold ? 1.0f : (unfold ? fmu[mi] : 0.0f);
@@ -872,9 +883,13 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                const int dl = ni * 32 + c * 16 + hi * 8;
-                                const f32x4 s0 = *reinterpret_cast<const f32x4 *>(svec + dl);
-                                const f32x4 s1 = *reinterpret_cast<const f32x4 *>(svec + dl + 4);
+                                float s0[4], s1[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const int src = (ni * 32 + c * 16 + hi * 8 + e) * 4;
+                                    s0[e] = lane_bcast(svl, src);
+                                    s1[e] = lane_bcast(svl, src + 16);
+                                }
 #pragma unroll
                                 for (int mi = 0; mi < MI; ++mi) {
                                     f32x4 va, vb;
