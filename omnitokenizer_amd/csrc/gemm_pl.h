@@ -272,6 +272,30 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     rdW(Pl, 0, 1);
 
     for (int ti = 0; ti < my_tiles; ++ti) {
+        // PL_GEGLU: the tile's per-row operand scales and the wave's 64 weight-row scales (one per lane) are requested HERE,
+        // a whole K loop before the epilogue needs them (5 registers): the epilogue then starts without a memory round trip
+        float pf_sa[MI], pf_sw = 0.0f;
+        if constexpr (EPI == PL_GEGLU && NI == 2) {
+            const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
+            int64_t bm;
+            int bn;
+            tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            int r32 = r32_, hi = hi_;
+            asm volatile("" : "+v"(r32), "+v"(hi));
+            const bool second = p.a_split_n > 0 && bn * TN >= p.a_split_n;
+            const float *ascl = second ? p.a2_scale : p.a_scale;
+            const float *abase = ascl ? ascl : p.w_scale;
+            int64_t mmax = ascl ? p.M - 1 : 0;
+            asm volatile("" : "+v"(abase), "+v"(mmax));
+            const int64_t m_w0 = bm * TM + wm * (32 * MI);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int64_t m = m_w0 + mi * 32 + r32;
+                pf_sa[mi] = abase[m < mmax ? m : mmax];
+            }
+            const int n_w0 = bn * TN + wn * (32 * NI);
+            pf_sw = p.w_scale[n_w0 < p.N ? n_w0 + hi * 32 + r32 : 0];
+        }
         for (int k = 0; k < nk; ++k) {
             const int s = ti * nk + k;
             const bool more = (DBG & 4) ? false : s + D < total;  // wave-uniform
@@ -374,7 +398,11 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
                         const int64_t m = m_w0 + mi * 32 + r32;
-                        const float av = abase[m < mmax ? m : mmax];
+                        float av;
+                        if constexpr (EPI == PL_GEGLU && NI == 2)
+                            av = pf_sa[mi];  // requested before the K loop
+                        else
+                            av = abase[m < mmax ? m : mmax];
                         sa[mi] = ascl_c * (av * has + (1.0f - has));  // exact: av (has = 1) or 1 (has = 0, av finite)
                     }
                 }
@@ -562,8 +590,17 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                             for (int h = 0; h < 2; ++h) {
                                 const int n = n_q0 + c * 16 + hi * 8 + h * 4;
-                                sv[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
-                                sg[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n + 32);
+                                if constexpr (NI == 2) {  // lane l holds the scale of column n_w0 + l (value 0..31, gate 32..63)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int src = (c * 16 + hi * 8 + h * 4 + e) * 4;
+                                        sv[c][h][e] = lane_bcast(pf_sw, src);
+                                        sg[c][h][e] = lane_bcast(pf_sw, src + 128);
+                                    }
+                                } else {
+                                    sv[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n);
+                                    sg[c][h] = *reinterpret_cast<const f32x4 *>(p.w_scale + n + 32);
+                                }
                             }
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) {
