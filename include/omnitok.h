@@ -50,10 +50,15 @@ const char *omnitok_version(void);
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
  *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
  *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
+ *   "qkv_pl"     1 (default, process-wide) with gemm_pl: the q|k|v projection reads centred planes from omnitok_stats_pack,
+ *                has the LayerNorm folded into its weight and writes the attention kernel's packed Q / K / V itself | 0 the
+ *                round-2 form (row_stats -> gemm_h2 with in-loop LayerNorm -> attn_pack)
  * Tuning knobs of the stand-alone kernel entry points for A/B measurements (process-wide; results do not depend on them --
  * tests check bitwise independence of the tile shape): "gemm_variant", "gemm_small", "gemm_gn", "gemm_lds_pad_kb",
  * "x3_tile", "h2_tile" (0 auto | 1 256x256 | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "pl_cfg" (0 auto | 1 256x256 |
- * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "peg_variant", "lm_wide_u"; "x3_dbg" / "h2_dbg" select
+ * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
+ * staged in LDS; all bit-exact, profiles/r03_vq_variants.txt), "pl_stagger" (start delay step of persistent GEMM workgroups in
+ * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant", "lm_wide_u"; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* ------------------------------------------------------------------------------------------
