@@ -212,6 +212,8 @@ def main():
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
             vq_bytes = Ltok * 40 + cfg.n_codes * 32
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 2)
+            # the search runs on the fp32-input MFMA: its mode roof IS the fp32 peak (fp16-split kernels carry no such field)
+            kernels["vq_argmin"]["frac_f32_peak"] = kernels["vq_argmin"].get("frac_of_mode_roof")
 
         if is_image:
             wl_name = "C2" if (B, a.resolution) == (64, 256) else "images"
