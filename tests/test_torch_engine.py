@@ -33,6 +33,17 @@ def test_engine_class_and_shapes_need_no_gpu(te):
         e.encode_shape(17, 250, 256)  # not a multiple of the patch size: the path rejects it
 
 
+def test_engine_pickles_as_its_configuration(te):
+    import io
+    e, (ints, enc, dec) = _cpu_engine(te)
+    buf = io.BytesIO()
+    torch.save(e, buf)
+    buf.seek(0)
+    e2 = torch.load(buf, weights_only=False)
+    assert dict(e2.config()) == ints and e2.blocks() == [enc, dec]
+    assert e2.encode_shape(17, 256, 256) == [5, 32, 32] and len(e2.missing()) == len(e.missing())
+
+
 def test_operators_fail_loudly_off_the_gpu(te):
     e, _ = _cpu_engine(te)
     with pytest.raises(RuntimeError, match="must be on the GPU"):
