@@ -55,7 +55,11 @@ def main():
                     help="omnitok_set_option switch for A/B measurements (e.g. attn_vpack=0); recorded in config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the hwmon clock / power sampling (profiled runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--native-gather", action="store_true",
+                    help="N > 1: issue the id all-gather from C++ (ncclAllGather through libomnitok.so, include/omnitok_comm.h) "
+                         "instead of torch.distributed; without the flag the native path is still probed after the timed region")
+    ap.add_argument("--no-also", action="store_true", help="skip the C2 / C5 / strict-fp32 / heavy-parity extras of the default C3 line")
     a = ap.parse_args()
 
     from omnitokenizer_amd import launch
@@ -67,6 +71,12 @@ def main():
     rc = launch.maybe_respawn(os.path.abspath(__file__), sys.argv[1:], a.gpus)
     if rc is not None:
         sys.exit(rc)
+    with launch.rank_errors():   # a failing rank names itself and its reason before the launcher tears the job down
+        run(a)
+
+
+def run(a):
+    from omnitokenizer_amd import launch
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU path)"
     info = launch.init_ranks(a.gpus, backend="nccl")   # RCCL on ROCm
     world, rank, local_rank = info.world, info.rank, info.local_rank
@@ -99,8 +109,12 @@ def main():
     n_total = B * world
 
     res = launch.timed_sharded_steps(info, lambda xs: model.encode(xs, is_image),
-                                     lambda i: model.decode(i, is_image), x, a.steps, a.warmup)
+                                     lambda i: model.decode(i, is_image), x, a.steps, a.warmup,
+                                     native_gather=a.native_gather)
     dt, ids = res.seconds, res.ids_local
+    # N > 1: the C++ ncclAllGather path (omnitok_comm.h) checked against the gathered ids of the timed region and timed,
+    # outside the timed region and never fatal -- so that the first multi-GPU run exercises it whichever path was timed
+    native_probe = launch.probe_native_gather(info, ids, res) if world > 1 else None
     tokens_per_clip = ids.numel() // B
     value = n_total * tokens_per_clip * a.steps / dt
 
@@ -238,6 +252,8 @@ def main():
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
                        "parallelism": f"clip-sharded x{world}", **({"options": a.option} if a.option else {})},
             "rccl_world_size": res.world_seen, "ids_crc32": res.ids_crc, "allgather_ms": res.allgather_ms,
+            "gather_impl": res.gather_impl, "native_gather_probe": native_probe,
+            "per_rank_ms": {"min": min(res.per_rank_ms), "max": max(res.per_rank_ms), "all": res.per_rank_ms},
             "roofline": roofline, "launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
             "kernels": kernels,
             "workspace_gb": round(model.workspace_bytes() / 2**30, 2),
@@ -344,8 +360,92 @@ def main():
                              "pixel_max_abs_err": float((g_rec - rec_ref).abs().max()),
                              "psnr_vs_ref_db": round(orc.psnr(g_rec, rec_ref), 2),
                              "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2)}
+        # ---- driver-observed extras of the default C3 line ------------------------------
+        if world == 1 and wl_name == "C3" and B == 32 and a.gemm_mode == 2 and not a.option and not a.no_also:
+            out["also"] = also_extras(model, x, sd, a)
         print(json.dumps(out), flush=True)
     launch.finish(info)
+
+
+def _time_steps(model, x, is_image, steps, warmup=1):
+    for _ in range(warmup):
+        ids = model.encode(x, is_image)
+        model.decode(ids, is_image)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(steps):
+        ids = model.encode(x, is_image)
+        model.decode(ids, is_image)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps * 1e3, ids
+
+
+def also_extras(model, x, sd, a):
+    """Short extra measurements put on the default line so that they are driver-observed, each a few steps and none inside
+    the timed region: the other two single-GPU BASELINE configurations (C2 images, C5-shape long clip), the same C3 step
+    in strict fp32 arithmetic (fp32-input MFMA GEMMs and attention: `gemm_mode` 0 / `attn_mode` 0), and the default
+    arithmetic against a heavy-statistics reference fixture (tests/golden/heavy_*: outputs of the reference itself on
+    trained-like weights, with the reference's own fp32-vs-fp64 noise as the yardstick)."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, make_args, synth
+    from omnitokenizer_amd.config import OmniTokConfig
+    also = {}
+    try:
+        # C3 in strict fp32: per-engine options, restored afterwards
+        model.set_option("gemm_mode", 0)
+        model.set_option("attn_mode", 0)
+        ms, _ = _time_steps(model, x, False, steps=2, warmup=1)
+        model.set_option("gemm_mode", -1)
+        model.set_option("attn_mode", -1)
+        also["strict_fp32"] = {"gemm_mode": 0, "attn_mode": 0, "ms_per_step": round(ms, 3),
+                               "patches_s": round(x.shape[0] * 5120 / ms * 1e3, 1),
+                               "note": "same C3 batch, fp32-input MFMA GEMMs and attention (the reference's arithmetic class); 2 steps"}
+    except Exception as e:  # noqa: BLE001
+        also["strict_fp32"] = {"error": repr(e)}
+    try:
+        xi = synth.synth_image(64, 256, seed=1234).cuda().contiguous()
+        ms, ids = _time_steps(model, xi, True, steps=3)
+        also["c2"] = {"workload": "C2: B=64 256x256 images", "ms_per_step": round(ms, 3),
+                      "patches_s": round(ids.numel() / ms * 1e3, 1), "steps": 3}
+        del xi
+    except Exception as e:  # noqa: BLE001
+        also["c2"] = {"error": repr(e)}
+    try:
+        args5 = make_args(2, resolution=512, n_codes=16384, sequence_length=65)
+        cfg5 = OmniTokConfig.from_args(args5)
+        m5 = OmniTokenizer_VQGAN(args5)
+        m5.load_state_dict(synth.synth_state_dict(cfg5, seed=0), strict=True)
+        m5 = m5.cuda().eval()
+        x5 = synth.synth_video(1, 65, 512, seed=1234).cuda().contiguous()
+        ms, ids = _time_steps(m5, x5, False, steps=3)
+        also["c5"] = {"workload": "C5 shape: 1 clip 65x512x512, n_codes 16384", "ms_per_step": round(ms, 3),
+                      "patches_s": round(ids.numel() / ms * 1e3, 1), "steps": 3}
+        del m5, x5
+    except Exception as e:  # noqa: BLE001
+        also["c5"] = {"error": repr(e)}
+    try:
+        from tests.helpers import GoldenCase
+        c = GoldenCase("heavy_s2_sdpa_r256_vid17")
+        mh = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
+        mh.load_state_dict(c.sd, strict=True)
+        mh = mh.cuda().eval()
+        r = {}
+        for tag, gm, am in (("default", -1, -1), ("strict_fp32", 0, 0)):
+            mh.set_option("gemm_mode", gm)
+            mh.set_option("attn_mode", am)
+            ids, z = mh.encode(c.x.cuda(), False, return_latents=True)
+            rec = mh.decode(c.ids.cuda(), False)
+            zerr = float((z.cpu() - c.z).abs().max())
+            perr = float((c.strided(rec.cpu()) - c.recon).abs().max())
+            r[tag] = {"id_flips_vs_reference": int((ids.cpu() != c.ids).sum()), "ids": int(c.ids.numel()),
+                      "z_max_abs_err": zerr, "z_err_over_reference_fp32_noise": round(zerr / c.fp32_noise_z, 2),
+                      "pixel_max_abs_err": perr, "pixel_err_over_reference_fp32_noise": round(perr / c.fp32_noise_pix, 2)}
+        r["fixture"] = ("tests/golden/heavy_s2_sdpa_r256_vid17.npz: the reference's own outputs on heavy-tailed weights, one "
+                        f"17x256x256 clip; its fp32-vs-fp64 noise: z {c.fp32_noise_z:.2e}, pixels {c.fp32_noise_pix:.2e} "
+                        f"(|pixel| up to {c.recon_absmax:.0f})")
+        also["parity_heavy"] = r
+    except Exception as e:  # noqa: BLE001
+        also["parity_heavy"] = {"error": repr(e)}
+    return also
 
 
 if __name__ == "__main__":

@@ -144,6 +144,15 @@ _PROTOS = {
     "omnitok_attn_window_planes": [P, I64, P, P, I64, P, c_float, c_int, c_int, c_int, c_int, P],
     "omnitok_attn_temporal_planes": [P, I64, P, P, I64, P, I64, P, P, c_float, P, c_int, I64, I64, c_int, c_int, P, P,
                                      c_float, c_int, P, P],
+    # include/omnitok_comm.h
+    "omnitok_comm_available": [c_char_p, c_int],
+    "omnitok_comm_unique_id": [P],
+    "omnitok_comm_create": [P, c_int, c_int, POINTER(P)],
+    "omnitok_comm_destroy": [P],
+    "omnitok_comm_world": [P],
+    "omnitok_comm_rank": [P],
+    "omnitok_comm_allgather_i32": [P, P, P, I64, P],
+    "omnitok_comm_allgather_ids": [P, P, P, I64, P],
     "omnitok_set_option": [c_char_p, c_int],
     "omnitok_debug_set_gemm_trace": [P],
     "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
@@ -153,7 +162,7 @@ _PROTOS = {
 _RESTYPES = {"omnitok_last_error": c_char_p, "omnitok_version": c_char_p,
              "omnitok_engine_destroy": None, "omnitok_engine_workspace_bytes": c_int64,
              "omnitok_engine_workspace_need_encode": c_int64, "omnitok_engine_workspace_need_decode": c_int64,
-             "omnitok_lm_destroy": None, "omnitok_lm_cache_bytes": c_int64,
+             "omnitok_lm_destroy": None, "omnitok_comm_destroy": None, "omnitok_lm_cache_bytes": c_int64,
              "omnitok_pl_planes_bytes": c_int64, "omnitok_pl_unscale": c_float}
 
 EXPORTED_SYMBOLS = tuple(_PROTOS)

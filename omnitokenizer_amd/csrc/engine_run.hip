@@ -104,7 +104,13 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
     // Plane data flow (gemm_pl.h): attention output -> planes (AO) -> to_out / proj with the residual add and the
     // FeedForward's LayerNorm in its epilogue (x in place, LN(x) planes -> Y) -> FF-in with the GEGLU hidden as planes
     // (HD) -> FF-out (+ residual).  Needs full-row tiles for the LayerNorm epilogue (dim 512 = the reference's only width).
-    const bool pl = gemm_pl_of(e) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    bool pl_ok = gemm_pl_of(e) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    // the plane producers scale by constants derived from the static operand bounds: a degenerate FeedForward LayerNorm
+    // (gamma == beta == 0 gives bound 0) or a non-finite bound sends the whole Transformer down the gemm_h2 / x3 branch,
+    // which handles missing ranges by itself
+    for (const Layer &ly : tw.layers)
+        if (!(ly.ff.ln_bound > 0.0f && ly.ff.ln_bound < 1e30f && ly.ff.h_bound > 0.0f && ly.ff.h_bound < 1e30f)) pl_ok = false;
+    const bool pl = pl_ok;
     bool ln_planes_ready = false;  // Y holds the planes of the FeedForward's LayerNorm(x) for the current x
     // producers that cannot write planes themselves: fp32 rows -> planes with one power-of-two scale per row
     auto pack_rows = [&](const float *src, void *planes, float *scales) -> int {

@@ -16,6 +16,8 @@
 // PyTorch-ROCm keeps the "cuda" device type: guards and streams come from the masquerading headers
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPCachingAllocatorMasqueradingAsCUDA.h>
+#include <hip/hip_runtime_api.h>
 #include <torch/custom_class.h>
 #include <torch/library.h>
 
@@ -37,7 +39,9 @@ struct Engine : torch::CustomClassHolder {
     omnitok_config cfg{};
     omnitok_engine *e = nullptr;
     bool finalized = false;
+    int device = -1;       // the GPU the engine's weight copies live on (set by the first set_weight / finalize)
     at::Tensor workspace;  // the engine's activations, a block of PyTorch's caching allocator
+    void *workspace_stream = nullptr;  // the stream the block was allocated on
 
     Engine(c10::Dict<std::string, int64_t> d, std::string enc, std::string dec)
         : cfg_dict(std::move(d)), enc_block(std::move(enc)), dec_block(std::move(dec)) {
@@ -82,6 +86,9 @@ struct Engine : torch::CustomClassHolder {
         TORCH_CHECK(t.is_cuda(), "omnitok.Engine.set_weight(", name, "): the tensor must live on the GPU");
         TORCH_CHECK(t.scalar_type() == at::kFloat || t.scalar_type() == at::kLong, "omnitok.Engine.set_weight(", name,
                     "): float32 (or int64 index tables) only -- the path computes in fp32 like the reference");
+        TORCH_CHECK(device < 0 || device == t.get_device(), "omnitok.Engine.set_weight(", name, "): tensor on GPU ",
+                    t.get_device(), ", the engine lives on GPU ", device);
+        device = t.get_device();
         c10::hip::HIPGuardMasqueradingAsCUDA guard(t.device());
         const at::Tensor c = t.contiguous();
         std::vector<int64_t> shape(c.sizes().begin(), c.sizes().end());
@@ -93,6 +100,9 @@ struct Engine : torch::CustomClassHolder {
         return rc;
     }
     void finalize(const at::Tensor &any_gpu_tensor) {
+        TORCH_CHECK(any_gpu_tensor.is_cuda() && (device < 0 || device == any_gpu_tensor.get_device()),
+                    "omnitok.Engine.finalize: pass a tensor of the engine's GPU");
+        device = any_gpu_tensor.get_device();
         c10::hip::HIPGuardMasqueradingAsCUDA guard(any_gpu_tensor.device());
         check(omnitok_engine_finalize(e, stream_of(any_gpu_tensor)), "engine_finalize");
         c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(any_gpu_tensor.get_device()).synchronize();  // the sources may be freed by the caller now
@@ -124,11 +134,32 @@ struct Engine : torch::CustomClassHolder {
         check(omnitok_engine_decode_shape(e, (int)T, (int)h, (int)w, &F, &H, &W), "engine_decode_shape");
         return {F, H, W};
     }
+    // every operator call: the inputs must live where the engine's weights live
+    void check_device(const at::Tensor &t, const char *what) const {
+        TORCH_CHECK(device < 0 || t.get_device() == device, "omnitok ", what, ": tensor on GPU ", t.get_device(),
+                    ", the engine lives on GPU ", device);
+    }
+    static bool capturing(const at::Tensor &t) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        const hipError_t e = hipStreamIsCapturing(c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream(), &st);
+        return e == hipSuccess && st != hipStreamCaptureStatusNone;
+    }
     void lend_workspace(int64_t need, const at::Tensor &like) {
         if (need < 0) return;  // invalid shape: the native call reports it
-        if (workspace.defined() && workspace.numel() >= need + 256 && workspace.device() == like.device()) return;
-        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(like.get_device()).synchronize();  // earlier calls may still use the old block
+        auto cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(like.get_device());
+        if (workspace.defined() && workspace.numel() >= need + 256 && workspace.device() == like.device()) {
+            // used from another stream than the one the block was allocated on: tell the caching allocator, so that
+            // the block is not recycled under a running kernel once the engine is gone
+            if (cur.stream() != workspace_stream && !capturing(like))
+                c10::hip::HIPCachingAllocatorMasqueradingAsCUDA::recordStreamMasqueradingAsCUDA(workspace.storage().data_ptr(), cur);
+            return;
+        }
+        TORCH_CHECK(!capturing(like), "omnitok: the engine workspace has to grow for this shape, which needs a "
+                                      "synchronisation: run one eager call of the same shape before capturing a HIP graph");
+        // kernels of earlier calls -- on ANY stream -- may still use the old block
+        TORCH_CHECK(hipDeviceSynchronize() == hipSuccess, "omnitok: hipDeviceSynchronize failed");
         workspace = at::empty({need + need / 50 + 512}, like.options().dtype(at::kByte));
+        workspace_stream = cur.stream();
         const uintptr_t p = (reinterpret_cast<uintptr_t>(workspace.data_ptr()) + 255) / 256 * 256;
         check(omnitok_engine_set_workspace(e, reinterpret_cast<void *>(p),
                                            workspace.numel() - (int64_t)(p - reinterpret_cast<uintptr_t>(workspace.data_ptr()))),
@@ -149,6 +180,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> encode_impl(const c10::intrusive_
     TORCH_CHECK(x.scalar_type() == at::kFloat, "omnitok engine_encode: float32 input");
     TORCH_CHECK(eng->finalized, "omnitok engine_encode: call Engine.finalize() after the weights were set");
     TORCH_CHECK(!eng->cfg.use_vae, "omnitok engine_encode: the engine was built with use_vae (no quantiser)");
+    eng->check_device(x, "engine_encode");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     const at::Tensor xc = x.contiguous();
     auto [B, F, H, W] = video_dims(xc);
@@ -179,6 +211,7 @@ at::Tensor engine_decode(const c10::intrusive_ptr<Engine> &eng, const at::Tensor
     TORCH_CHECK(ids.is_cuda(), "omnitok engine_decode: the ids must be on the GPU");
     TORCH_CHECK(ids.scalar_type() == at::kLong && ids.dim() == 4, "omnitok engine_decode: int64 ids [B,T,h,w]");
     TORCH_CHECK(eng->finalized, "omnitok engine_decode: call Engine.finalize() after the weights were set");
+    eng->check_device(ids, "engine_decode");
     c10::hip::HIPGuardMasqueradingAsCUDA guard(ids.device());
     const at::Tensor ic = ids.contiguous();
     const int64_t B = ic.size(0), T = ic.size(1), h = ic.size(2), w = ic.size(3);
@@ -188,8 +221,11 @@ at::Tensor engine_decode(const c10::intrusive_ptr<Engine> &eng, const at::Tensor
     check(omnitok_decode(eng->e, ic.data_ptr<int64_t>(), (int)B, (int)T, (int)h, (int)w, out.data_ptr<float>(),
                          Engine::stream_of(ic)),
           "decode");
-    // the reference raises IndexError from F.embedding for ids outside [0, n_codes) (omnitokenizer.py:270)
-    check(omnitok_engine_check_ids(eng->e, Engine::stream_of(ic)), "decode (id range)");
+    // the reference raises IndexError from F.embedding for ids outside [0, n_codes) (omnitokenizer.py:270).  The check
+    // reads one flag back (hipMemcpyAsync + stream synchronise), which a stream capture cannot contain: while a HIP
+    // graph is being captured the operator leaves the flag on the device (bad ids decode as code 0, like
+    // OmniTokenizer_VQGAN.decode(check_ids=False)) and the caller may read it after the replay
+    if (!Engine::capturing(ic)) check(omnitok_engine_check_ids(eng->e, Engine::stream_of(ic)), "decode (id range)");
     return out;
 }
 

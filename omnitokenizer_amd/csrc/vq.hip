@@ -580,11 +580,23 @@ static int launch_vq_var(const float *z, const float *packed, const float *ee, i
                          hipStream_t stream) {
     constexpr bool cosine = MODE == VQ_COS;
     const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
-    // code-range splits: aim at >= 2048 workgroups (whole rounds of the chip's 512 two-per-CU slots at the
-    // BASELINE sizes: C3 640 x 4 = 5 rounds, C2 256 x 8 = 4 rounds), at least 16 tiles (512 codes) each
+    // Code-range splits.  Measured at the BASELINE sizes (profiles/r04_vq_split_sweep.txt: C3 640 row blocks x 256 tiles,
+    // C2 256 x 256, C5 272 x 512, 8 C5 clips 2176 x 512, one clip 20 x 256, one image 4 x 256): an unsplit launch is the
+    // slowest arm at every size but the smallest (one tail round of long workgroups), and past the point where the
+    // chip's 512 slots see a few rounds more splits only add prologues and atomics.  The rule minimises
+    //     (rounds + 1/2) * (tiles per workgroup + 10),   rounds = row blocks * splits / 512
+    // over splits in {1, 2, 4, 8, 16} with at least 16 tiles each -- it picks 4 / 4 / 8 / 2 / 16 / 16 there: the best
+    // measured arm at five of the six sizes (one clip: 16 instead of 8, 26.8 vs 25.6 us).
     const int ntiles = n_codes >> 5;
     int nsplit = 1;
-    while (nsplit < 16 && blocks * nsplit < 2048 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
+    {
+        double best = 1e300;
+        for (int s = 1; s <= 16; s *= 2) {
+            if (s > 1 && ntiles / s < 16) break;
+            const double cost = ((double)blocks * s / 512.0 + 0.5) * ((double)(ntiles + s - 1) / s + 10.0);
+            if (cost < best) { best = cost; nsplit = s; }
+        }
+    }
     if (g_vq_split >= 1) nsplit = g_vq_split;  // "vq_split" option: force (tests / A-B)
     if (nsplit > ntiles) nsplit = ntiles;
     if (VAR == 2)  // the staged fragments (1 KiB per tile) + ee must fit the CU's LDS

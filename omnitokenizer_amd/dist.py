@@ -71,6 +71,91 @@ class IdGather:
         return self.out
 
 
+class NativeComm:
+    """An RCCL communicator owned by libomnitok.so (include/omnitok_comm.h): ncclGetUniqueId on rank 0, the 128 bytes
+    broadcast through the EXISTING torch.distributed process group (whatever its backend), ncclCommInitRank on every
+    rank's current device.  world == 1 needs no process group (single-GPU plumbing test)."""
+
+    def __init__(self, group=None, device=None):
+        import ctypes
+        from . import _lib
+        self._lib = _lib
+        lib = _lib.load()
+        where = ctypes.create_string_buffer(256)
+        if not lib.omnitok_comm_available(where, 256):
+            raise _lib.OmnitokError(f"native gather: {where.value.decode()}")
+        self.where = where.value.decode()
+        if dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            self.rank, self.world = 0, 1
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        ident = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(lib.omnitok_comm_unique_id(ident), "comm_unique_id")
+        if self.world > 1:
+            t = torch.tensor(list(ident), dtype=torch.uint8)
+            on_gpu = dist.get_backend(group) == "nccl"
+            if on_gpu:
+                t = t.to(self.device)
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(t, src=src, group=group)
+            ident = (ctypes.c_ubyte * 128)(*t.cpu().tolist())
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.omnitok_comm_create(ident, self.rank, self.world, ctypes.byref(h)), "comm_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.load().omnitok_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeIdGather:
+    """IdGather with the collective issued from C++: `omnitok_comm_allgather_ids` (narrow int64 -> int32, ncclAllGather,
+    widen) as three stream-ordered operations on a side stream that waits for the producer stream, so the host never
+    blocks and the local decode overlaps the gather exactly as with IdGather.  Same start() / wait() surface; even
+    shards only (BASELINE C4: 256 clips on 8 GPUs) -- ragged batches use IdGather."""
+
+    def __init__(self, n_total: int, tail, device, comm: NativeComm):
+        self.comm, self.world, self.rank = comm, comm.world, comm.rank
+        self.n_total, self.tail = int(n_total), tuple(int(v) for v in tail)
+        if self.n_total % self.world:
+            raise ValueError("NativeIdGather needs n_total % world == 0 (use IdGather for ragged shards)")
+        self.count = self.n_total // self.world
+        for v in self.tail:
+            self.count *= v
+        self.out = torch.empty((self.n_total,) + self.tail, dtype=torch.int64, device=device)
+        self.side = torch.cuda.Stream(device)
+        self.pending = False
+        self._keep = None
+
+    def start(self, ids_local: torch.Tensor):
+        assert not self.pending, "NativeIdGather.start() called twice without wait()"
+        assert ids_local.dtype == torch.int64 and ids_local.is_contiguous() and ids_local.numel() == self.count
+        lib = self.comm._lib.load()
+        self.side.wait_stream(torch.cuda.current_stream(ids_local.device))
+        ids_local.record_stream(self.side)
+        self._keep = ids_local
+        self.comm._lib.check(lib.omnitok_comm_allgather_ids(self.comm.handle, ids_local.data_ptr(), self.out.data_ptr(),
+                                                            self.count, self.side.cuda_stream), "comm_allgather_ids")
+        self.pending = True
+        return self
+
+    def wait(self) -> torch.Tensor:
+        assert self.pending, "NativeIdGather.wait() without start()"
+        torch.cuda.current_stream(self.out.device).wait_stream(self.side)
+        self.pending, self._keep = False, None
+        return self.out
+
+
 def all_gather_ids(ids_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
     """ids_local [b_local, ...] int64 -> [n_total, ...] int64 on every rank (blocking form of IdGather)."""
     world = dist.get_world_size(group)

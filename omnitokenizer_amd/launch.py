@@ -67,6 +67,7 @@ class RankInfo:
     world: int = 1
     local_rank: int = 0
     backend: str = "none"
+    abandoned_thread: bool = False
 
 
 def init_ranks(expected_world: int, backend: str = "nccl", set_cuda_device: bool = True) -> RankInfo:
@@ -87,6 +88,31 @@ def init_ranks(expected_world: int, backend: str = "nccl", set_cuda_device: bool
     return RankInfo(rank, world, local_rank, backend if world > 1 else "none")
 
 
+class rank_errors:
+    """`with rank_errors(info): ...` -- a rank that fails says which rank it is and why on stderr BEFORE the launcher
+    tears the job down (torchrun's own report is "rank 1 exitcode 1" with no reason), then exits non-zero without
+    waiting on collectives the other ranks will never complete."""
+
+    def __init__(self, info: "RankInfo" = None):
+        self.info = info
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, et, ev, tb):
+        if et is None or issubclass(et, SystemExit):
+            return False
+        import traceback
+        rank = self.info.rank if self.info is not None else int(os.environ.get("RANK", "0"))
+        world = self.info.world if self.info is not None else int(os.environ.get("WORLD_SIZE", "1"))
+        sys.stderr.write(f"rank {rank} of {world}: {et.__name__}: {ev}\n")
+        sys.stderr.write("".join(traceback.format_exception(et, ev, tb)))
+        sys.stderr.flush()
+        if world > 1:
+            os._exit(1)   # do not run atexit / destructors that wait for the other ranks
+        return False
+
+
 @dataclass
 class ShardedResult:
     seconds: float                  # max over ranks of the timed region
@@ -95,7 +121,9 @@ class ShardedResult:
     rec_local: torch.Tensor = None
     n_total: int = 0
     ids_crc: int = 0                # CRC-32 of the gathered ids (equal on every rank, checked)
-    allgather_ms: Optional[float] = None
+    allgather_ms: Optional[float] = None   # one start() + wait() of the step's own persistent gather object
+    per_rank_ms: Optional[List[float]] = None   # every rank's own ms per step of the timed region (rank order)
+    gather_impl: str = "none"
     world_seen: int = 1
     extra: dict = field(default_factory=dict)
 
@@ -112,8 +140,10 @@ def _barrier(info: RankInfo, on_gpu: bool):
 
 def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.Tensor],
                         decode: Callable[[torch.Tensor], torch.Tensor], x_local: torch.Tensor,
-                        steps: int, warmup: int) -> ShardedResult:
-    """Weak-scaling protocol: every rank owns `x_local` (its clips), n_total = world * local."""
+                        steps: int, warmup: int, native_gather: bool = False) -> ShardedResult:
+    """Weak-scaling protocol: every rank owns `x_local` (its clips), n_total = world * local.
+    native_gather: issue the id all-gather from C++ (dist.NativeIdGather: ncclAllGather through libomnitok.so on a side
+    stream) instead of torch.distributed's all_gather_into_tensor."""
     on_gpu = x_local.is_cuda
     b_local = x_local.shape[0]
     n_total = b_local * info.world
@@ -132,7 +162,11 @@ def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.T
             # the one collective of the path, issued asynchronously: decode consumes only the local shard, so the
             # gather overlaps it and is waited for only when the gathered tensor is needed (its CRC, the caller)
             if state["gather"] is None:
-                state["gather"] = od.IdGather(n_total, ids_local.shape[1:], ids_local.device)
+                if native_gather:
+                    state["comm"] = od.NativeComm(device=ids_local.device)
+                    state["gather"] = od.NativeIdGather(n_total, ids_local.shape[1:], ids_local.device, state["comm"])
+                else:
+                    state["gather"] = od.IdGather(n_total, ids_local.shape[1:], ids_local.device)
             g = state["gather"].start(ids_local)
             if trace is not None:
                 trace.append("gather_start")
@@ -153,10 +187,13 @@ def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.T
     t0 = time.perf_counter()
     for _ in range(steps):
         ids, rec = step()
+    if on_gpu:
+        torch.cuda.synchronize()
+    own = time.perf_counter() - t0     # this rank alone (a straggler shows here, not in the barrier-closed time)
     _barrier(info, on_gpu)
     dt = time.perf_counter() - t0
     res = ShardedResult(seconds=dt, steps=steps, ids_local=ids, rec_local=rec, n_total=n_total,
-                        world_seen=info.world)
+                        world_seen=info.world, per_rank_ms=[round(own / steps * 1e3, 3)])
     if trace is not None:
         res.extra["step_trace"] = list(trace)
     ids_all = state["ids_all"]
@@ -181,20 +218,68 @@ def timed_sharded_steps(info: RankInfo, encode: Callable[[torch.Tensor], torch.T
         res.world_seen = int(ones.item())
         if res.world_seen != info.world:
             raise RuntimeError(f"collective saw {res.world_seen} ranks, expected {info.world}")
-        # cost of the collective alone (untimed region), averaged
-        reps = 5
+        owns = torch.zeros(info.world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(owns, torch.tensor([own / steps * 1e3], dtype=torch.float64, device=dev))
+        res.per_rank_ms = [round(v, 3) for v in owns.cpu().tolist()]
+        res.gather_impl = type(state["gather"]).__name__
+        # cost of the collective alone (untimed region): the step's own persistent gather object, start() + wait() --
+        # no allocation, no clone; what a step would pay if nothing overlapped it
+        g, reps = state["gather"], 10
+        g.start(ids).wait()
         _barrier(info, on_gpu)
         t1 = time.perf_counter()
         for _ in range(reps):
-            od.all_gather_ids(ids, n_total)
-        _barrier(info, on_gpu)
+            g.start(ids).wait()
+        if on_gpu:
+            torch.cuda.synchronize()
         ag = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], device=dev, dtype=torch.float64)
         dist.all_reduce(ag, op=dist.ReduceOp.MAX)
         res.allgather_ms = float(ag.item())
     return res
 
 
+def probe_native_gather(info: RankInfo, ids_local: torch.Tensor, res: ShardedResult, timeout_s: float = 45.0):
+    """The C++ ncclAllGather path (include/omnitok_comm.h, dist.NativeIdGather) exercised next to whichever gather the
+    timed region used: communicator bootstrap through the existing process group, one gather compared (CRC-32) with
+    the timed region's gathered ids, then its start() + wait() time.  Never fatal and never unbounded: it runs on a
+    helper thread that is abandoned after `timeout_s` (the caller then leaves with os._exit once its line is out)."""
+    import threading
+    out = {"ok": False}
+
+    def body():
+        try:
+            torch.cuda.set_device(ids_local.device)
+            comm = od.NativeComm(device=ids_local.device)
+            g = od.NativeIdGather(res.n_total, ids_local.shape[1:], ids_local.device, comm)
+            got = g.start(ids_local).wait()
+            torch.cuda.synchronize()
+            crc = zlib.crc32(got.cpu().numpy().tobytes())
+            reps = 10
+            t = time.perf_counter()
+            for _ in range(reps):
+                g.start(ids_local).wait()
+            torch.cuda.synchronize()
+            out.update(ok=bool(crc == res.ids_crc), ids_crc32=crc, ms=round((time.perf_counter() - t) / reps * 1e3, 4),
+                       rccl=comm.where, world=comm.world)
+            out["_comm"] = comm   # keep the communicator alive until the process ends (destroying it is collective)
+        except Exception as e:  # noqa: BLE001
+            out["error"] = repr(e)
+
+    th = threading.Thread(target=body, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        out["error"] = f"timeout after {timeout_s:.0f} s"
+        info.abandoned_thread = True
+    res.extra["native_comm"] = out.pop("_comm", None)
+    return out
+
+
 def finish(info: RankInfo, on_gpu: bool = True):
+    if getattr(info, "abandoned_thread", False):   # a helper thread hangs inside a collective: no orderly teardown
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if info.world > 1:
         _barrier(info, on_gpu)
         dist.destroy_process_group()

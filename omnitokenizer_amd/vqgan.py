@@ -206,9 +206,13 @@ class OmniTokenizer_VQGAN(nn.Module):
     def _signature(self):
         """Change detector for the engine's weight copies: an epoch counter bumped by load_state_dict / _apply (.to(),
         .cuda(), .float()) plus the storage pointer and in-place version of EVERY parameter and buffer on the path
-        (p.data.copy_(), an EMA swap, partial weight surgery after the first encode are all seen).  The tensor list is
-        cached per epoch: reading ~300 (data_ptr, _version) pairs costs tens of microseconds, the state_dict() walk that
-        used to be here cost more host time than a single-image encode's launches."""
+        -- in-place edits THROUGH THE PARAMETER under no_grad (p.mul_(), p.copy_(), torch.nn.init.*) and re-assigned
+        storage are seen.  NOT seen: edits through `p.data` (p.data.copy_(), p.data.mul_(), the usual EMA store / restore
+        idiom) -- `.data` is a fresh tensor object with its own version counter, so neither the pointer nor p._version
+        moves; after such an edit call mark_weights_changed(), or the engine keeps computing with its old copies
+        (tests/test_gpu_e2e.py::test_data_edits_need_mark_weights_changed pins both halves).  A device-side checksum
+        would catch them at the price of a kernel and a host synchronisation per call, which the path does not pay.
+        The tensor list is cached per epoch: reading ~300 (data_ptr, _version) pairs costs tens of microseconds."""
         cached = getattr(self, "_sig_tensors", None)
         if cached is None or cached[0] != self._weights_epoch:
             cached = (self._weights_epoch, [t for t in list(self.parameters()) + list(self.buffers())])
@@ -222,7 +226,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         check(_lib.load().omnitok_engine_set_option(self._engine, name.encode(), int(value)), "engine_set_option")
 
     def mark_weights_changed(self):
-        """Call after editing parameters in place so that the next encode/decode re-uploads them."""
+        """Call after editing parameters through `.data` (p.data.copy_(), EMA swaps, ...) so that the next encode / decode
+        re-uploads them; edits through the parameter itself, load_state_dict and .to() are detected without it."""
         self._weights_epoch += 1
 
     def _apply(self, fn, *a, **k):
@@ -364,8 +369,10 @@ class OmniTokenizer_VQGAN(nn.Module):
         # shape function instead of opaque Python
         x5 = x if x.dim() == 5 else x[:, :, None]
         ids, emb, z = torch.ops.omnitok.vqgan_encode(x5, self._handle, bool(include_embeddings), bool(return_latents))
-        # decode() trusts these ids (no range check read-back) for as long as the tensor is not modified
-        self._own_ids = (ids.data_ptr(), ids._version, tuple(ids.shape))
+        # decode() trusts THIS tensor object (no range check read-back) for as long as it is alive and unmodified.  By
+        # identity, not by address: the caching allocator hands a freed block to the next tensor of the same size, and
+        # every fresh tensor has _version 0, so (data_ptr, _version, shape) would also match foreign ids.
+        self._own_ids = (weakref.ref(ids), ids._version)
         if not include_embeddings:
             emb = None
         elif self.use_external_codebook:
@@ -507,7 +514,7 @@ class OmniTokenizer_VQGAN(nn.Module):
             # host synchronisation), so it is skipped by default while a HIP graph is being captured and for the
             # untouched output of this module's own encode() (its ids are in range by construction)
             own = getattr(self, "_own_ids", None)
-            trusted = own is not None and own == (encodings.data_ptr(), encodings._version, tuple(encodings.shape))
+            trusted = own is not None and own[0]() is encodings and own[1] == encodings._version
             check_ids = not torch.cuda.is_current_stream_capturing() and not trusted
         if check_ids:
             rc = lib.omnitok_engine_check_ids(self._engine, stream)

@@ -444,6 +444,89 @@ def run_b32_case(name="s2_sdpa_r256_vid17_b32", stride=8):
     print(f"{name}: clips {B32_CLIPS} ids {tuple(torch.cat(ids_l).shape)}")
 
 
+def boundary_distance(z64, E64, ids, chunk=2048):
+    """Distance (L2, in latent space, fp64) from every latent to the nearest decision boundary of its code's cell:
+    min over j != i of (d_j - d_i) / (2 |e_j - e_i|) with d = squared distances.  A perturbation dz can flip the token only
+    if |dz|_2 >= this -- the currency in which id flips of different arithmetics are compared."""
+    z, ids = z64.reshape(-1, z64.shape[-1]), ids.reshape(-1)
+    out = torch.empty(z.shape[0], dtype=torch.float64)
+    for a in range(0, z.shape[0], chunk):
+        zc, ic = z[a:a + chunk], ids[a:a + chunk]
+        d = (zc * zc).sum(1, keepdim=True) - 2.0 * zc @ E64.t() + (E64 * E64).sum(1)[None]
+        di = d.gather(1, ic[:, None])
+        sep = torch.cdist(E64[ic], E64, compute_mode="donot_use_mm_for_euclid_dist")   # |e_j - e_i|
+        m = (d - di) / (2.0 * sep.clamp_min(1e-300))
+        m[sep < 1e-12] = float("inf")                        # exact duplicates of the code (none in a randn codebook)
+        m.scatter_(1, ic[:, None], float("inf"))             # the code itself
+        out[a:a + chunk] = m.amin(1)
+    return out
+
+
+def run_heavy_batch_case(name="heavy_s2_sdpa_r256_vid17_b8", batch=8, stride=8):
+    """Batch-scale evidence on trained-like statistics: 8 distinct 17x256x256 clips ("mixed": clip 0
+    is one constant colour, the others image-like), synth profile "heavy", the REFERENCE itself run in fp32 and -- the
+    same nn.Module after .double() -- in fp64.  Both id sets, both z and the strided reconstructions are stored, so that
+    a GPU test can state its result in the reference's own currency: ids that flip between the reference's fp32 and
+    fp64 runs, and the per-token distance between its fp32 and fp64 latents."""
+    args = make_args(2, resolution=256)
+    cfg = OmniTokConfig.from_args(args, attention_mode="sdpa")
+    sd = synth.synth_state_dict(cfg, seed=0, profile="heavy")
+    x = synth.synth_video(batch, 17, 256, seed=1234, kind="mixed")
+    out = {}
+    for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+        model = rh.build_reference_model(args)
+        msg = model.load_state_dict(sd, strict=False)
+        assert not msg.unexpected_keys, msg.unexpected_keys
+        model = model.to(dt)
+        ids_l, z_l, rec_l = [], [], []
+        with torch.no_grad(), rh.attention_mode("sdpa"):
+            for b in range(batch):  # one clip at a time: the reference's results do not depend on the batch
+                xb = x[b:b + 1].to(dt)
+                h = model.pre_vq_conv(model.encoder(xb, False))
+                z = torch.nn.functional.normalize(h, p=2, dim=1)
+                ids = model.codebook(z)["encodings"]
+                assert torch.equal(ids, model.encode(xb, False)) if b == 0 else True
+                ids_l.append(ids)
+                z_l.append(z.permute(0, 2, 3, 4, 1).contiguous())
+                # decode the fp32 ids in both precisions: the pixel yardstick is arithmetic noise, not id flips
+                rec_l.append(model.decode(out["ids32"][b:b + 1] if tag == "64" else ids, False))
+        out["ids" + tag], out["z" + tag], out["rec" + tag] = torch.cat(ids_l), torch.cat(z_l), torch.cat(rec_l)
+        assert out["z" + tag].dtype == dt and out["rec" + tag].dtype == dt
+    ids32, ids64, z32, z64 = out["ids32"], out["ids64"], out["z32"], out["z64"]
+    E = sd["codebook.embeddings"].double()
+    flip = (ids32 != ids64).reshape(-1).nonzero().flatten()
+    zf = z64.reshape(-1, 8)[flip]
+    d32 = ((zf - E[ids32.reshape(-1)[flip]]) ** 2).sum(1)
+    d64 = ((zf - E[ids64.reshape(-1)[flip]]) ** 2).sum(1)
+    noise_l2 = (z32.double() - z64).reshape(-1, 8).norm(dim=1)
+    noise_z_clip = (z32.double() - z64).abs().reshape(batch, -1).amax(1)
+    noise_pix_clip = (out["rec32"].double() - out["rec64"]).abs().reshape(batch, -1).amax(1)
+    sl = (Ellipsis, slice(None, None, stride), slice(None, None, stride))
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        stage=2, mode="sdpa", overrides=repr(dict(resolution=256)), batch=batch, frames=17, stride=stride,
+        weight_seed=0, input_seed=1234, profile="heavy", input_kind="mixed",
+        state_crc=np.uint32(synth.state_checksum(sd)),
+        input_crc=np.uint32(__import__("zlib").crc32(x.numpy().tobytes())),
+        ids=ids32.numpy().astype(np.int16), ids64=ids64.numpy().astype(np.int16),
+        # z64 = z.double() + z64_resid.double() to 1e-12 (the residual is ~1e-5, stored in fp32): half the bytes of fp64
+        z=z32.numpy(), z64_resid=(z64 - z32.double()).float().numpy(), emb=np.zeros((0,), np.float32),
+        recon=out["rec32"][sl].contiguous().numpy(),
+        recon_absmax=np.float32(out["rec32"].abs().max().item()),
+        fp32_noise_z=np.float32(noise_z_clip.max().item()), fp32_noise_pix=np.float32(noise_pix_clip.max().item()),
+        fp32_noise_z_clip=noise_z_clip.numpy().astype(np.float32),
+        fp32_noise_pix_clip=noise_pix_clip.numpy().astype(np.float32),
+        fp32_noise_l2_max=np.float32(noise_l2.max().item()),
+        # distance of every fp64 latent to the nearest cell boundary of ITS fp64 code (see boundary_distance)
+        boundary=boundary_distance(z64, E, ids64).float().numpy(),
+        ref_flips=np.int32(flip.numel()), ref_flip_index=flip.numpy().astype(np.int32),
+        ref_flip_gap=(d32 - d64).numpy(),
+    )
+    print(f"{name}: {ids32.numel()} tokens, uniq {ids32.unique().numel()}; reference fp32-vs-fp64: {flip.numel()} id flips "
+          f"(fp64 gaps {(d32 - d64).tolist()}), z noise {noise_z_clip.max().item():.2e} (L2 {noise_l2.max().item():.2e}), "
+          f"pixel noise {noise_pix_clip.max().item():.2e}, |recon|max {out['rec32'].abs().max().item():.1f}")
+
+
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     only = sys.argv[1] if len(sys.argv) > 1 else None
@@ -478,3 +561,5 @@ if __name__ == "__main__":
     if only in (None, "heavy"):
         for c in HEAVY_CASES:
             run_case(*c, profile="heavy")
+    if only in (None, "heavy", "heavy_b8"):
+        run_heavy_batch_case()

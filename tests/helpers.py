@@ -30,6 +30,8 @@ EXT_CASES = ["ext_s2_sdpa_r64_img", "ext_s2_sdpa_r64_vid", "ext_s1_legacy_r128_v
 # trained-checkpoint-like statistics (synth profile "heavy") and image-like / constant-colour inputs
 HEAVY_CASES = ["heavy_s2_sdpa_r64_img", "heavy_s2_sdpa_r64_vid", "heavy_s1_legacy_r64_vid", "heavy_s2_sdpa_r128_vid_16k",
                "heavy_s2_sdpa_r256_vid17"]
+# 8 distinct 17x256x256 clips, heavy profile, the reference in fp32 AND fp64 (ids, z) -- 40 960 tokens
+HEAVY_BATCH_CASE = "heavy_s2_sdpa_r256_vid17_b8"
 VAE_CASES = ["vae_s2_sdpa_r64_img", "vae_s2_sdpa_r64_vid", "vae_s1_legacy_r64_vid", "vae_s2_sdpa_r256_vid"]
 
 
@@ -69,6 +71,17 @@ class GoldenCase:
         # how far the reference's own fp32 result is from the fp64 one (heavy-statistics fixtures only)
         self.fp32_noise_z = float(g["fp32_noise_z"]) if "fp32_noise_z" in g.files else 0.0
         self.fp32_noise_pix = float(g["fp32_noise_pix"]) if "fp32_noise_pix" in g.files else 0.0
+        # batch-scale heavy fixture (make_golden.run_heavy_batch_case): the reference's fp64 run beside its fp32 run
+        if "ids64" in g.files:
+            self.ids64 = torch.from_numpy(g["ids64"].astype(np.int64))
+            self.z64 = self.z.double() + torch.from_numpy(g["z64_resid"]).double()
+            self.fp32_noise_z_clip = torch.from_numpy(g["fp32_noise_z_clip"])
+            self.fp32_noise_pix_clip = torch.from_numpy(g["fp32_noise_pix_clip"])
+            self.fp32_noise_l2_max = float(g["fp32_noise_l2_max"])
+            self.ref_flips = int(g["ref_flips"])
+            # L2 distance (fp64) of every latent to the nearest boundary of its code's cell: a perturbation smaller than
+            # this cannot flip the token
+            self.boundary = torch.from_numpy(g["boundary"]).double()
         self.recon = torch.from_numpy(g["recon"])  # strided
         self.perplexity = float(g["perplexity"]) if "perplexity" in g.files else None
         self.recon_absmax = float(g["recon_absmax"])

@@ -18,7 +18,7 @@ def lib():
 
 def test_header_symbols_exported(lib):
     from omnitokenizer_amd import _lib
-    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("omnitok.h", "omnitok_lm.h", "omnitok_debug.h"))
+    hdr = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("omnitok.h", "omnitok_lm.h", "omnitok_debug.h", "omnitok_comm.h"))
     # the measurement-only entry points live in their own header, outside the drop-in boundary
     assert "omnitok_debug_" not in open(os.path.join(ROOT, "include", "omnitok.h")).read()
     declared = set(re.findall(r"\b(omnitok_[a-z0-9_]+)\s*\(", hdr))
