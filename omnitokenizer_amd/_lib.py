@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, Structure, c_char, c_char_p, c_float, c_int, c_int64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libomnitok.so")
+# OMNITOK_LIB: another build of the same library (measurement builds of tools/: ablation arms compiled with extra -D flags)
+LIB_PATH = os.environ.get("OMNITOK_LIB") or os.path.join(HERE, "lib", "libomnitok.so")
 
 
 class OmnitokConfig(Structure):

@@ -535,7 +535,534 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2p_kernel(AttnH2Params p
         }
 }
 
-int g_attn_h2_variant = 1;  // "attn_h2_variant": 1 pipelined + LDS-DMA kernel (default), 0 the first kernel
+
+// -------------------------------------------------------------------------------------------
+// Variants 2 and 3 ("attn_h2_variant" 2 / 3): the arithmetic and the operand formats of the kernel above, with the
+// instruction stream of a tile arranged around what its ISA showed (profiles/r04_attn_h2_isa.txt).  hipcc emitted the K
+// and V fragment reads right in front of their uses -- `2 x ds_read_b128, s_waitcnt lgkmcnt(0), 3 x MFMA` twelve times per
+// sub-block -- so every MFMA triple started with an exposed LDS round trip, and it kept the softmax of sub-block a
+// AFTER the S^T MFMAs of sub-block b in program order (an in-order wave then runs them one after the other whatever the
+// source intended).  Here
+//   * all fragment reads of a phase are issued as one batch BEFORE the phase that precedes their use (the K fragments
+//     of both sub-blocks at the top of the tile, the V fragments of a sub-block before its softmax), pinned with
+//     sched_barrier fences: every MFMA chain finds its operands in registers and issues back to back;
+//   * SUBS = 2 (variant 2): 64-key tiles, two workgroups per CU as before.  SUBS = 1 (variant 3): 32-key tiles, 32 KiB of
+//     LDS per workgroup and <= 168 registers: three workgroups per CU, so that a SIMD has three waves in different phases
+//     (one in its MFMA chain, the others in softmax / waiting on the barrier).
+// -------------------------------------------------------------------------------------------
+// DBG (measurement builds behind "attn_h2_dbg", wrong results): 1 no softmax arithmetic (P = S), 2 no S^T MFMAs, 4 no P.V MFMAs,
+// 8 no barrier / DMA wait in the tile loop, 16 no DMA in the tile loop, 32 no P split (lo = hi)
+template <bool HAS_BIAS, int SUBS, int DBG = 0, int MINB = (SUBS == 1 ? 3 : 2)>
+__global__ __launch_bounds__(256, MINB) void attn_spatial_h2x_kernel(AttnH2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    constexpr int TILE = SUBS * 16384;  // K (SUBS blocks of 8 KiB) | V (SUBS blocks)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int nqb = p.nqb;
+    const int b = blockIdx.x, jb = b >> 3;
+    const int grp = (jb / nqb) * 8 + (b & 7);
+    if (grp >= p.ngrp_real) return;
+    const int qb = jb % nqb, head = grp % p.heads, seq = grp / p.heads;
+    const int nblk = p.N / 32;
+    const int64_t unit0 = ((int64_t)seq * p.heads + head) * nblk;
+    const bool wave_active = qb * 128 + wave * 32 < p.N;
+    const int qblk = wave_active ? qb * 4 + wave : 0;
+    const int q_local = qblk * 32 + r32;
+
+    u32x4 qf[2][4];
+    {
+        const unsigned char *qb_ = p.qp + (unit0 + qblk) * 8192 + hi * 512 + r32 * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[pl][ks] = *reinterpret_cast<const u32x4 *>(qb_ + (pl * 4 + ks) * 1024);
+    }
+    int qy = 0, qx = 0;
+    const float *btab = nullptr;
+    if constexpr (HAS_BIAS) {
+        qy = q_local / p.gw; qx = q_local % p.gw;
+        btab = p.bias_table + head;
+    }
+
+    // tile t = SUBS x 8 KiB of K + SUBS x 8 KiB of V; wave w moves the 1 KiB chunks 4 i + w of each half
+    const unsigned char *kg = p.kp + unit0 * 8192 + wave * 1024 + lane * 16;
+    const unsigned char *vg = p.vp + unit0 * 8192 + wave * 1024 + lane * 16;
+    auto dma = [&](int t, int buf) {
+        unsigned char *s = smem_h2 + buf * TILE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2 * SUBS; ++i) {
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(kg + (int64_t)t * (SUBS * 8192) + i * 4096),
+                                             (lds_void_t *)(s + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(vg + (int64_t)t * (SUBS * 8192) + i * 4096),
+                                             (lds_void_t *)(s + SUBS * 8192 + i * 4096), 16, 0, 0);
+        }
+    };
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.0f;
+    float m_run = -INFINITY, l_run = 0.0f;
+    const float cs = HAS_BIAS ? 1.44269504088896340736f : p.s_unscale * 1.44269504088896340736f;
+
+    const int ntiles = p.N / (32 * SUBS);
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if ((DBG & 16) == 0 && t + 1 < ntiles) dma(t + 1, buf ^ 1);
+        const unsigned char *Ks = smem_h2 + buf * TILE + hi * 512 + r32 * 16;
+        const unsigned char *Vs = Ks + SUBS * 8192;
+
+        // fragment batches: 8 x ds_read_b128 each
+        auto load_k = [&](int sub, u32x4 (&f)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const u32x4 *>(Ks + sub * 8192 + i * 1024);  // [plane][ks]
+        };
+        auto load_v = [&](int sub, u32x4 (&f)[8]) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] = *reinterpret_cast<const u32x4 *>(Vs + sub * 8192 + i * 1024);  // [plane][j * 2 + mt]
+        };
+        auto qk = [&](int sub, const u32x4 (&kf)[8]) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+            if constexpr (DBG & 2) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[r] = __builtin_bit_cast(float, kf[r & 7][r >> 3] ^ qf[0][r & 3][r >> 2]) * 1e-30f;
+                return st;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, kf[ks]), kl = __builtin_bit_cast(f16x8, kf[4 + ks]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[1][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[0][ks]), st, 0, 0, 0);
+            }
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * (32 * SUBS) + sub * 32 + mfma32_row(r, hi);
+                    const int ky = kv / p.gw, kx = kv % p.gw;
+                    st[r] = fmaf(st[r], p.s_unscale,
+                                 btab[((qy - ky + p.gh - 1) * (2 * p.gw - 1) + (qx - kx + p.gw - 1)) * p.heads]);
+                }
+            }
+            return st;
+        };
+        auto softmax = [&](f32x16 &st, f16x8 (&ph)[2], f16x8 (&pl)[2]) {
+            float alpha = 1.0f;
+            if constexpr ((DBG & 1) == 0) {
+                float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+                mx = halves_max(fmaxf(mx, st[15]));
+                const float m_new = fmaxf(m_run, mx);
+                const float mc = fmaf(m_new, cs, -P_SHIFT);
+                float ps = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], cs, -mc));
+                    ps += st[r];
+                }
+                ps = halves_sum(ps);
+                alpha = __builtin_amdgcn_exp2f((m_run - m_new) * cs);
+                l_run = fmaf(l_run, alpha, ps);
+                m_run = m_new;
+            } else {
+                l_run += st[0];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = st[8 * j + e];
+                    pb[e] = st[8 * j + 4 + e];
+                }
+                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                ph[j] = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                if constexpr (DBG & 32) {
+                    pl[j] = ph[j];
+                } else {
+                    const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                    const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                    pl[j] = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            return alpha;
+        };
+        auto rescale = [&](float alpha) {
+            if constexpr (DBG & 1) return;
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            }
+        };
+        auto pv = [&](const u32x4 (&vf)[8], const f16x8 (&ph)[2], const f16x8 (&pl)[2]) {
+            if constexpr (DBG & 4) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    ot[0][r] += __builtin_bit_cast(float, vf[r & 7][r >> 3]) * (float)ph[0][r & 7];
+                    ot[1][r] += __builtin_bit_cast(float, vf[(r + 1) & 7][r >> 3]) * (float)pl[1][r & 7];
+                }
+                return;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, vf[j * 2 + mt]), vl = __builtin_bit_cast(f16x8, vf[4 + j * 2 + mt]);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[j], ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[j], ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[j], ot[mt], 0, 0, 0);
+                }
+        };
+
+        if constexpr (SUBS == 2) {
+            u32x4 ka[8], kb[8], va[8], vb[8];
+            f16x8 pha[2], pla[2], phb[2], plb[2];
+            load_k(0, ka);
+            load_k(1, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sa = qk(0, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(0, va);                            // lands under the S^T MFMAs of b and the softmax of a
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sb = qk(1, kb);
+            __builtin_amdgcn_sched_barrier(0);
+            const float alpha_a = softmax(sa, pha, pla);
+            rescale(alpha_a);
+            load_v(1, vb);                            // lands under the P.V MFMAs of a and the softmax of b
+            __builtin_amdgcn_sched_barrier(0);
+            pv(va, pha, pla);
+            __builtin_amdgcn_sched_barrier(0);
+            const float alpha_b = softmax(sb, phb, plb);
+            rescale(alpha_b);
+            pv(vb, phb, plb);
+        } else {
+            u32x4 ka[8], va[8];
+            f16x8 pha[2], pla[2];
+            load_k(0, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sa = qk(0, ka);
+            __builtin_amdgcn_sched_barrier(0);
+            load_v(0, va);
+            __builtin_amdgcn_sched_barrier(0);
+            const float alpha_a = softmax(sa, pha, pla);
+            rescale(alpha_a);
+            pv(va, pha, pla);
+        }
+        if constexpr ((DBG & 8) == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    if (!wave_active) return;
+    float bound = p.v_bound;
+    if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
+    const float inv_l = 1.0f / (l_run * h2_scale_of_bound(bound));
+    if (p.out_planes) {
+        const float so = h2_scale_of_bound(bound);
+        const int64_t row = (int64_t)seq * p.N + q_local;
+        if (head == 0 && hi == 0) p.out_scale[row] = 1.0f / so;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) pl_store_ot_block(ot[d], inv_l * so, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+        return;
+    }
+    float *orow = p.out + ((int64_t)seq * p.N + q_local) * p.ldo + head * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = ot[d][g * 4 + e] * inv_l;
+            *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+        }
+}
+
+
+// -------------------------------------------------------------------------------------------
+// Variant 4 ("attn_h2_variant" 4): 64 queries per wave.  The ablation arms of variant 3 (profiles/r04_attn_ablation.txt)
+// price the launch at  MFMA 0.53 ms + softmax VALU 0.22 ms + LDS fragment reads / DMA / barriers 0.41 ms, almost additive
+// (1.00 ms measured): a wave reads the whole 16 KiB K|V sub-block from LDS for 24 MFMAs, and an in-order wave runs its
+// phases one after the other.  Here a wave owns TWO 32-query blocks (A, B) of the same (sequence, head):
+//   * every K / V fragment read from LDS feeds 6 MFMAs instead of 3 (half the LDS bytes per flop, half the barriers and
+//     DMA issues per flop: a workgroup covers 256 queries);
+//   * the two blocks are independent, so the softmax of A is interleaved INTO the S^T MFMAs of B and the softmax of B into
+//     the P.V MFMAs of A by sched_group_barrier pipelines (1 MFMA : ~10 VALU) -- matrix and vector work of ONE wave overlap.
+// Arithmetic per query block is that of variants 1 - 3, bit for bit.  ILV = false: the same kernel without the pipelines.
+// -------------------------------------------------------------------------------------------
+//
+// OPT (variant 6): two cuts of the softmax's VALU work, which the ablation shows is paid in full beside the MFMAs --
+//   * the rescale of O is DEFERRED (cdna guide T13): a block's row maximum replaces the reference maximum only when it
+//     exceeds it by more than 2^6.5 (wave-uniform decision, taken before the block's P is formed, so nothing is scaled
+//     twice or not at all); otherwise P = exp(s - m_ref) may reach 2^6.5, which is why P is scaled by 2^9 instead of 2^14
+//     before the fp16 split (2^15.5 < 65504; the split stays a 22-bit hi|lo pair, and O / l is unchanged in exact
+//     arithmetic).  On l2-normalised q, k the running maximum settles within the first blocks: the 32 multiplies per
+//     block and query block, taken ~85 % of the time before, become rare;
+//   * the lo plane of P comes from v_fma_mix_f32 (hi as fp16 operand: lo = p - hi in one instruction instead of a
+//     conversion and a subtraction): 4 instead of 6 instructions per pair of probabilities.
+template <bool HAS_BIAS, bool ILV, bool OPT = false>
+__global__ __launch_bounds__(256, 2) void attn_spatial_h2w_kernel(AttnH2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    constexpr int TILE = 16384;  // K block (8 KiB) | V block (8 KiB) of 32 keys
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int nqb = p.nqb;       // 256-query blocks per (sequence, head)
+    const int b = blockIdx.x, jb = b >> 3;
+    const int grp = (jb / nqb) * 8 + (b & 7);
+    if (grp >= p.ngrp_real) return;
+    const int qb = jb % nqb, head = grp % p.heads, seq = grp / p.heads;
+    const int nblk = p.N / 32;
+    const int64_t unit0 = ((int64_t)seq * p.heads + head) * nblk;
+    bool active[2];
+    int q_local[2];
+    u32x4 qf[2][2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int qblk_raw = qb * 8 + wave * 2 + i;
+        active[i] = qblk_raw < nblk;
+        const int qblk = active[i] ? qblk_raw : 0;
+        q_local[i] = qblk * 32 + r32;
+        const unsigned char *qb_ = p.qp + (unit0 + qblk) * 8192 + hi * 512 + r32 * 16;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                qf[i][pl][ks] = *reinterpret_cast<const u32x4 *>(qb_ + (pl * 4 + ks) * 1024);
+    }
+    int qy[2] = {0, 0}, qx[2] = {0, 0};
+    const float *btab = nullptr;
+    if constexpr (HAS_BIAS) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            qy[i] = q_local[i] / p.gw;
+            qx[i] = q_local[i] % p.gw;
+        }
+        btab = p.bias_table + head;
+    }
+
+    const unsigned char *kg = p.kp + unit0 * 8192 + wave * 1024 + lane * 16;
+    const unsigned char *vg = p.vp + unit0 * 8192 + wave * 1024 + lane * 16;
+    auto dma = [&](int t, int buf) {
+        unsigned char *s = smem_h2 + buf * TILE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(kg + (int64_t)t * 8192 + i * 4096), (lds_void_t *)(s + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(vg + (int64_t)t * 8192 + i * 4096), (lds_void_t *)(s + 8192 + i * 4096), 16, 0,
+                                             0);
+        }
+    };
+
+    f32x16 ot[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[i][d][r] = 0.0f;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.0f, 0.0f};
+    const float cs = HAS_BIAS ? 1.44269504088896340736f : p.s_unscale * 1.44269504088896340736f;
+
+    const int ntiles = p.N / 32;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) dma(t + 1, buf ^ 1);
+        const unsigned char *Ks = smem_h2 + buf * TILE + hi * 512 + r32 * 16;
+        const unsigned char *Vs = Ks + 8192;
+        u32x4 kf[8], vf[8];
+        auto qk = [&](int i) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, kf[ks]), kl = __builtin_bit_cast(f16x8, kf[4 + ks]);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, __builtin_bit_cast(f16x8, qf[i][0][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[i][1][ks]), st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[i][0][ks]), st, 0, 0, 0);
+            }
+            if constexpr (HAS_BIAS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = t * 32 + mfma32_row(r, hi);
+                    const int ky = kv / p.gw, kx = kv % p.gw;
+                    st[r] = fmaf(st[r], p.s_unscale,
+                                 btab[((qy[i] - ky + p.gh - 1) * (2 * p.gw - 1) + (qx[i] - kx + p.gw - 1)) * p.heads]);
+                }
+            }
+            return st;
+        };
+        auto rescale = [&](int i, float alpha) {
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[i][d][r] *= alpha;
+            }
+        };
+        auto softmax = [&](int i, f32x16 &st, f16x8 (&ph)[2], f16x8 (&pl)[2]) {
+            float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, st[r]), st[r + 1]);
+            mx = halves_max(fmaxf(mx, st[15]));
+            float alpha = 1.0f, mc;
+            if constexpr (OPT) {
+                // m_run holds the reference maximum in log2 units
+                const float mxs = mx * cs;
+                if (__any(mxs > m_run[i] + 6.5f)) {
+                    const float m_new = fmaxf(m_run[i], mxs);
+                    const float a = __builtin_amdgcn_exp2f(m_run[i] - m_new);  // 0 on the first block (m_run = -inf)
+                    l_run[i] *= a;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ot[i][d][r] *= a;
+                    m_run[i] = m_new;
+                }
+                mc = m_run[i] - 9.0f;
+            } else {
+                const float m_new = fmaxf(m_run[i], mx);
+                mc = fmaf(m_new, cs, -P_SHIFT);
+                alpha = __builtin_amdgcn_exp2f((m_run[i] - m_new) * cs);
+                m_run[i] = m_new;
+            }
+            float ps = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[r] = __builtin_amdgcn_exp2f(fmaf(st[r], cs, -mc));
+                ps += st[r];
+            }
+            ps = halves_sum(ps);
+            if constexpr (OPT) l_run[i] += ps;
+            else l_run[i] = fmaf(l_run[i], alpha, ps);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (OPT) {
+                    u32x4 h4, l4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = st[8 * j + 2 * e], b2 = st[8 * j + 2 * e + 1];
+                        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+                        const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b2}, f16x2_t));
+                        float ra, rb;
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(hp), "v"(a));
+                        asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(hp), "v"(b2));
+                        h4[e] = hp;
+                        l4[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{ra, rb}, f16x2_t));
+                    }
+                    ph[j] = __builtin_bit_cast(f16x8, h4);
+                    pl[j] = __builtin_bit_cast(f16x8, l4);
+                } else {
+                    f32x4 pa, pb;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pa[e] = st[8 * j + e];
+                        pb[e] = st[8 * j + 4 + e];
+                    }
+                    const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                    const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                    const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                    ph[j] = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                    pl[j] = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+            return alpha;
+        };
+        auto pv = [&](int i, const f16x8 (&ph)[2], const f16x8 (&pl)[2]) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, vf[j * 2 + mt]), vl = __builtin_bit_cast(f16x8, vf[4 + j * 2 + mt]);
+                    ot[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[j], ot[i][mt], 0, 0, 0);
+                    ot[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[j], ot[i][mt], 0, 0, 0);
+                    ot[i][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[j], ot[i][mt], 0, 0, 0);
+                }
+        };
+        // 12 x (1 MFMA : 10 VALU / transcendental) for the region that ends here
+        auto pipeline = [&]() {
+            if constexpr (ILV) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x402, 10, 0);
+                }
+            }
+        };
+
+        f16x8 pha[2], pla[2], phb[2], plb[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[i] = *reinterpret_cast<const u32x4 *>(Ks + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sa = qk(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vf[i] = *reinterpret_cast<const u32x4 *>(Vs + i * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 sb = qk(1);                                  // S^T(B) MFMAs ...
+        const float alpha_a = softmax(0, sa, pha, pla);     // ... with the softmax of A in their shadow
+        pipeline();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!OPT) rescale(0, alpha_a);
+        pv(0, pha, pla);                                    // P.V(A) MFMAs ...
+        const float alpha_b = softmax(1, sb, phb, plb);     // ... with the softmax of B in their shadow
+        pipeline();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!OPT) rescale(1, alpha_b);
+        pv(1, phb, plb);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    float bound = p.v_bound;
+    if (p.v_bound_dev) bound *= p.v_bound_dev[(int64_t)p.v_bound_stride * (seq / p.seq_per_clip)];
+    const float so = h2_scale_of_bound(bound);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!active[i]) continue;
+        const float inv_l = 1.0f / (l_run[i] * so);
+        const int64_t row = (int64_t)seq * p.N + q_local[i];
+        if (p.out_planes) {
+            if (head == 0 && hi == 0) p.out_scale[row] = 1.0f / so;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) pl_store_ot_block(ot[i][d], inv_l * so, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+            continue;
+        }
+        float *orow = p.out + row * p.ldo + head * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ot[i][d][g * 4 + e] * inv_l;
+                *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+            }
+    }
+}
+
+int g_attn_h2_dbg = 0;  // "attn_h2_dbg": measurement builds of variant 3 (OMNITOK_ATTN_MEASUREMENT_BUILDS only)
+// "attn_h2_variant": 6 (default) 64 queries per wave, deferred rescale, v_fma_mix split | 5 64 queries per wave, softmax of
+// variants 1 - 3 | 4 = 5 with sched_group_barrier pipelines | 3 32 queries per wave, hoisted fragment reads, 32-key tiles, three
+// workgroups per CU (also what the legacy-bias path runs) | 2 the same with 64-key tiles | 1 the r02 / r03 pipelined + LDS-DMA kernel
+// | 0 the first kernel.  One box, C3 shape (profiles/r04_attn_variants.txt): 1.109 / 1.007 / 0.929 / 0.916 ms for 1 / 3 / 5 / 6.
+int g_attn_h2_variant = 6;
+//  // "attn_h2_variant": 1 pipelined + LDS-DMA kernel (default), 0 the first kernel
 
 }  // namespace omnitok
 
@@ -617,7 +1144,58 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
     dim3 grid((unsigned)((int64_t)ngrp * p.nqb));
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<false>), AH_LDS_BYTES)) return rc;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<true>), AH_LDS_BYTES)) return rc;
-    if (g_attn_h2_variant == 1) {
+    // the legacy-bias builds of the 64-query kernels spill registers: the bias path (stage-1 / legacy configurations) stays on variant 3
+    const int variant = (bias_table && g_attn_h2_variant >= 4) ? 3 : g_attn_h2_variant;
+    if (variant == 6) {
+        p.nqb = (N + 255) / 256;
+        dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
+        if (bias_table) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false, true>), gridw, dim3(256), 2 * 16384, stream, p);
+        else hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false, true>), gridw, dim3(256), 2 * 16384, stream, p);
+    } else if (variant == 4 || variant == 5) {
+        // 256 queries per workgroup
+        p.nqb = (N + 255) / 256;
+        dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
+        const int lds = 2 * 16384;
+        const bool ilv = variant == 4;
+        if (bias_table) {
+            if (ilv) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, true>), gridw, dim3(256), lds, stream, p);
+            else hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false>), gridw, dim3(256), lds, stream, p);
+        } else {
+            if (ilv) hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, true>), gridw, dim3(256), lds, stream, p);
+            else hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false>), gridw, dim3(256), lds, stream, p);
+        }
+    } else if (variant == 2 || variant == 3) {
+        const bool v3 = variant == 3;
+        const int lds = v3 ? 2 * 16384 : 2 * 32768;
+        if (v3) {
+#ifdef OMNITOK_ATTN_MEASUREMENT_BUILDS  // wrong-result ablation arms (profiles/r04_attn_ablation.txt)
+#define OT_ATTN_DBG(D) case D: hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 1, D>), grid, dim3(256), lds, stream, p); break;
+            if (g_attn_h2_dbg > 0 && !bias_table) {
+                switch (g_attn_h2_dbg) {
+                    OT_ATTN_DBG(1) OT_ATTN_DBG(2) OT_ATTN_DBG(4) OT_ATTN_DBG(6) OT_ATTN_DBG(7) OT_ATTN_DBG(8) OT_ATTN_DBG(24) OT_ATTN_DBG(32)
+                    OT_ATTN_DBG(33)
+                    case 100: hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 1, 0, 4>), grid, dim3(256), lds, stream, p); break;
+                    case 101: hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 1, 0, 2>), grid, dim3(256), lds, stream, p); break;
+                    case 102: hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 1, 0, 1>), grid, dim3(256), lds, stream, p); break;
+                    default: set_error("attn_h2_dbg %d not built", g_attn_h2_dbg); return OMNITOK_ERR_INVALID;
+                }
+                OT_LAUNCH_CHECK("attn_spatial_h2 (measurement build)");
+                return OMNITOK_OK;
+            }
+#endif
+            if (bias_table)
+                hipLaunchKernelGGL((attn_spatial_h2x_kernel<true, 1>), grid, dim3(256), lds, stream, p);
+            else
+                hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 1>), grid, dim3(256), lds, stream, p);
+        } else {
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2x_kernel<false, 2>), lds)) return rc;
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2x_kernel<true, 2>), lds)) return rc;
+            if (bias_table)
+                hipLaunchKernelGGL((attn_spatial_h2x_kernel<true, 2>), grid, dim3(256), lds, stream, p);
+            else
+                hipLaunchKernelGGL((attn_spatial_h2x_kernel<false, 2>), grid, dim3(256), lds, stream, p);
+        }
+    } else if (variant == 1) {
         if (bias_table)
             hipLaunchKernelGGL(attn_spatial_h2p_kernel<true>, grid, dim3(256), AH_LDS_BYTES, stream, p);
         else

@@ -65,6 +65,7 @@ extern int g_h2_dbg;
 extern int g_gemm_mode;
 extern int g_attn_mode;
 extern int g_attn_h2_variant;
+extern int g_attn_h2_dbg;
 extern int g_attn_vpack;
 extern int g_gemm_pl;
 extern int g_qkv_pl;
@@ -86,6 +87,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "gemm_mode")) omnitok::g_gemm_mode = value;
     else if (!strcmp(name, "attn_mode")) omnitok::g_attn_mode = value;
     else if (!strcmp(name, "attn_h2_variant")) omnitok::g_attn_h2_variant = value;
+    else if (!strcmp(name, "attn_h2_dbg")) omnitok::g_attn_h2_dbg = value;
     else if (!strcmp(name, "attn_vpack")) omnitok::g_attn_vpack = value;
     else if (!strcmp(name, "gemm_pl")) omnitok::g_gemm_pl = value;
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;

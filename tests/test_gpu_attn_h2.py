@@ -18,13 +18,14 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=[1, 0], ids=["pipelined_dma", "reg_staged"])
+@pytest.fixture(params=[3, 1, 0, 2, 4, 5, 6], ids=["hoisted_32key", "pipelined_dma", "reg_staged", "hoisted_64key", "wide_interleaved", "wide", "wide_deferred_rescale"])
 def variant(request):
-    """both builds of the attention kernel ("attn_h2_variant": 1 = software-pipelined + LDS-DMA, the default)."""
+    """every build of the attention kernel ("attn_h2_variant": 1 = software-pipelined + LDS-DMA, 0 = register-staged, 2 / 3 = fragment
+    reads hoisted in front of the MFMA chains with 64- / 32-key tiles)."""
     from omnitokenizer_amd import _lib
     _lib.set_option("attn_h2_variant", request.param)
     yield request.param
-    _lib.set_option("attn_h2_variant", 1)
+    _lib.set_option("attn_h2_variant", 6)
 
 
 def dev(t):
