@@ -50,6 +50,9 @@ const char *omnitok_version(void);
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
  *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
  *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
+ *   "attn_window_mode" 1 (default, process-wide, with gemm_pl / qkv_pl) window attention on the fp16 matrix cores from packed
+ *                operands (omnitok_stats_pack_windows -> packing epilogues -> omnitok_attn_window_h2) | 0 fp32 q|k|v and the
+ *                fp32-MFMA kernel omnitok_attn_window_planes
  *   "qkv_pl"     1 (default, process-wide) with gemm_pl: the q|k|v projection reads centred planes from omnitok_stats_pack,
  *                has the LayerNorm folded into its weight and writes the attention kernel's packed Q / K / V itself | 0 the
  *                round-2 form (row_stats -> gemm_h2 with in-loop LayerNorm -> attn_pack)
@@ -238,6 +241,13 @@ int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream);
  * attention.py:404-412). */
 int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
                        float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, omnitok_stream_t stream);
+/* The same pass with the OUTPUT rows (planes, a_scale, stats) in window-major order -- (frame, window, position inside the
+ * ws x ws window), the row order reference attention.py:170-188 (window_partition) gives the WindowAttention operand --
+ * while x [rows, dim] is read in token order (frame, y, x) of a gh x gw grid.  The q|k|v plane GEMM of a 'w' block then sees
+ * one window per 64 consecutive rows and its packing epilogues (3 / 4 with n_tokens = ws * ws) write the packed operands
+ * of omnitok_attn_window_h2 directly. */
+int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                               float *a_scale, float *stats, int gh, int gw, int ws, omnitok_stream_t stream);
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of
@@ -352,6 +362,15 @@ int omnitok_attn_window(const float *qkv, int64_t ldqkv, const float *bias_dense
 int omnitok_attn_window_planes(const float *qkv, int64_t ldqkv, const float *bias_dense, float *out, int64_t ldo,
                                void *out_planes, float out_bound, int Bn, int gh, int gw, int heads,
                                omnitok_stream_t stream);
+/* Window attention on the fp16 matrix cores from PACKED operands (csrc/attn_h2.hip; reference attention.py:254-293): qp / kp / vp
+ * are the fragment-order hi|lo planes the q|k|v plane GEMM's packing epilogues (omnitok_pl_gemm epilogue 4 without scale
+ * vectors, q_mul = the head scale; epilogue 3) write when the GEMM's rows are in window-major order
+ * (omnitok_stats_pack_windows) with n_tokens = 64; q_bound / k_bound / v_bound the static bounds they were scaled with.
+ * bias_dense: [heads][64 keys][64 queries].  Output rows in token order: fp32 `out` [Bn * gh * gw, ldo] or, when out_planes
+ * is given, hi|lo planes (K = heads * 64) scaled by the power of two of v_bound. */
+int omnitok_attn_window_h2(const void *qp, const void *kp, const void *vp, const float *bias_dense, float *out, int64_t ldo,
+                           void *out_planes, float q_bound, float k_bound, float v_bound, int Bn, int gh, int gw, int heads,
+                           omnitok_stream_t stream);
 
 /* Temporal attention (reference attention.py:402-486 with is_spatial=False): per (column, head)
  * T tokens; l2norm, q/k scales and scale applied inside. causal: is_causal / causal mask;

@@ -143,6 +143,8 @@ _PROTOS = {
     "omnitok_attn_spatial_h2_planes": [P, P, P, P, I64, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P, c_int,
                                        c_int, P, c_int, c_int, P],
     "omnitok_attn_window_planes": [P, I64, P, P, I64, P, c_float, c_int, c_int, c_int, c_int, P],
+    "omnitok_attn_window_h2": [P, P, P, P, P, I64, P, c_float, c_float, c_float, c_int, c_int, c_int, c_int, P],
+    "omnitok_stats_pack_windows": [P, I64, c_int, c_float, c_int, P, I64, P, P, c_int, c_int, c_int, P],
     "omnitok_attn_temporal_planes": [P, I64, P, P, I64, P, I64, P, P, c_float, P, c_int, I64, I64, c_int, c_int, P, P,
                                      c_float, c_int, P, P],
     # include/omnitok_comm.h

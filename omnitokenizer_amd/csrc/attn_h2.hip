@@ -1056,6 +1056,144 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2w_kernel(AttnH2Params p
     }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// Window attention on packed operands (reference attention.py:254-293): one wave per (frame, window, head) -- 64 queries
+// x 64 keys x 64 channels -- with Q, K, V as the 8 KiB fragment-order blocks the q|k|v plane GEMM's packing epilogues
+// write when its rows arrive in window-major order (omnitok_stats_pack_windows; n_tokens = 64, so a "sequence" of the
+// packed layout is one window).  Every operand byte is read once, by one wave, as lane-linear 16-byte loads straight
+// into MFMA fragments: no LDS, no staging, 48 KiB in and 16 KiB (planes) out per wave -- an HBM-bound kernel, which is
+// what SURVEY 8(d) prices window attention as.  Arithmetic: the fp16 hi|lo split products of the spatial kernel,
+// logits = q.k (q pre-multiplied by the head scale in the packing epilogue) + relative_position_bias[head][key][query]
+// (dense [heads][64][64], built once at finalize), softmax over the window's 64 keys in fp32, P.V.
+// The output rows go back to token order (frame, y, x): as fp16 hi|lo planes for the proj GEMM, or fp32 rows.
+// -------------------------------------------------------------------------------------------
+struct WinH2Params {
+    const unsigned char *qp, *kp, *vp;
+    const float *bias_dense;  // [heads][64 kv][64 q]
+    float *out; int64_t ldo;
+    unsigned char *out_planes;
+    float out_mul;            // power-of-two scale of the output planes (static bound of |V|)
+    float s_unscale, v_scale;  // 1 / (sq sk); the V planes' power-of-two scale
+    int gh, gw, heads, nwin_x, nwin;
+};
+
+__global__ __launch_bounds__(256, 2) void attn_window_h2_kernel(WinH2Params p, int64_t total_units) {
+    const int lane = threadIdx.x & 63;
+    const int64_t unit = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (frame, window, head), head fastest
+    if (unit >= total_units) return;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int head = (int)(unit % p.heads);
+    const int64_t seq = unit / p.heads;           // (frame, window)
+    const int win = (int)(seq % p.nwin);
+    const int64_t frame = seq / p.nwin;
+    const int wy = win / p.nwin_x, wx = win % p.nwin_x;
+    const int64_t base = (seq * p.heads + head) * 2 * 8192 + hi * 512 + r32 * 16;
+
+    // K fragments of both 32-key blocks: [kb][plane * 4 + ks]
+    u32x4 kf[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kf[kb][i] = *reinterpret_cast<const u32x4 *>(p.kp + base + kb * 8192 + i * 1024);
+    const float *bh = p.bias_dense + (int64_t)head * 64 * 64;
+    const float LOG2E = 1.44269504088896340736f;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        u32x4 qf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const u32x4 *>(p.qp + base + qb * 8192 + i * 1024);
+        // V fragments of both key blocks are requested before the S^T MFMAs: they land under them and the softmax
+        u32x4 vf[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) vf[kb][i] = *reinterpret_cast<const u32x4 *>(p.vp + base + kb * 8192 + i * 1024);
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const f16x8 kh = __builtin_bit_cast(f16x8, kf[kb][ks]), kl = __builtin_bit_cast(f16x8, kf[kb][4 + ks]);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, __builtin_bit_cast(f16x8, qf[ks]), st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[4 + ks]), st[kb], 0, 0, 0);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[ks]), st[kb], 0, 0, 0);
+            }
+        }
+        // logits (attention.py:274-282) and the softmax over the window's 64 keys (both blocks are in registers: one pass)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kb * 32 + mfma32_row(r, hi);
+                const float sgt = fmaf(st[kb][r], p.s_unscale, bh[kv * 64 + qb * 32 + r32]);
+                st[kb][r] = sgt;
+                mx = fmaxf(mx, sgt);
+            }
+        mx = halves_max(mx);
+        const float mc = fmaf(mx, LOG2E, -P_SHIFT);
+        float ps = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                st[kb][r] = __builtin_amdgcn_exp2f(fmaf(st[kb][r], LOG2E, -mc));
+                ps += st[kb][r];
+            }
+        ps = halves_sum(ps);
+        f32x16 ot[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] = 0.0f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 pa, pb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    pa[e] = st[kb][8 * j + e];
+                    pb[e] = st[kb][8 * j + 4 + e];
+                }
+                const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
+                const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);
+                const f16x4 lb = __builtin_convertvector(pb - __builtin_convertvector(hb, f32x4), f16x4);
+                const f16x8 ph = __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7);
+                const f16x8 pl = __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 vh = __builtin_bit_cast(f16x8, vf[kb][j * 2 + mt]), vl = __builtin_bit_cast(f16x8, vf[kb][4 + j * 2 + mt]);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph, ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl, ot[mt], 0, 0, 0);
+                    ot[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph, ot[mt], 0, 0, 0);
+                }
+            }
+        // token row of this lane's query (window position qb * 32 + r32), reference window_reverse (attention.py:191-207)
+        const int pos = qb * 32 + r32;
+        const int64_t row = frame * (int64_t)p.gh * p.gw + (int64_t)(wy * 8 + (pos >> 3)) * p.gw + wx * 8 + (pos & 7);
+        const float inv_l = 1.0f / (ps * p.v_scale);   // ps carries 2^14, the V planes their power-of-two scale: both exact
+        if (p.out_planes) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) pl_store_ot_block(ot[d], inv_l * p.out_mul, p.out_planes, row, head * 2 + d, p.heads * 2, hi);
+        } else {
+            float *orow = p.out + row * p.ldo + head * 64;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = ot[d][g * 4 + e] * inv_l;
+                    *reinterpret_cast<f32x4 *>(orow + d * 32 + g * 8 + hi * 4) = o;
+                }
+        }
+    }
+}
+
 int g_attn_h2_dbg = 0;  // "attn_h2_dbg": measurement builds of variant 3 (OMNITOK_ATTN_MEASUREMENT_BUILDS only)
 // "attn_h2_variant": 6 (default) 64 queries per wave, deferred rescale, v_fma_mix split | 5 64 queries per wave, softmax of
 // variants 1 - 3 | 4 = 5 with sched_group_barrier pipelines | 3 32 queries per wave, hoisted fragment reads, 32-key tiles, three
@@ -1205,5 +1343,34 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
     else
         hipLaunchKernelGGL(attn_spatial_h2_kernel<false>, grid, dim3(256), AH_LDS_BYTES, stream, p);
     OT_LAUNCH_CHECK("attn_spatial_h2");
+    return OMNITOK_OK;
+}
+
+// Window attention over packed operands (see attn_window_h2_kernel).  qp / kp / vp: the packed planes of Bn * (gh / 8) *
+// (gw / 8) windows x heads, 64 tokens each, rows in window-major order; q_bound / k_bound / v_bound: the static bounds the
+// packing epilogues scaled them with.  out (fp32 [Bn * gh * gw, ldo], token order) or out_planes (hi|lo planes, K = heads *
+// 64, scaled by the power of two of v_bound: the consumer's a_scale_const = omnitok_pl_unscale(v_bound)).
+extern "C" int omnitok_attn_window_h2(const void *qp, const void *kp, const void *vp, const float *bias_dense, float *out,
+                                      int64_t ldo, void *out_planes, float q_bound, float k_bound, float v_bound, int Bn, int gh,
+                                      int gw, int heads, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(qp && kp && vp && bias_dense && (out || out_planes), "attn_window_h2: null pointer");
+    OT_CHECK_ARG(gh % 8 == 0 && gw % 8 == 0, "attn_window_h2: grid %dx%d not divisible by the 8x8 window", gh, gw);
+    OT_CHECK_ARG(aligned16(qp) && aligned16(kp) && aligned16(vp) && (!out || (aligned16(out) && ldo % 4 == 0)) &&
+                     (!out_planes || aligned16(out_planes)), "attn_window_h2: unaligned");
+    OT_CHECK_ARG(q_bound > 0.0f && k_bound > 0.0f && v_bound > 0.0f, "attn_window_h2: operand bounds must be positive");
+    WinH2Params p;
+    p.qp = static_cast<const unsigned char *>(qp); p.kp = static_cast<const unsigned char *>(kp);
+    p.vp = static_cast<const unsigned char *>(vp);
+    p.bias_dense = bias_dense; p.out = out; p.ldo = ldo; p.out_planes = static_cast<unsigned char *>(out_planes);
+    p.v_scale = h2_scale_of_bound(v_bound);
+    p.out_mul = p.v_scale;
+    p.s_unscale = 1.0f / (h2_scale_of_bound(q_bound) * h2_scale_of_bound(k_bound));
+    p.gh = gh; p.gw = gw; p.heads = heads; p.nwin_x = gw / 8; p.nwin = (gh / 8) * (gw / 8);
+    const int64_t total = (int64_t)Bn * p.nwin * heads;
+    if (total == 0) return OMNITOK_OK;
+    OT_CHECK_ARG((total + 3) / 4 < (1ll << 31), "attn_window_h2: grid too large");
+    hipLaunchKernelGGL(attn_window_h2_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, total);
+    OT_LAUNCH_CHECK("attn_window_h2");
     return OMNITOK_OK;
 }

@@ -69,6 +69,7 @@ extern int g_attn_h2_dbg;
 extern int g_attn_vpack;
 extern int g_gemm_pl;
 extern int g_qkv_pl;
+extern int g_attn_window_mode;
 extern int g_pl_cfg;
 extern int g_pl_stagger;
 extern int g_vq_variant;
@@ -93,6 +94,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
     else if (!strcmp(name, "pl_stagger")) omnitok::g_pl_stagger = value;
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;
+    else if (!strcmp(name, "attn_window_mode")) omnitok::g_attn_window_mode = value;
     else if (!strcmp(name, "lm_wide_u")) omnitok::g_lm_wide_u = value;
     else if (!strcmp(name, "h2_dbg")) omnitok::g_h2_dbg = value;
     else if (!strcmp(name, "h2_tile")) omnitok::g_h2_tile = value;

@@ -51,6 +51,8 @@ struct LayerW {  // 'w' block
     const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;
     const float *wqkv_fold = nullptr, *fold_b = nullptr, *fold_u = nullptr;  // all 3D rows folded (q, k, v from LN(x))
     float ln_bound = 0.0f, ao_bound = 0.0f;  // >= max |LN(x)|, >= max |window attention output|
+    // >= max |q * scale|, >= max |k|: |LN(x) . W_j| <= ||LN(x)||_2 ||W_j||_2 (operand ranges of the packed window attention)
+    float q_bound = 0.0f, k_bound = 0.0f;
 };
 struct LayerFF {
     const float *lw, *lb, *w1p, *w2p;

@@ -336,6 +336,11 @@ int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &pr
                                           stream))
                     return rc;
                 L.w.ao_bound = 1.01f * l2 * vn;  // |softmax-weighted V| <= max |V_j| <= ||LN(x)|| ||Wv_j||
+                float qn = 0, kn = 0;
+                if (int rc = weight_range(e, L.w.wqkv, c.dim, c.dim, c.dim, &qn, nullptr, stream)) return rc;
+                if (int rc = weight_range(e, L.w.wqkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &kn, nullptr, stream)) return rc;
+                L.w.q_bound = 1.01f * l2 * qn / sqrtf((float)c.dim_head);  // q * head_dim^-0.5 (attention.py:227, 274)
+                L.w.k_bound = 1.01f * l2 * kn;
             }
         }
         float *w1p, *w2p;

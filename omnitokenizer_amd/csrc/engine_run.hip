@@ -25,6 +25,10 @@ int g_gemm_pl = 1;
 // kernel's packed planes (no fp32 Q / K, no attn_pack pass); V by a swapped-orientation launch.  0: gemm_h2 with the
 // LayerNorm fused into its A loader (r02 form).
 int g_qkv_pl = 1;
+// "attn_window_mode" 1 (default, with gemm_pl / qkv_pl): window attention on the fp16 matrix cores from packed operands --
+// the q|k|v plane GEMM runs on window-major rows (omnitok_stats_pack_windows) and its packing epilogues write what
+// omnitok_attn_window_h2 reads; no fp32 q|k|v in memory.  0: fp32 q|k|v + the fp32-MFMA kernel of attn_spatial.hip.
+int g_attn_window_mode = 1;
 
 int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->opt_gemm_mode : g_gemm_mode; }
 int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
@@ -387,6 +391,61 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                    eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL, 0, 0,
                            0, stream, ab_ao));
         } else {
+            const auto okb = [](float v) { return v > 0.0f && v < 1e30f; };
+            if (pl && g_qkv_pl && g_attn_window_mode == 1 && ly.w.wqkv_fold && e->plw.count(ly.w.wqkv_fold) && c.window_size == 8 &&
+                gh % 8 == 0 && gw % 8 == 0 && c.dim_head == 64 && okb(ly.w.q_bound) && okb(ly.w.k_bound) && okb(ly.w.ao_bound)) {
+                // Window attention on packed operands (reference attention.py:254-293): the centred rows go out in
+                // window-major order, so that every 64 consecutive GEMM rows are one window and the packing epilogues (n_tokens
+                // = 64; no RoPE, no l2norm, q * head scale) write the attention kernel's Q / K / V blocks directly; the
+                // attention kernel maps its output rows back to token order (window_reverse) as planes for the proj GEMM.
+                const int64_t Lp = (L + 255) / 256 * 256;
+                OT_RUN("stats_pack", 2.0 * L * D * 4.0,
+                       omnitok_stats_pack_windows(e->X.p, L, D, 1e-5f, 1, e->X2.p, Lp, e->Z.p, e->ST.p, gh, gw, 8, stream));
+                const H2W &wf = e->plw[ly.w.wqkv_fold];
+                unsigned char *qp = reinterpret_cast<unsigned char *>(e->Y.p);
+                unsigned char *kp = reinterpret_cast<unsigned char *>(e->HD.p);
+                unsigned char *vp = kp + (size_t)L * D * 4;
+                omnitok_pl_gemm g{};
+                g.a = e->X2.p;
+                g.a_scale = e->Z.p;
+                g.w = wf.pl;
+                g.w_scale = wf.sc;
+                g.fold_stats = e->ST.p;
+                g.fold_b = ly.w.fold_b;
+                g.M = L;
+                g.K = D;
+                omnitok_pl_gemm q = g;
+                q.N = 2 * D;
+                q.fold_cols = 2 * D;
+                q.epilogue = 4;
+                q.qp = qp;
+                q.kp = kp;
+                q.qk_k0 = D;
+                q.n_tokens = 64;
+                q.heads = heads;
+                q.q_mul = 1.0f / sqrtf((float)c.dim_head);
+                q.q_bound = ly.w.q_bound;
+                q.k_bound = ly.w.k_bound;
+                OT_RUN("gemm_qkv", gemm_f * 2 * D, omnitok_gemm_pl(&q, stream));
+                omnitok_pl_gemm v = g;
+                v.w = static_cast<const char *>(wf.pl) + (int64_t)(2 * D / 64) * (D / 32) * 8192;
+                v.w_scale = wf.sc + 2 * D;
+                v.fold_b = ly.w.fold_b + 2 * D;
+                v.fold_cols = D;
+                v.N = D;
+                v.epilogue = 3;
+                v.vp = vp;
+                v.n_tokens = 64;
+                v.heads = heads;
+                v.v_bound = ly.w.ao_bound;
+                OT_RUN("gemm_qkv", gemm_f * D, omnitok_gemm_pl(&v, stream));
+                OT_RUN("attn_window", 4.0 * (double)L * 64.0 * D,
+                       omnitok_attn_window_h2(qp, kp, vp, ly.w.bias_dense, nullptr, 0, e->AO.p, ly.w.q_bound, ly.w.k_bound,
+                                              ly.w.ao_bound, B * T, gh, gw, heads, stream));
+                if (int rc = gemm_out_pl(ly, e->AO.p, nullptr, omnitok_pl_unscale(ly.w.ao_bound), ly.w.wproj, ly.w.bproj))
+                    return rc;
+                goto feed_forward;
+            }
             if (pl && g_qkv_pl && ly.w.wqkv_fold && e->plw.count(ly.w.wqkv_fold)) {
                 // q, k, v all from LN(x) (reference attention.py:262-272): the gain folded into every weight row
                 const int64_t Lp = (L + 255) / 256 * 256;

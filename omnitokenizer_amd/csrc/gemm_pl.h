@@ -821,7 +821,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         swl = p.w_scale[ncl];
                         if (fold && p.fold_b) fxl = p.fold_b[ncl];
                         if (unfold) fxl = p.fold_u[ncl];
-                        svl = svec[ln];
+                        svl = svec ? svec[ln] : 1.0f;
                     }
                     const bool rope = p.cosT != nullptr;  // kernel-uniform
                     unsigned char *rope_c = pl_smem + d_stage * C::STAGE;
@@ -913,7 +913,10 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         for (int mi = 0; mi < MI; ++mi) {
                             const float t = ss[mi] + swap32(ss[mi]);
                             inv[mi] = mul * so / fmaxf(sqrtf(t), 1e-12f);  // F.normalize eps (attention.py:24-25), SDPA scale,
-                        }                                                   // power-of-two operand scale
+                            // power-of-two operand scale.  Without scale vectors (window attention, attention.py:272-275: q * scale and
+                            // k as projected) there is no normalisation either
+                            if (!svec) inv[mi] = mul * so;
+                        }
                         // phase B: l2norm, learned scale, split, store
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
@@ -967,13 +970,17 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     const float *mbase = p.fold_stats ? p.fold_stats : p.w_scale;   // row means (times un = 0 without a fold)
                     int64_t mumax = p.fold_stats ? p.M - 1 : 0;
                     asm volatile("" : "+v"(mbase), "+v"(mumax));
-                    float swn[NI], un[NI];
+                    // centred operand: plain columns (n >= fold_cols) get + mean u_n, LayerNorm-folded columns (n < fold_cols: the
+                    // window attention's V is projected from LN(x), attention.py:262-272) get rstd * (...) + b_n
+                    const bool vfold = p.fold_stats && n_w0 < p.fold_cols;  // wave-uniform (fold_cols % 64 == 0)
+                    float swn[NI], un[NI], bn[NI];
                     int vcol[NI];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) {
                         vcol[ni] = n_w0 + ni * 32 + pl_perm(r32);    // column inside V: head vcol / 64, d half (vcol / 32) & 1
                         swn[ni] = p.w_scale[vcol[ni]] * ascl_c * sv;
-                        un[ni] = (p.fold_stats && p.fold_u) ? p.fold_u[vcol[ni]] * sv : 0.0f;  // centred operand: + mean u
+                        un[ni] = (p.fold_stats && !vfold && p.fold_u) ? p.fold_u[vcol[ni]] * sv : 0.0f;
+                        bn[ni] = (vfold && p.fold_b) ? p.fold_b[vcol[ni]] * sv : 0.0f;
                     }
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
@@ -981,8 +988,10 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         const int64_t row = m_w0 + mi * 32;               // first token of this 32-token block
                         // row factors: lane r32 loads those of row + r32 (coalesced), registers pick theirs by lane shuffles
                         const int64_t rl = row + r32;
-                        const float sa_l = abase[rl < mmax ? rl : mmax] * has + (1.0f - has);
+                        float sa_l = abase[rl < mmax ? rl : mmax] * has + (1.0f - has);
                         const float mu_l = mbase[2 * (rl < mumax ? rl : mumax)];
+                        const float rs_l = mbase[2 * (rl < mumax ? rl : mumax) + (p.fold_stats ? 1 : 0)];
+                        if (vfold) sa_l *= rs_l;   // rstd_m (acc sa sw): one more rounding than the fp32 epilogue's order, inside the split's own
                         float sa_r[16], mu_r[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -1002,8 +1011,8 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                 f32x4 pa, pb;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) {
-                                    pa[e] = acc[ni][mi][8 * j + e] * (sa_r[8 * j + e] * swn[ni]) + mu_r[8 * j + e] * un[ni];
-                                    pb[e] = acc[ni][mi][8 * j + 4 + e] * (sa_r[8 * j + 4 + e] * swn[ni]) + mu_r[8 * j + 4 + e] * un[ni];
+                                    pa[e] = acc[ni][mi][8 * j + e] * (sa_r[8 * j + e] * swn[ni]) + (mu_r[8 * j + e] * un[ni] + bn[ni]);
+                                    pb[e] = acc[ni][mi][8 * j + 4 + e] * (sa_r[8 * j + 4 + e] * swn[ni]) + (mu_r[8 * j + 4 + e] * un[ni] + bn[ni]);
                                 }
                                 const f16x4 ha = __builtin_convertvector(pa, f16x4), hb = __builtin_convertvector(pb, f16x4);
                                 const f16x4 la = __builtin_convertvector(pa - __builtin_convertvector(ha, f32x4), f16x4);

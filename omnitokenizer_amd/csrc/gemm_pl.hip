@@ -250,10 +250,10 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
         case PL_QKPACK:
             OT_CHECK_ARG(g->qp && g->kp && aligned16(g->qp) && aligned16(g->kp) && g->heads > 0 && g->qk_k0 == g->heads * 64 &&
                              g->N == 2 * g->qk_k0 && g->n_tokens > 0 && g->n_tokens % 32 == 0 && g->M % g->n_tokens == 0 &&
-                             g->q_scale && g->k_scale && g->q_bound > 0.0f && g->k_bound > 0.0f &&
+                             (g->q_scale == nullptr) == (g->k_scale == nullptr) && g->q_bound > 0.0f && g->k_bound > 0.0f &&
                              (g->rope_cos == nullptr) == (g->rope_sin == nullptr),
                          "gemm_pl: packed Q | K needs qp, kp, N == 2 * heads * 64, whole sequences of n_tokens %% 32 == 0 rows, "
-                         "the q / k scale vectors and bounds");
+                         "both q / k scale vectors (or neither: no l2 normalisation) and bounds");
             p.qp = static_cast<unsigned char *>(g->qp);
             p.kp = static_cast<unsigned char *>(g->kp);
             p.qk_k0 = g->qk_k0;

@@ -255,10 +255,14 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const f32x4 *__re
 // (16 consecutive rows x 16 B of one (k block, plane, k group)).
 constexpr int SP_CSTRIDE = 16 * 16 + 16;  // LDS stride of a 16-row chunk column (16 B pad: bank spread)
 
+// win_gw > 0: the OUTPUT rows (planes, a_scale, stats) are in window-major order -- row = (frame, window, position inside the
+// ws x ws window), the order reference attention.py:170-188 window_partition produces -- while x is read in token order
+// (frame, y, x): the operand of the window-attention q|k|v GEMM, whose packing epilogues then see 64 consecutive rows per
+// window and need no row map of their own.
 template <int H>
 __global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restrict__ x, int64_t rows, float eps, int center,
                                                             unsigned char *__restrict__ planes, float *__restrict__ a_scale,
-                                                            float *__restrict__ stats) {
+                                                            float *__restrict__ stats, int win_gh, int win_gw, int win_ws) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     constexpr int K = 256 * H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,7 +272,15 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + r;
-        const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (row < rows ? row : rows - 1) * K);
+        int64_t src = row < rows ? row : rows - 1;
+        if (win_gw > 0) {
+            const int S = win_gh * win_gw, w2 = win_ws * win_ws, nwx = win_gw / win_ws;
+            const int64_t f = src / S;
+            const int rr = (int)(src - f * S), win = rr / w2, pos = rr - win * w2;
+            const int y = (win / nwx) * win_ws + pos / win_ws, xx = (win % nwx) * win_ws + pos % win_ws;
+            src = f * S + y * win_gw + xx;
+        }
+        const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + src * K);
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             v[r][h] = __builtin_nontemporal_load(xr + lane + 64 * h);
@@ -399,9 +411,27 @@ extern "C" int omnitok_row_stats(const float *x, int64_t rows, int dim, float ep
     return OMNITOK_OK;
 }
 
+static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                           float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, int win_gh, int win_gw, int win_ws,
+                           omnitok_stream_t stream_);
+
 extern "C" int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
                                   float *a_scale, float *stats, float *bounds, int64_t rows_per_clip,
                                   omnitok_stream_t stream_) {
+    return stats_pack_impl(x, rows, dim, eps, center, planes, m_pad, a_scale, stats, bounds, rows_per_clip, 0, 0, 0, stream_);
+}
+
+extern "C" int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim, float eps, int center, void *planes,
+                                          int64_t m_pad, float *a_scale, float *stats, int gh, int gw, int ws,
+                                          omnitok_stream_t stream_) {
+    OT_CHECK_ARG(gh > 0 && gw > 0 && ws > 0 && gh % ws == 0 && gw % ws == 0 && rows % ((int64_t)gh * gw) == 0,
+                 "stats_pack_windows: %lld rows of a %d x %d grid, window %d", (long long)rows, gh, gw, ws);
+    return stats_pack_impl(x, rows, dim, eps, center, planes, m_pad, a_scale, stats, nullptr, 0, gh, gw, ws, stream_);
+}
+
+static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                           float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, int win_gh, int win_gw, int win_ws,
+                           omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(x && planes && a_scale, "stats_pack: null pointer");
     OT_CHECK_ARG(dim > 0 && dim % 256 == 0 && dim <= 1024, "stats_pack: dim=%d (multiples of 256 up to 1024)", dim);
@@ -415,7 +445,7 @@ extern "C" int omnitok_stats_pack(const float *x, int64_t rows, int dim, float e
     do {                                                                                                               \
         if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh>), lds)) return rc;       \
         hipLaunchKernelGGL(stats_pack_kernel<Hh>, grid, dim3(256), lds, stream, x, rows, eps, center,                  \
-                           static_cast<unsigned char *>(planes), a_scale, stats);                                      \
+                           static_cast<unsigned char *>(planes), a_scale, stats, win_gh, win_gw, win_ws);              \
     } while (0)
     switch (dim / 256) {
         case 1: OT_SP(1); break;

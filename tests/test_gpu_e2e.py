@@ -218,6 +218,30 @@ def test_heavy_statistics_at_batch_scale(models, modes):
     assert torch.isfinite(recon).all()
 
 
+@pytest.mark.parametrize("name", ["s2_sdpa_r64_vid", "s2_sdpa_r256_img", "heavy_s2_sdpa_r128_vid_16k"])
+def test_window_attention_paths_agree(models, name):
+    """'w' blocks (reference attention.py:254-293) on packed operands and the fp16 matrix cores ("attn_window_mode" 1, the
+    default) against the fp32-MFMA window kernel (mode 0) and the reference's golden outputs: both satisfy the same bars."""
+    from omnitokenizer_amd import _lib
+    c = GoldenCase(name)
+    m = models(c)
+    res = {}
+    try:
+        for mode in (0, 1):
+            _lib.set_option("attn_window_mode", mode)
+            ids, z = m.encode(c.x.cuda(), c.is_image, return_latents=True)
+            res[mode] = (ids.cpu(), z.cpu())
+    finally:
+        _lib.set_option("attn_window_mode", 1)
+    tol = max(Z_TOL, 8.0 * c.fp32_noise_z)
+    for mode, (ids, z) in res.items():
+        zerr = (z - c.z).abs().max().item()
+        print(f"{name} attn_window_mode {mode}: z err {zerr:.2e}, flips {(ids != c.ids).sum().item()}")
+        assert zerr < tol, (mode, zerr)
+        assert_ids_match_or_near_tie(ids, c.ids, z, c.sd["codebook.embeddings"], f"{name} window mode {mode}")
+    assert (res[0][1] - res[1][1]).abs().max().item() < 2 * tol
+
+
 def test_two_engines_with_different_modes_in_one_process():
     """The arithmetic / data-flow modes are per-engine fields (omnitok_engine_set_option): two modules of one process run
     different modes side by side, each bit-identical to a run of that mode selected process-wide."""
