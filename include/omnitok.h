@@ -194,7 +194,8 @@ typedef struct omnitok_pl_gemm {
     const float *ln_beta;       /* or NULL                                                                      */
     float ln_eps;
     int epilogue;               /* 0 fp32 | 1 GEGLU -> planes | 2 fp32 AND LayerNorm -> planes (N == 512) |     */
-                                /* 3 packed V planes of omnitok_attn_spatial_h2 | 4 packed Q | K planes           */
+                                /* 3 packed V planes of omnitok_attn_spatial_h2 | 4 packed Q | K planes |         */
+                                /* 5 fp32 pixels (un-patchify store, up_* below)                                 */
     /* LayerNorm folded into the weight (epilogues 0, 3, 4): the operand a holds the CENTRED rows x - mean(x)
      * (omnitok_stats_pack), the weight rows n < fold_cols were multiplied by gamma before packing, and the epilogue finishes
      *   n <  fold_cols:  LayerNorm(x) . W^T = rstd_m ((x - mean_m) . (W o gamma)^T) + b_n     (b = W beta, or NULL)
@@ -223,6 +224,15 @@ typedef struct omnitok_pl_gemm {
     int N, K;
     int cfg;                    /* 0 auto | 1 256x256 tiles, one workgroup per CU | 2 128x256, two per CU        */
     long long *debug_cycles;    /* measurement: shader-clock span of workgroup 0 (NULL = off)                   */
+    /* Operand row map (0 = identity): GEMM row m reads plane row (m / a_rpg) * a_gstride + a_goff + m % a_rpg (a_rpg and
+     * a_goff multiples of 256: the frame groups of the token tensor, reference omnitokenizer.py:1006-1017 to_pixels_first_frame /
+     * to_pixels take tokens[:, :1] / tokens[:, 1:]).                                                                */
+    int64_t a_rpg, a_gstride, a_goff;
+    /* epilogue 5: fp32 output (+ bias) scattered as pixels -- row m = patch (b, t, gy, gx) of a [B, up_C, up_F, up_H, up_W]
+     * video `c`, column n = feature ((ch up_pt + j) up_p + p1) up_p + p2, frame up_f0 + t up_pt + j (the Rearrange
+     * 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' of omnitokenizer.py:1006-1017 fused into the store).
+     * up_p == 8 and (up_W / up_p) % 32 == 0: a 32-row block of the tile is 32 consecutive patches of one patch row     */
+    int up_C, up_F, up_H, up_W, up_f0, up_t, up_pt, up_p;
 } omnitok_pl_gemm;
 int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad);
 /* the factor that undoes the power-of-two scale derived from a static bound (a_scale_const of the consumer) */
@@ -248,6 +258,11 @@ int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int cen
  * of omnitok_attn_window_h2 directly. */
 int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
                                float *a_scale, float *stats, int gh, int gw, int ws, omnitok_stream_t stream);
+/* LayerNorm(x) [rows, dim] straight into hi|lo planes scaled by the power of two of `bound` (>= max |LayerNorm(x)|; the
+ * consumer's a_scale_const = omnitok_pl_unscale(bound)): a standalone LayerNorm in front of a plane GEMM in one pass. */
+int omnitok_layernorm_planes(const float *x, int64_t rows, int dim, float eps, const float *gamma, const float *beta,
+                             float bound, void *planes, int64_t m_pad, omnitok_stream_t stream);
+
 /* stats[m][2] = (mean, 1/sqrt(var + eps)) of x[m, :dim] (two-pass, like omnitok_layernorm).
  * bounds (optional, [n_clips][2] floats zeroed by the caller, clip of row m = m / rows_per_clip, a single
  * clip if rows_per_clip <= 0) receive, by atomic max over the rows of each clip, rigorous upper bounds of

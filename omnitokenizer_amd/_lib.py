@@ -47,6 +47,9 @@ class OmnitokPlGemm(Structure):
         ("q_mul", c_float), ("q_bound", c_float), ("k_bound", c_float), ("v_bound", c_float),
         ("v_bound_dev", c_void_p), ("v_bound_stride", c_int), ("rows_per_clip", c_int64),
         ("M", c_int64), ("N", c_int), ("K", c_int), ("cfg", c_int), ("debug_cycles", c_void_p),
+        ("a_rpg", c_int64), ("a_gstride", c_int64), ("a_goff", c_int64),
+        ("up_C", c_int), ("up_F", c_int), ("up_H", c_int), ("up_W", c_int), ("up_f0", c_int), ("up_t", c_int),
+        ("up_pt", c_int), ("up_p", c_int),
     ]
 
 
@@ -143,6 +146,7 @@ _PROTOS = {
     "omnitok_attn_spatial_h2_planes": [P, P, P, P, I64, P, P, c_int, c_int, c_int, c_float, c_float, c_float, P, c_int,
                                        c_int, P, c_int, c_int, P],
     "omnitok_attn_window_planes": [P, I64, P, P, I64, P, c_float, c_int, c_int, c_int, c_int, P],
+    "omnitok_layernorm_planes": [P, I64, c_int, c_float, P, P, c_float, P, I64, P],
     "omnitok_attn_window_h2": [P, P, P, P, P, I64, P, c_float, c_float, c_float, c_int, c_int, c_int, c_int, P],
     "omnitok_stats_pack_windows": [P, I64, c_int, c_float, c_int, P, I64, P, P, c_int, c_int, c_int, P],
     "omnitok_attn_temporal_planes": [P, I64, P, P, I64, P, I64, P, P, c_float, P, c_int, I64, I64, c_int, c_int, P, P,

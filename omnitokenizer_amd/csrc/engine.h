@@ -176,8 +176,9 @@ int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int6
             const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
             int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0,
             const VPack *vpk = nullptr, bool *vpacked = nullptr);
+// out_planes: the final LayerNorm goes to Y as hi|lo operand planes (static scale of tw.out_bound) instead of fp32 rows in X
 int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
-                    hipStream_t stream, bool transpose_out = false);
+                    hipStream_t stream, bool transpose_out = false, bool out_planes = false);
 int reset_bounds(omnitok_engine *e, int B, hipStream_t stream);
 void workspace_widths(const omnitok_engine *e, int64_t (&wd)[8]);
 int64_t workspace_bytes_for(const omnitok_engine *e, int64_t L);

@@ -331,7 +331,39 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
         std::swap(e->X, e->X2);
     }
     if (int rc = run_transformer(e, e->dec_t, B, T2, &ghc, &gwc, false, stream, true)) return rc;
-    if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream)) return rc;
+    // Plane data flow of to_pixels: the last Transformer's norm_out writes LayerNorm(x) as operand planes (Y) instead of fp32
+    // rows, and the two pixel GEMMs scatter their fp32 results straight into the video (un-patchify epilogue): no token
+    // tensor after norm_out, no [L, K] pixel rows, no un-patchify pass.
+    bool plain_blocks = true;  // no pooling / Up blocks in the last Transformer: its grid is the token grid
+    for (const char *q = c.dec_block; *q; ++q) plain_blocks = plain_blocks && (*q == 't' || *q == 'w');
+    const bool px_pl = plain_blocks && gemm_pl_of(e) && gemm_mode_of(e) == 2 && D == 512 && !c.patch_embed_cnn && S % 256 == 0 && p == 8 && gw2 % 32 == 0 &&
+                       e->plw.count(e->px_w[0]) && (T2 == 1 || e->plw.count(e->px_w[1])) && e->dec_s.out_bound > 0.0f &&
+                       e->dec_s.out_bound < 1e30f;
+    if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream, false, px_pl)) return rc;
+    if (px_pl) {
+        for (int i = 0; i < 2; ++i) {
+            if (i == 1 && T2 == 1) break;
+            const int tt = i ? T2 - 1 : 1, Kp = i ? K1 : K0;
+            const H2W &wp = e->plw[e->px_w[i]];
+            omnitok_pl_gemm g{};
+            g.a = e->Y.p;
+            g.a_scale_const = omnitok_pl_unscale(e->dec_s.out_bound);
+            g.a_rpg = (int64_t)tt * S;
+            g.a_gstride = (int64_t)T2 * S;
+            g.a_goff = i ? S : 0;
+            g.w = wp.pl;
+            g.w_scale = wp.sc;
+            g.bias = e->px_b[i];
+            g.c = pixels_out;
+            g.epilogue = 5;
+            g.up_C = C; g.up_F = F; g.up_H = H; g.up_W = W_; g.up_f0 = i; g.up_t = tt; g.up_pt = i ? pt : 1; g.up_p = p;
+            g.M = (int64_t)B * tt * S;
+            g.N = Kp;
+            g.K = D;
+            OT_RUN("gemm_pixels", 2.0 * g.M * (double)Kp * D, omnitok_gemm_pl(&g, stream));
+        }
+        return OMNITOK_OK;
+    }
     // ---- to_pixels (reference omnitokenizer.py:1006-1033, 1089-1096) -------------------------
     OT_RUN("gemm_pixels", 2.0 * B * S * (double)K0 * D,
            eg_gemm(e, e->X.p, D, e->px_w[0], D, e->px_b[0], nullptr, 0, e->HD.p, K0, (int64_t)B * S, K0, D,

@@ -466,6 +466,10 @@ int build_patch_operands(omnitok_engine *e, hipStream_t stream) {
             if (int rc = pack_h2(e, e->pe_w[i], ld, D, ld, stream)) return rc;
             const int Kp = C * g.p_dec * g.p_dec * (i ? g.pt_dec : 1);
             if (int rc = pack_h2(e, e->px_w[i], D, Kp, D, stream)) return rc;
+            // plane data flow (gemm_pl.h): the pixel GEMM's operand comes from the norm_out pass as planes, the un-patchify
+            // store is its epilogue
+            if (Kp % 32 == 0)
+                if (int rc = pack_pl(e, e->px_w[i], D, Kp, D, stream)) return rc;
         }
     }
     return OMNITOK_OK;

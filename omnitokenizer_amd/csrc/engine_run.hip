@@ -96,7 +96,7 @@ static int eg_gemm_pl(omnitok_engine *e, omnitok_pl_gemm g, const float *w, hipS
 // transpose_out: the final LayerNorm stores its rows in the OTHER stage's token order ('(b t)(h w)' <-> '(b h w) t'),
 // i.e. the rearrange that follows every Transformer on the path is fused into the norm_out store.
 int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
-                           hipStream_t stream, bool transpose_out) {
+                           hipStream_t stream, bool transpose_out, bool out_planes) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim, heads = c.heads;
     int gh = *ghp, gw = *gwp;
@@ -545,6 +545,13 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                    eg_gemm(e, e->HD.p, e->inner_pad, ly.ff.w2p, e->inner_pad, nullptr, e->X.p, D, e->X.p, D, L, D,
                            e->inner_pad, OMNITOK_GEMM_RESIDUAL, 0, 0, 0, stream));
         }
+    }
+    if (out_planes) {  // the consumer is a plane GEMM (to_pixels): LayerNorm + operand split in one pass, rows stay in place
+        OT_RUN("layernorm", 2.0 * L * D * 4.0,
+               omnitok_layernorm_planes(e->X.p, L, D, 1e-5f, tw.og, tw.ob, tw.out_bound, e->Y.p, (L + 255) / 256 * 256, stream));
+        *ghp = gh;
+        *gwp = gw;
+        return OMNITOK_OK;
     }
     if (transpose_out && T > 1)  // rows (b, t, s) -> (b, s, t) after a spatial stage, (b, s, t) -> (b, t, s) after a temporal one
         OT_RUN("layernorm", 2.0 * L * D * 4.0,

@@ -34,6 +34,7 @@ enum PlEpi {
     PL_ROWLN = 2,       // full-row tiles (TN == N): fp32 output (+ bias, + residual) AND LayerNorm(out) as planes
     PL_VPACK = 3,       // SWAP only: V columns into the attention kernel's packed fp16 planes (attn_h2.hip)
     PL_QKPACK = 4,      // Q | K columns (one head per wave): RoPE + l2norm + scales -> the attention kernel's packed planes
+    PL_UNPATCH = 5,     // fp32 (+ bias) scattered as pixels: the un-patchify Rearrange of to_pixels fused into the store
 };
 
 struct PlParams {
@@ -85,6 +86,9 @@ struct PlParams {
     int64_t M;
     int N, K;
     int nbm, nbn, ntiles, gn;
+    // operand row map (a_rpg == 0: identity): the frame groups of the token tensor
+    int64_t a_rpg, a_gstride, a_goff;
+    int up_C, up_F, up_H, up_W, up_f0, up_t, up_pt, up_p;  // PL_UNPATCH
     long long *cycles;                // measurement: s_memtime span of workgroup 0 (null = off)
     int stagger;                      // start delay step in ~1 us units ("pl_stagger"); workgroup phase = (id / 8) % 8
 };
@@ -196,7 +200,9 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
         int bn;
         tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
         const unsigned char *ab = (p.a_split_n > 0 && bn * TN >= p.a_split_n) ? p.a2 : p.a;
-        d_a = ab + bm * (TM / 64) * (int64_t)kblocks * 8192;
+        int64_t arow = bm * TM;
+        if (p.a_rpg > 0) arow = (arow / p.a_rpg) * p.a_gstride + p.a_goff + arow % p.a_rpg;  // whole tiles: a_rpg % TM == 0
+        d_a = ab + (arow >> 6) * (int64_t)kblocks * 8192;
         d_w = p.w + (int64_t)bn * (TN / 64) * (int64_t)kblocks * 8192;
         d_tile = ti;
         d_k = 0;
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         frs[mi] = sp[p.fold_stats ? 1 : 0];
                     }
                 }
-                if constexpr (EPI == PL_F32) {
+                if constexpr (EPI == PL_F32 || EPI == PL_UNPATCH) {
                     float *cb = p.c;
                     int64_t ldc = p.ldc;
                     int ncol0 = n_w0;
@@ -465,6 +471,30 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         u32x4 res[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(0, i, (int)p.ldr), 0);
+                        // PL_UNPATCH: wave-uniform bases.  A 32-row block = 32 consecutive patches (b, t, gy, gx0 ..) of one patch row
+                        // (gw % 32 == 0), a 32-column block = 4 pixel rows (p1) x 8 pixels (p2) of one (channel, frame) plane of the
+                        // patch (p == 8): only the block bases need divisions, and they are uniform
+                        int64_t up_rowb[MI], up_colb[NI];
+                        if constexpr (EPI == PL_UNPATCH) {
+                            const int gw = p.up_W >> 3, gh = p.up_H >> 3;
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) {
+                                int64_t rr = m_w0 + mi * 32;
+                                rr = rr < p.M ? rr : 0;
+                                const int gx0 = (int)(rr % gw); rr /= gw;
+                                const int gy = (int)(rr % gh); rr /= gh;
+                                const int tt = (int)(rr % p.up_t);
+                                const int64_t b = rr / p.up_t;
+                                up_rowb[mi] = ((b * p.up_C * p.up_F + p.up_f0 + tt * p.up_pt) * p.up_H + gy * 8) * (int64_t)p.up_W + gx0 * 8;
+                            }
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) {
+                                const int n0 = n_w0 + ni * 32;            // = (ch pt + j) 64 + p1_0 8
+                                const int cj = n0 >> 6, p1_0 = (n0 >> 3) & 7;
+                                const int j = cj % p.up_pt, ch = cj / p.up_pt;
+                                up_colb[ni] = (((int64_t)ch * p.up_F + j) * p.up_H + p1_0) * (int64_t)p.up_W;
+                            }
+                        }
                         // column constants of the row-major side: the lane's 4 columns of each 32-column block, once per tile
                         f32x4 swr[NI], fbr[NI], fgr[NI];
 #pragma unroll
@@ -517,6 +547,14 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                         res[i] = __builtin_amdgcn_raw_buffer_load_b128(r_rs, vo_r, so(ni * MI + mi + 1, i, (int)p.ldr), 0);
                                     if constexpr (DBG & 16) {
                                         if (v[0] == 12345.678f) p.c[lane] = v[1];  // measurement build: no stores
+                                    } else if constexpr (EPI == PL_UNPATCH) {
+                                        // element (m, n) of the token x feature result is pixel  up_rowb[mi] + (i 8 + rrow) 8  +  up_colb[ni]
+                                        // + (rch / 2) W + (rch % 2) 4: the lane's 4 columns are 16 contiguous bytes, the 8 lanes of a row cover 4
+                                        // pixel rows of the patch and neighbouring rows (gx, gx + 1) continue them (256-byte runs)
+                                        const int64_t m = m_w0 + mi * 32 + i * 8 + rrow;
+                                        if (m < p.M && n_w0 + ni * 32 < p.N)
+                                            *reinterpret_cast<f32x4 *>(p.c + up_rowb[mi] + up_colb[ni] + (i * 8 + rrow) * 8 + (rch >> 1) * p.up_W +
+                                                                       (rch & 1) * 4) = v;
                                     } else
                                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), c_rs, vo_c,
                                                                                so(ni * MI + mi, i, (int)ldc), 0);

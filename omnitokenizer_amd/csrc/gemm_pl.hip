@@ -92,7 +92,7 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     int n_cu = 0;
     if (int rc = current_device_cus(&n_cu)) return rc;
     constexpr int LDS = C::LDS + (EPI == PL_ROWLN ? 2 * C::WN * C::TM * 4 : 0) +
-                        ((EPI == PL_ROWLN || EPI == PL_F32) && C::EPI_T ? C::NW * 4096 : 0);
+                        ((EPI == PL_ROWLN || EPI == PL_F32 || EPI == PL_UNPATCH) && C::EPI_T ? C::NW * 4096 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), LDS)) return rc;
     const int64_t nbm = (p.M + C::TM - 1) / C::TM;
@@ -122,6 +122,8 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
     if constexpr (EPI == PL_VPACK) {
         return launch_pl_cfg<EPI, true, PlCfg<4, 2, 4>>(p, stream);
     } else if constexpr (EPI == PL_QKPACK) {
+        return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+    } else if constexpr (EPI == PL_UNPATCH) {
         return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
@@ -222,6 +224,13 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
         p.fold_u = g->fold_u;
         p.fold_cols = g->fold_cols;
     }
+    if (g->a_rpg > 0) {
+        OT_CHECK_ARG(g->a_rpg % 256 == 0 && g->a_goff % 256 == 0 && g->a_gstride % 64 == 0 && g->M % g->a_rpg == 0 && !g->a2,
+                     "gemm_pl: operand row map needs a_rpg, a_goff %% 256 == 0, a_gstride %% 64 == 0 and whole groups");
+        p.a_rpg = g->a_rpg;
+        p.a_gstride = g->a_gstride;
+        p.a_goff = g->a_goff;
+    }
     const int cfg = g->cfg > 0 ? g->cfg : (g_pl_cfg > 0 ? g_pl_cfg : 1);
     OT_CHECK_ARG(p.a_split_n % 256 == 0 && p.c_split_n % 256 == 0, "gemm_pl: split columns must be multiples of 256");
     switch (g->epilogue) {
@@ -267,6 +276,16 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             p.sq = h2_scale_of_bound(g->q_bound);
             p.sk = h2_scale_of_bound(g->k_bound);
             return launch_pl<PL_QKPACK>(p, cfg, stream);
+        case PL_UNPATCH:
+            OT_CHECK_ARG(g->c && aligned16(g->c) && g->up_p == 8 && g->up_pt > 0 && g->up_t > 0 && g->up_C > 0 &&
+                             g->up_H % g->up_p == 0 && g->up_W % (32 * g->up_p) == 0 &&
+                             g->N == g->up_C * g->up_pt * g->up_p * g->up_p && g->up_f0 >= 0 &&
+                             g->up_f0 + g->up_t * g->up_pt <= g->up_F &&
+                             g->M % ((int64_t)g->up_t * (g->up_H / g->up_p) * (g->up_W / g->up_p)) == 0 && !g->residual && !g->c2,
+                         "gemm_pl: the un-patchify epilogue needs p == 8, W %% 256 == 0, N == C pt p p and whole videos of t x (H / p) x (W / p) patches");
+            p.up_C = g->up_C; p.up_F = g->up_F; p.up_H = g->up_H; p.up_W = g->up_W; p.up_f0 = g->up_f0; p.up_t = g->up_t;
+            p.up_pt = g->up_pt; p.up_p = g->up_p;
+            return launch_pl<PL_UNPATCH>(p, 1, stream);
         case PL_ROWLN:
             OT_CHECK_ARG(g->N == 512 && g->c && g->ldc % 4 == 0 && aligned16(g->c) && g->out_planes && g->out_planes_k == g->N &&
                              g->out_bound > 0.0f && g->ln_gamma && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))) &&

@@ -259,12 +259,35 @@ constexpr int SP_CSTRIDE = 16 * 16 + 16;  // LDS stride of a 16-row chunk column
 // ws x ws window), the order reference attention.py:170-188 window_partition produces -- while x is read in token order
 // (frame, y, x): the operand of the window-attention q|k|v GEMM, whose packing epilogues then see 64 consecutive rows per
 // window and need no row map of their own.
-template <int H>
-__global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restrict__ x, int64_t rows, float eps, int center,
-                                                            unsigned char *__restrict__ planes, float *__restrict__ a_scale,
-                                                            float *__restrict__ stats, int win_gh, int win_gw, int win_ws) {
+// MODE 2: the planes hold LayerNorm(x) = (x - mean) rstd gamma (+ beta) scaled by the power of two of the static bound ln_bound
+// (a_scale is not written): the operand of a plane GEMM that follows a standalone LayerNorm (to_pixels after norm_out).
+// The mode is a template parameter: the plain pass (MODE 0) is the hottest HBM-bound kernel of the step and keeps its
+// branch-free load batch.
+struct SpArgs {
+    const float *x;
+    int64_t rows;
+    float eps;
+    int center;
+    unsigned char *planes;
+    float *a_scale, *stats;
+    int win_gh, win_gw, win_ws;
+    const float *ln_g, *ln_b;
+    float ln_bound;
+};
+enum { SP_PLAIN = 0, SP_WINDOWS = 1, SP_LAYERNORM = 2 };
+
+template <int H, int MODE>
+__global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     constexpr int K = 256 * H;
+    const float *__restrict__ x = a.x;
+    const int64_t rows = a.rows;
+    const float eps = a.eps;
+    const int center = a.center;
+    unsigned char *__restrict__ planes = a.planes;
+    float *__restrict__ a_scale = a.a_scale;
+    float *__restrict__ stats = a.stats;
+    const int win_gh = a.win_gh, win_gw = a.win_gw, win_ws = a.win_ws;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
     unsigned char *lds = sp_lds + wave * (2 * 32 * SP_CSTRIDE);  // [plane][32 chunks][16 rows][16 B] (padded)
@@ -273,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restr
     for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + r;
         int64_t src = row < rows ? row : rows - 1;
-        if (win_gw > 0) {
+        if constexpr (MODE == SP_WINDOWS) {
             const int S = win_gh * win_gw, w2 = win_ws * win_ws, nwx = win_gw / win_ws;
             const int64_t f = src / S;
             const int rr = (int)(src - f * S), win = rr / w2, pos = rr - win * w2;
@@ -285,6 +308,14 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restr
         for (int h = 0; h < H; ++h) {
             v[r][h] = __builtin_nontemporal_load(xr + lane + 64 * h);
             if (row >= rows) v[r][h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // pad rows of the plane block are zero
+        }
+    }
+    f32x4 lg[H], lb[H];
+    if constexpr (MODE == SP_LAYERNORM) {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            lg[h] = reinterpret_cast<const f32x4 *>(a.ln_g)[lane + 64 * h];
+            lb[h] = a.ln_b ? reinterpret_cast<const f32x4 *>(a.ln_b)[lane + 64 * h] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
     float scl[16];
@@ -304,11 +335,24 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(const float *__restr
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[r][h][0]), fabsf(v[r][h][1])), fmaxf(fabsf(v[r][h][2]), fabsf(v[r][h][3]))));
         }
         q = wave_allsum(q);
+        const int64_t row = row0 + r;
+        if constexpr (MODE == SP_LAYERNORM) {  // LayerNorm(x) with the arithmetic of layernorm_kernel, one static scale for every row
+            const float rstd = 1.0f / sqrtf(q / (float)K + eps);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (center ? v[r][h][e] : v[r][h][e] - mean) * rstd * lg[h][e];
+                if (a.ln_b) o += lb[h];
+                v[r][h] = row < rows ? o : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+            scl[r] = h2_scale_of_bound(a.ln_bound);
+            continue;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         const float sc = h2_scale_of_bound(mx);
         scl[r] = sc;
-        const int64_t row = row0 + r;
         if (lane == 0 && row < rows) {
             if (stats) *reinterpret_cast<float2 *>(stats + 2 * row) = make_float2(mean, 1.0f / sqrtf(q / (float)K + eps));
             a_scale[row] = 1.0f / sc;
@@ -429,23 +473,16 @@ extern "C" int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim,
     return stats_pack_impl(x, rows, dim, eps, center, planes, m_pad, a_scale, stats, nullptr, 0, gh, gw, ws, stream_);
 }
 
-static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
-                           float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, int win_gh, int win_gw, int win_ws,
-                           omnitok_stream_t stream_) {
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    OT_CHECK_ARG(x && planes && a_scale, "stats_pack: null pointer");
+template <int MODE>
+static int stats_pack_launch(SpArgs a, int dim, int64_t m_pad, hipStream_t stream) {
     OT_CHECK_ARG(dim > 0 && dim % 256 == 0 && dim <= 1024, "stats_pack: dim=%d (multiples of 256 up to 1024)", dim);
-    OT_CHECK_ARG(m_pad >= rows && m_pad % 64 == 0 && aligned16(x) && aligned16(planes) &&
-                     (!stats || (reinterpret_cast<uintptr_t>(stats) & 7) == 0) && (!bounds || stats),
-                 "stats_pack: m_pad %% 64, alignment, bounds need stats");
     if (m_pad == 0) return OMNITOK_OK;
     const int lds = 4 * 2 * 32 * SP_CSTRIDE;
     const dim3 grid((unsigned)(m_pad / 64));
 #define OT_SP(Hh)                                                                                                      \
     do {                                                                                                               \
-        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh>), lds)) return rc;       \
-        hipLaunchKernelGGL(stats_pack_kernel<Hh>, grid, dim3(256), lds, stream, x, rows, eps, center,                  \
-                           static_cast<unsigned char *>(planes), a_scale, stats, win_gh, win_gw, win_ws);              \
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh, MODE>), lds)) return rc; \
+        hipLaunchKernelGGL((stats_pack_kernel<Hh, MODE>), grid, dim3(256), lds, stream, a);                            \
     } while (0)
     switch (dim / 256) {
         case 1: OT_SP(1); break;
@@ -455,6 +492,22 @@ static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int
     }
 #undef OT_SP
     OT_LAUNCH_CHECK("stats_pack");
+    return OMNITOK_OK;
+}
+
+static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
+                           float *a_scale, float *stats, float *bounds, int64_t rows_per_clip, int win_gh, int win_gw, int win_ws,
+                           omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && planes && a_scale, "stats_pack: null pointer");
+    OT_CHECK_ARG(m_pad >= rows && m_pad % 64 == 0 && aligned16(x) && aligned16(planes) &&
+                     (!stats || (reinterpret_cast<uintptr_t>(stats) & 7) == 0) && (!bounds || stats),
+                 "stats_pack: m_pad %% 64, alignment, bounds need stats");
+    SpArgs a{};
+    a.x = x; a.rows = rows; a.eps = eps; a.center = center; a.planes = static_cast<unsigned char *>(planes);
+    a.a_scale = a_scale; a.stats = stats; a.win_gh = win_gh; a.win_gw = win_gw; a.win_ws = win_ws;
+    if (int rc = (win_gw > 0 ? stats_pack_launch<SP_WINDOWS>(a, dim, m_pad, stream) : stats_pack_launch<SP_PLAIN>(a, dim, m_pad, stream)))
+        return rc;
     if (bounds && rows > 0) {
         const int64_t rpc = rows_per_clip > 0 ? rows_per_clip : rows;
         const int64_t n_clips = (rows + rpc - 1) / rpc;
@@ -464,6 +517,18 @@ static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int
         OT_LAUNCH_CHECK("range_from_stats");
     }
     return OMNITOK_OK;
+}
+
+extern "C" int omnitok_layernorm_planes(const float *x, int64_t rows, int dim, float eps, const float *gamma, const float *beta,
+                                        float bound, void *planes, int64_t m_pad, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && gamma && planes && bound > 0.0f, "layernorm_planes: null pointer / bound");
+    OT_CHECK_ARG(m_pad >= rows && m_pad % 64 == 0 && aligned16(x) && aligned16(planes) && aligned16(gamma) && (!beta || aligned16(beta)),
+                 "layernorm_planes: m_pad %% 64, alignment");
+    SpArgs a{};
+    a.x = x; a.rows = rows; a.eps = eps; a.planes = static_cast<unsigned char *>(planes);
+    a.ln_g = gamma; a.ln_b = beta; a.ln_bound = bound;
+    return stats_pack_launch<SP_LAYERNORM>(a, dim, m_pad, stream);
 }
 
 extern "C" int omnitok_weight_range(const float *w, int64_t ldw, int rows, int K, float *out2,
