@@ -46,6 +46,9 @@ struct LayerT {  // 't' block (+ FF)
     float vnorm = 0.0f;     // max_j ||Wv_j||_2: |attention output| <= max_rows ||x||_2 * vnorm
     float q_amax = 0.0f, k_amax = 0.0f;  // max |q_scale|, max |k_scale|: ranges of the l2-normalised q / k (attn_h2.hip)
     std::string bias_prefix;  // spatial_rel_pos_bias prefix ("" if none)
+    // temporal attention over ONE token (images): softmax over a single key is exactly 1, the block is x + (x Wv^T) Wo^T.
+    // wvo = Wo . Wv (fp64 accumulation, rounded once) lets the plane data flow run it as ONE GEMM from the planes of x
+    const float *wvo = nullptr;
 };
 struct LayerW {  // 'w' block
     const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;

@@ -250,6 +250,17 @@ static int fold_ln_weight(omnitok_engine *e, const float *w, const float *gamma,
     return OMNITOK_OK;
 }
 
+// wvo[o][i] = sum_m wo[o][m] wv[m][i]  (both [D, D] row-major), fp64 accumulation.  One thread per output element.
+__global__ __launch_bounds__(256) void compose_vo_kernel(const float *__restrict__ wo, const float *__restrict__ wv, int D,
+                                                         float *__restrict__ wvo) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= D * D) return;
+    const int o = idx / D, i = idx % D;
+    double acc = 0.0;
+    for (int m = 0; m < D; ++m) acc += (double)wo[(int64_t)o * D + m] * (double)wv[(int64_t)m * D + i];
+    wvo[idx] = (float)acc;
+}
+
 int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &prefix, const std::string &block,
                              bool spatial, hipStream_t stream) {
     const omnitok_config &c = e->cfg;
@@ -294,6 +305,15 @@ int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &pr
             if (int rc = ln_range(e, L.t.ng, L.t.nb, c.dim, &L.t.ln_bound, nullptr, stream)) return rc;
             if (int rc = weight_range(e, L.t.wkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &L.t.vnorm, nullptr, stream))
                 return rc;
+            if (!spatial && c.dim == 512) {  // images run the temporal blocks on one token: Wo . Wv as one packed weight
+                float *wvo;
+                if (int rc = alloc_f(e, &wvo, (int64_t)c.dim * c.dim)) return rc;
+                hipLaunchKernelGGL(compose_vo_kernel, dim3((c.dim * c.dim + 255) / 256), dim3(256), 0, stream, L.t.wo,
+                                   L.t.wkv + (int64_t)c.dim * c.dim, c.dim, wvo);
+                OT_LAUNCH_CHECK("compose_vo");
+                if (int rc = pack_pl(e, wvo, c.dim, c.dim, c.dim, stream)) return rc;
+                L.t.wvo = wvo;
+            }
             L.t.q_scale = W(e, p + ".1.q_scale");
             L.t.k_scale = W(e, p + ".1.k_scale");
             if (int rc = weight_range(e, L.t.q_scale, c.dim_head, 1, c.dim_head, nullptr, &L.t.q_amax, stream)) return rc;

@@ -218,6 +218,17 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                 // (causal or not, with or without ALiBi), so the attention output is V bit for bit:
                 // only the V half of to_kv is needed (rows [D, 2D) of the weight); LN, to_q, the K
                 // half and the attention kernel drop out.  Identical results to the general path.
+                if (pl && ly.t.wvo && e->plw.count(ly.t.wvo)) {
+                    // plane data flow: x as planes (one power-of-two scale per row) -> ONE GEMM on Wo . Wv with the residual
+                    // add and the FeedForward's LayerNorm planes in its epilogue.  (x Wv^T) Wo^T = x (Wo Wv)^T in exact
+                    // arithmetic; the composed weight is rounded once from fp64, the two-step form rounds V to fp32 in
+                    // between -- both inside the path's fp32 noise (golden image fixtures, tests/test_gpu_e2e.py).
+                    const int64_t Lp = (L + 255) / 256 * 256;
+                    OT_RUN("stats_pack", 2.0 * L * D * 4.0,
+                           omnitok_stats_pack(e->X.p, L, D, 1e-5f, 0, e->X2.p, Lp, e->Z.p, nullptr, nullptr, 0, stream));
+                    if (int rc = gemm_out_pl(ly, e->X2.p, e->Z.p, 1.0f, ly.t.wvo, nullptr)) return rc;
+                    goto feed_forward;
+                }
                 if (bs && gemm_mode_of(e) == 2)  // only the ranges are needed here
                     OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, bs, rpc, stream));
                 OT_RUN("gemm_qkv", gemm_f * D,
