@@ -145,7 +145,11 @@ def run(a):
         attn_split = a.gemm_mode == 2 and int(opts.get("attn_mode", 1)) == 1
         roofs = {n: gemm_roof for n in mfma if n.startswith("gemm_")}
         roofs["attn_spatial"] = PEAK_F16_TFLOPS / 3 if attn_split else PEAK_F32_TFLOPS
-        roofs["attn_window"] = roofs["vq_argmin"] = PEAK_F32_TFLOPS
+        # window attention runs on the split-operand pipe too since r04 ("attn_window_mode" 1); it is priced against HBM as well
+        # below (16 flop/B -- its roof is bandwidth: packed q, k, v in + planes out = 4 L D 4 bytes per launch)
+        win_split = a.gemm_mode == 2 and int(opts.get("attn_window_mode", 1)) == 1 and int(opts.get("gemm_pl", 1)) == 1
+        roofs["attn_window"] = PEAK_F16_TFLOPS / 3 if win_split else PEAK_F32_TFLOPS
+        roofs["vq_argmin"] = PEAK_F32_TFLOPS
         for name, k in kernels.items():
             if k["ms_per_step"] > 0:
                 if name in mfma:
@@ -223,6 +227,10 @@ def run(a):
                 tr = e["read_bytes"] + e["write_bytes"] if "read_bytes" in e else None
                 k["traffic_bytes_per_launch"] = tr
                 k["traffic_gbs"] = round(tr * k["launches_per_step"] / (k["ms_per_step"] * 1e-3) / 1e9, 1) if tr else None
+        if "attn_window" in kernels and kernels["attn_window"]["ms_per_step"] > 0:
+            kw = kernels["attn_window"]
+            kw["algorithmic_gbs"] = round(kw["launches_per_step"] * 4.0 * Ltok * 512 * 4 / (kw["ms_per_step"] * 1e-3) / 1e9, 1)
+            kw["frac_hbm_peak"] = round(kw["algorithmic_gbs"] / PEAK_HBM_GBS, 4)
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
             vq_bytes = Ltok * 40 + cfg.n_codes * 32
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 2)

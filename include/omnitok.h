@@ -233,6 +233,9 @@ typedef struct omnitok_pl_gemm {
      * 'b t h w (c pt p1 p2) -> b c (t pt) (h p1) (w p2)' of omnitokenizer.py:1006-1017 fused into the store).
      * up_p == 8 and (up_W / up_p) % 32 == 0: a 32-row block of the tile is 32 consecutive patches of one patch row     */
     int up_C, up_F, up_H, up_W, up_f0, up_t, up_pt, up_p;
+    /* 0, or the number of leading k that are not zero padding in BOTH operands (planes and weight are laid out for K): the
+     * K loop then stops after ceil(k_valid / 16) steps -- FF-out's K = 1408 holds 1365 hidden channels                */
+    int k_valid;
 } omnitok_pl_gemm;
 int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad);
 /* the factor that undoes the power-of-two scale derived from a static bound (a_scale_const of the consumer) */

@@ -49,7 +49,7 @@ class OmnitokPlGemm(Structure):
         ("M", c_int64), ("N", c_int), ("K", c_int), ("cfg", c_int), ("debug_cycles", c_void_p),
         ("a_rpg", c_int64), ("a_gstride", c_int64), ("a_goff", c_int64),
         ("up_C", c_int), ("up_F", c_int), ("up_H", c_int), ("up_W", c_int), ("up_f0", c_int), ("up_t", c_int),
-        ("up_pt", c_int), ("up_p", c_int),
+        ("up_pt", c_int), ("up_p", c_int), ("k_valid", c_int),
     ]
 
 

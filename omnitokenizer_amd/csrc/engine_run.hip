@@ -536,6 +536,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
             h.M = L;
             h.N = D;
             h.K = e->inner_pad;
+            h.k_valid = c.ff_inner;  // the hidden's pad columns are exactly 0 (GEGLU epilogue) and so are the weight's
             OT_RUN("gemm_ff_out", gemm_f * c.ff_inner, eg_gemm_pl(e, h, ly.ff.w2p, stream));
         } else if (fused && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU)) {
             OT_RUN("row_stats", L * D * 4.0, omnitok_row_stats(e->X.p, L, D, 1e-5f, e->ST.p, nullptr, 0, stream));

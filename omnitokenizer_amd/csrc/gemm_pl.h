@@ -85,6 +85,7 @@ struct PlParams {
     int64_t v_rpc;
     int64_t M;
     int N, K;
+    int nk;                           // K steps of 16 actually run: ceil(k_valid / 16) <= K / 16 (the rest of K is zero padding)
     int nbm, nbn, ntiles, gn;
     // operand row map (a_rpg == 0: identity): the frame groups of the token tensor
     int64_t a_rpg, a_gstride, a_goff;
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     const int pair = (C::WPS == 2) ? (wave >> 2) : 0;  // the two waves of a SIMD inside one workgroup: staggered DMA issue
     if ((int)blockIdx.x >= p.ntiles) return;
     const int my_tiles = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int nk = p.K >> 4, kblocks = p.K >> 5;
+    const int nk = p.nk, kblocks = p.K >> 5;
     const int total = my_tiles * nk;
     long long t_start = 0;
     if (p.cycles && blockIdx.x == 0 && tid == 0) t_start = __builtin_amdgcn_s_memtime();

@@ -213,6 +213,8 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
     p.M = g->M;
     p.N = g->N;
     p.K = g->K;
+    OT_CHECK_ARG(g->k_valid >= 0 && g->k_valid <= g->K, "gemm_pl: k_valid=%d outside [0, K]", g->k_valid);
+    p.nk = g->k_valid > 0 ? (g->k_valid + 15) / 16 : g->K / 16;
     p.cycles = g->debug_cycles;
     if (g->fold_stats) {
         OT_CHECK_ARG(g->fold_cols >= 0 && g->fold_cols % 64 == 0 && (g->fold_cols >= g->N || g->fold_u) &&

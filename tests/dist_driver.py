@@ -21,13 +21,22 @@ def main():
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=0)
     ap.add_argument("--clips", type=int, default=2, help="clips per rank")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="this rank raises before the timed region (error-report test)")
     a = ap.parse_args()
 
     from omnitokenizer_amd import launch
     rc = launch.maybe_respawn(os.path.abspath(__file__), sys.argv[1:], a.gpus)
     if rc is not None:
         sys.exit(rc)
+    with launch.rank_errors():
+        run(a)
+
+
+def run(a):
+    from omnitokenizer_amd import launch
     info = launch.init_ranks(a.gpus, backend="gloo", set_cuda_device=False)
+    if info.rank == a.fail_rank:
+        raise RuntimeError("injected failure on this rank (tests/test_dist_gloo.py)")
 
     from oracle import omnitok_oracle as orc
     from tests.helpers import GoldenCase
@@ -43,6 +52,7 @@ def main():
     if info.rank == 0:
         print(json.dumps({"n_gpus": info.world, "world_seen": res.world_seen, "ids_crc32": res.ids_crc,
                           "n_total": res.n_total, "allgather_ms": res.allgather_ms, "seconds": res.seconds,
+                          "per_rank_ms": res.per_rank_ms, "gather_impl": res.gather_impl,
                           "ids_local_shape": list(res.ids_local.shape), "rec_local_shape": list(res.rec_local.shape),
                           "step_trace": res.extra.get("step_trace")}),
               flush=True)

@@ -132,6 +132,8 @@ def test_self_spawning_launcher_gloo():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["world_seen"] == 2 and out["n_total"] == 4
     assert out["allgather_ms"] is not None and out["ids_local_shape"][0] == 2
+    # every rank's own step time is on the result (a straggler would show), and the gather is the persistent object of the step
+    assert len(out["per_rank_ms"]) == 2 and all(v > 0 for v in out["per_rank_ms"]) and out["gather_impl"] == "IdGather"
     # the id all-gather is off the critical path: issued after encode, waited for only AFTER the local decode
     assert out["step_trace"] == ["encode", "gather_start", "decode", "gather_wait"]
     # single-rank run of the same driver: no respawn, no collective
@@ -140,6 +142,19 @@ def test_self_spawning_launcher_gloo():
     assert r1.returncode == 0, r1.stderr[-2000:]
     out1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     assert out1["n_gpus"] == 1 and out1["allgather_ms"] is None
+
+
+def test_failing_rank_names_itself():
+    """A rank that raises prints `rank r of N: <error>` before the launcher tears the job down (torchrun alone reports only
+    'exitcode 1'), and the job exits non-zero instead of hanging in the other rank's collective."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "dist_driver.py"), "--gpus", "2", "--fail-rank", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode != 0
+    assert "rank 1 of 2: RuntimeError: injected failure on this rank" in r.stderr, r.stderr[-2000:]
 
 
 def test_launcher_rejects_wrong_world(monkeypatch):
