@@ -811,8 +811,9 @@ __global__ __launch_bounds__(256, MINB) void attn_spatial_h2x_kernel(AttnH2Param
 //     block and query block, taken ~85 % of the time before, become rare;
 //   * the lo plane of P comes from v_fma_mix_f32 (hi as fp16 operand: lo = p - hi in one instruction instead of a
 //     conversion and a subtraction): 4 instead of 6 instructions per pair of probabilities.
-template <bool HAS_BIAS, bool ILV, bool OPT = false>
-__global__ __launch_bounds__(256, 2) void attn_spatial_h2w_kernel(AttnH2Params p) {
+// NWAVE = 8 (variant 7): 512 queries per workgroup, one workgroup per CU -- half the L2 -> LDS traffic and barriers per flop again.
+template <bool HAS_BIAS, bool ILV, bool OPT = false, int NWAVE = 4>
+__global__ __launch_bounds__(64 * NWAVE, NWAVE == 4 ? 2 : 1) void attn_spatial_h2w_kernel(AttnH2Params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
     constexpr int TILE = 16384;  // K block (8 KiB) | V block (8 KiB) of 32 keys
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -829,7 +830,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2w_kernel(AttnH2Params p
     u32x4 qf[2][2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int qblk_raw = qb * 8 + wave * 2 + i;
+        const int qblk_raw = qb * (2 * NWAVE) + wave * 2 + i;
         active[i] = qblk_raw < nblk;
         const int qblk = active[i] ? qblk_raw : 0;
         q_local[i] = qblk * 32 + r32;
@@ -853,13 +854,14 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_h2w_kernel(AttnH2Params p
 
     const unsigned char *kg = p.kp + unit0 * 8192 + wave * 1024 + lane * 16;
     const unsigned char *vg = p.vp + unit0 * 8192 + wave * 1024 + lane * 16;
-    auto dma = [&](int t, int buf) {
+    auto dma = [&](int t, int buf) {  // 8 pieces of 1 KiB per matrix: piece NWAVE i + wave
         unsigned char *s = smem_h2 + buf * TILE + wave * 1024;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((glob_void_t *)(kg + (int64_t)t * 8192 + i * 4096), (lds_void_t *)(s + i * 4096), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glob_void_t *)(vg + (int64_t)t * 8192 + i * 4096), (lds_void_t *)(s + 8192 + i * 4096), 16, 0,
-                                             0);
+        for (int i = 0; i < 8 / NWAVE; ++i) {
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(kg + (int64_t)t * 8192 + i * (NWAVE * 1024)),
+                                             (lds_void_t *)(s + i * (NWAVE * 1024)), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glob_void_t *)(vg + (int64_t)t * 8192 + i * (NWAVE * 1024)),
+                                             (lds_void_t *)(s + 8192 + i * (NWAVE * 1024)), 16, 0, 0);
         }
     };
 
@@ -1284,7 +1286,11 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<true>), AH_LDS_BYTES)) return rc;
     // the legacy-bias builds of the 64-query kernels spill registers: the bias path (stage-1 / legacy configurations) stays on variant 3
     const int variant = (bias_table && g_attn_h2_variant >= 4) ? 3 : g_attn_h2_variant;
-    if (variant == 6) {
+    if (variant == 7 && N % 512 == 0) {
+        p.nqb = N / 512;
+        dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
+        hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false, true, 8>), gridw, dim3(512), 2 * 16384, stream, p);
+    } else if (variant == 6 || variant == 7) {
         p.nqb = (N + 255) / 256;
         dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
         if (bias_table) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false, true>), gridw, dim3(256), 2 * 16384, stream, p);

@@ -18,7 +18,7 @@ def ops():
     return _ops
 
 
-@pytest.fixture(params=[3, 1, 0, 2, 4, 5, 6], ids=["hoisted_32key", "pipelined_dma", "reg_staged", "hoisted_64key", "wide_interleaved", "wide", "wide_deferred_rescale"])
+@pytest.fixture(params=[6, 3, 1, 0, 2, 4, 5, 7], ids=["wide_deferred_rescale", "hoisted_32key", "pipelined_dma", "reg_staged", "hoisted_64key", "wide_interleaved", "wide", "wide_8waves"])
 def variant(request):
     """every build of the attention kernel ("attn_h2_variant": 1 = software-pipelined + LDS-DMA, 0 = register-staged, 2 / 3 = fragment
     reads hoisted in front of the MFMA chains with 64- / 32-key tiles)."""

@@ -95,7 +95,7 @@ def main():
         ms = timeit(lambda: ops.attn_pack(q, kv[:, :D], kv[:, D:], 1024, 8, qs, qs, cos, sin, v_bound=8.0), a.iters)
         res["attn_pack"] = (ms, 6.0 * L * D * 4 / ms / 1e6, "GB/s")
         packed, bounds = ops.attn_pack(q, kv[:, :D], kv[:, D:], 1024, 8, qs, qs, cos, sin, v_bound=8.0)
-        for var in (1, 3, 5, 6):
+        for var in (1, 3, 5, 6, 7):
             _lib.set_option("attn_h2_variant", var)
             ms = timeit(lambda: ops.attn_spatial_h2(packed, bounds, L // 1024, 1024, 8), a.iters)
             res[f"attn_spatial_h2_v{var}"] = (ms, 4.0 * (L // 1024) * 8 * 1024 * 1024 * 64 / ms / 1e9, "TF")
