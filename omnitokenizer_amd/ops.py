@@ -258,6 +258,46 @@ def stats_pack(x, eps=1e-5, center=False):
     return planes, scales, stats
 
 
+def stats_pack_windows(x, gh, gw, ws=8, eps=1e-5, center=True):
+    """stats_pack with the OUTPUT rows (planes, scales, stats) in window-major order (frame, window, position): the operand of the
+    window-attention q|k|v plane GEMM (reference attention.py:170-188 window_partition).  x [frames * gh * gw, K] in token order."""
+    x = _req(x, "x")
+    M, K = x.shape
+    planes = torch.empty(_pad256(M) * K, device=x.device, dtype=torch.int32)
+    scales = torch.empty(max(M, 1), device=x.device, dtype=torch.float32)
+    stats = torch.empty(max(M, 1), 2, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_stats_pack_windows(_p(x), M, K, eps, int(bool(center)), _p(planes), _pad256(M), _p(scales), _p(stats),
+                                                 gh, gw, ws, _stream()), "stats_pack_windows")
+    return planes, scales, stats
+
+
+def layernorm_planes(x, gamma, beta, bound, eps=1e-5):
+    """LayerNorm(x) [M, K] as hi|lo operand planes scaled by the power of two of `bound` (consumer: a_scale_const = pl_unscale(bound))."""
+    x = _req(x, "x")
+    M, K = x.shape
+    planes = torch.empty(_pad256(M) * K, device=x.device, dtype=torch.int32)
+    check(_lib.load().omnitok_layernorm_planes(_p(x), M, K, eps, _p(_req(gamma, "gamma")), _p(beta), float(bound), _p(planes),
+                                               _pad256(M), _stream()), "layernorm_planes")
+    return planes
+
+
+def attn_window_h2(qp, kp, vp, bias_dense, q_bound, k_bound, v_bound, Bn, gh, gw, heads, planes=False):
+    """Window attention from packed operands (omnitok_attn_window_h2): fp32 [Bn * gh * gw, heads * 64] in token order, or with
+    planes=True the hi|lo planes of it (scaled by the power of two of v_bound)."""
+    rows = Bn * gh * gw
+    if planes:
+        out = torch.empty(_pad256(rows) * heads * 64, device=qp.device, dtype=torch.int32)
+        check(_lib.load().omnitok_attn_window_h2(_p(qp), _p(kp), _p(vp), _p(_req(bias_dense, "bias_dense")), None, 0, _p(out),
+                                                 float(q_bound), float(k_bound), float(v_bound), Bn, gh, gw, heads, _stream()),
+              "attn_window_h2")
+        return out
+    out = torch.empty(rows, heads * 64, device=qp.device, dtype=torch.float32)
+    check(_lib.load().omnitok_attn_window_h2(_p(qp), _p(kp), _p(vp), _p(_req(bias_dense, "bias_dense")), _p(out), heads * 64, None,
+                                             float(q_bound), float(k_bound), float(v_bound), Bn, gh, gw, heads, _stream()),
+          "attn_window_h2")
+    return out
+
+
 def fold_layernorm_weight(weight, gamma, beta=None, rows_fold=None):
     """(w', b, u) for linear_pl(fold=...) on a centred operand: rows < rows_fold of w multiplied by gamma with b = w beta,
     u = row sums of the other rows (what the engine prepares once per layer)."""
@@ -324,7 +364,8 @@ def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias
             qp = torch.empty(M * heads * 64, device=dev, dtype=torch.int32)
             kp = torch.empty(M * heads * 64, device=dev, dtype=torch.int32)
             g.qp, g.kp, g.qk_k0 = qp.data_ptr(), kp.data_ptr(), heads * 64
-            g.q_scale, g.k_scale = attn["q_scale"].data_ptr(), attn["k_scale"].data_ptr()
+            if attn.get("q_scale") is not None:   # None: no l2 normalisation, no learned scale (window attention)
+                g.q_scale, g.k_scale = attn["q_scale"].data_ptr(), attn["k_scale"].data_ptr()
             if attn.get("cos") is not None:
                 g.rope_cos, g.rope_sin = attn["cos"].data_ptr(), attn["sin"].data_ptr()
             g.q_mul, g.q_bound, g.k_bound = float(attn["q_mul"]), float(attn["q_bound"]), float(attn["k_bound"])

@@ -291,3 +291,57 @@ def test_engine_plane_data_flow_matches_fp32_data_flow(ops):
         _lib.set_option("gemm_pl", 1)
     assert (ids0 != ids1).float().mean().item() <= 2e-3
     assert maxerr(px0, px1) < 2e-5
+
+
+def test_window_attention_from_packed_operands_vs_fp64(ops):
+    """The r04 window path end to end at the operator level (reference attention.py:254-293): centred planes in window-major
+    order -> plane GEMM with the LayerNorm folded into every column and the packing epilogues (no l2norm, q * head_dim^-0.5)
+    -> omnitok_attn_window_h2 (dense relative-position bias, output back in token order), against an fp64 restatement of
+    LayerNorm -> qkv -> window_partition -> softmax(q k^T scale + bias) v -> window_reverse; fp32 rows and plane output agree."""
+    torch.manual_seed(0)
+    Bn, gh, gw, heads, D = 2, 16, 24, 8, 512
+    rows = Bn * gh * gw
+    x = rnd(rows, D, seed=301, scale=1.5) + 0.3
+    gamma, beta = rnd(D, seed=302) * 0.1 + 1.0, rnd(D, seed=303) * 0.1
+    w = rnd(3 * D, D, seed=304, scale=0.04)
+    bias = rnd(heads, 64, 64, seed=305, scale=0.5)   # [head][key][query]
+    # fp64 reference
+    xd = x.double()
+    ln = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + 1e-5) * gamma.double() + beta.double()
+    qkv = ln @ w.double().t()
+
+    def part(t):   # [rows, D] -> [Bn, nwy, nwx, 64, heads, 64]
+        t = t.reshape(Bn, gh // 8, 8, gw // 8, 8, heads, 64).permute(0, 1, 3, 2, 4, 5, 6)
+        return t.reshape(Bn, gh // 8, gw // 8, 64, heads, 64)
+    q, k, v = (part(qkv[:, i * D:(i + 1) * D]) for i in range(3))
+    s_ = torch.einsum("bijqhd,bijkhd->bijhqk", q * 0.125, k) + bias.double().permute(0, 2, 1)[None, None, None]
+    o = torch.einsum("bijhqk,bijkhd->bijqhd", torch.softmax(s_, -1), v)
+    ref = o.reshape(Bn, gh // 8, gw // 8, 8, 8, heads * 64).permute(0, 1, 3, 2, 4, 5).reshape(rows, heads * 64)
+    # the HIP path
+    planes, scales, stats = ops.stats_pack_windows((x), gh, gw, center=True)
+    wf, fb, fu = ops.fold_layernorm_weight((w), (gamma), (beta), rows_fold=3 * D)
+    wp = ops.pl_pack_weight(wf)
+    l2 = float((ln.norm(dim=1).max()) * 1.01)
+    qb = l2 * float(w[:D].norm(dim=1).max()) * 0.125
+    kb = l2 * float(w[D:2 * D].norm(dim=1).max())
+    vb = l2 * float(w[2 * D:].norm(dim=1).max())
+    attn = dict(n_tokens=64, heads=heads, q_scale=None, k_scale=None, q_mul=0.125, q_bound=qb, k_bound=kb, v_bound=vb)
+    qp, kp = ops.linear_pl(planes, wp, rows, 2 * D, D, a_scale=scales, epilogue=4, fold=(stats, fb, None, 2 * D), attn=attn)
+    wv = ops.pl_pack_weight(wf[2 * D:].contiguous())
+    vp = ops.linear_pl(planes, wv, rows, D, D, a_scale=scales, epilogue=3, fold=(stats, fb[2 * D:].contiguous(), None, D), attn=attn)
+    out = ops.attn_window_h2(qp, kp, vp, (bias), qb, kb, vb, Bn, gh, gw, heads)
+    err = maxerr(out, ref)
+    print(f"window attention from packed operands: max err {err:.2e} (|ref| max {ref.abs().max():.2f})")
+    assert err < 2e-5
+    op = ops.attn_window_h2(qp, kp, vp, (bias), qb, kb, vb, Bn, gh, gw, heads, planes=True)
+    got = ops.pl_unpack_planes(op, rows, heads * 64) * ops.pl_unscale(vb)
+    assert maxerr(got, out) < 2e-6 * max(1.0, float(out.abs().max()))
+
+
+def test_layernorm_planes_matches_layernorm(ops):
+    x = rnd(700, 512, seed=311, scale=2.0) + 0.5
+    g, b = rnd(512, seed=312) * 0.1 + 1.0, rnd(512, seed=313) * 0.2
+    ref = ops.layernorm(x, g, b)
+    bound = float(ref.abs().max()) * 1.01
+    got = ops.pl_unpack_planes(ops.layernorm_planes((x), (g), (b), bound), 700, 512) * ops.pl_unscale(bound)
+    assert maxerr(got, ref) <= float(ref.abs().max()) * 2.0 ** -21

@@ -4,10 +4,10 @@
 # from, then tools/pmc_to_json.py turns the per-kernel means into profiles/pmc_traffic.json stamped with the sha256 of
 # the csrc/ tree the library was built from.  bash tools/pmc_collect.sh <tag> [bench args...]
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 cd /tmp; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
-BENCH="python bench.py --no-cpu-baseline --no-clock-probe --steps 1 --warmup 1 $*"
+BENCH="python bench.py --no-cpu-baseline --no-clock-probe --no-also --steps 1 --warmup 1 $*"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_MFMA SQ_INSTS_LDS"; do
   name=$(echo $pass | cut -d' ' -f1)
   timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $OUT/${TAG}_pmcraw_$name -- $BENCH > $OUT/${TAG}_pmc_$name.log 2>&1
