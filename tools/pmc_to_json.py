@@ -21,14 +21,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = {
     "gemm_ff_in": ["gemm_pl_kernel<1,"],          # GEGLU epilogue: FF-in only
     "gemm_out": ["gemm_pl_kernel<2,"],            # full-row residual + LayerNorm epilogue: the out-projections
-    "gemm_qk_pack": ["gemm_pl_kernel<4,"],        # spatial q|k launch (packed Q / K)
-    "gemm_v_pack": ["gemm_pl_kernel<3,"],         # spatial v launch (packed V)
+    "gemm_qk_pack": ["gemm_pl_kernel<4,"],        # spatial and window q|k launches (packed Q / K)
+    "gemm_v_pack": ["gemm_pl_kernel<3,"],         # spatial and window v launches (packed V)
+    "gemm_pixels": ["gemm_pl_kernel<5,"],         # to_pixels with the un-patchify store
     # the fp32 epilogue serves FF-out (16 launches, K = 1408) AND the temporal / window q|k|v launches (10, K = 512): one
     # kernel name, so the counters cannot be split per family -- reported under its own key, not as gemm_ff_out
     "gemm_f32_epilogue_mixed": ["gemm_pl_kernel<0,"],
-    "attn_spatial": ["attn_spatial_h2p_kernel"],
+    "attn_spatial": ["attn_spatial_h2w_kernel", "attn_spatial_h2p_kernel", "attn_spatial_h2x_kernel"],   # r04 default: h2w
     "attn_temporal": ["attn_temporal_reg"],
-    "attn_window": ["attn_window_kernel"],
+    "attn_window": ["attn_window_h2_kernel", "attn_window_kernel"],
     "vq_argmin": ["vq_argmin_kernel"],
     "peg3d": ["peg3d_lds_kernel"],
     "stats_pack": ["stats_pack_kernel"],
