@@ -6,7 +6,8 @@ import torch
 
 from oracle import c_oracle
 from oracle import omnitok_oracle as orc
-from tests.helpers import GoldenCase, E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, HEAVY_CASES, VAE_CASES, VARIANT_CASES
+from tests.helpers import (GoldenCase, E2E_CASES, EXT_CASES, FULL_CASES, GOLDEN, HEAVY_BATCH_CASE, HEAVY_CASES, VAE_CASES,
+                           VARIANT_CASES)
 import os
 
 FAST = [c for c in E2E_CASES if "r256" not in c]
@@ -145,3 +146,33 @@ def test_oracle_external_codebook_matches_reference(name):
     cq = c_oracle.vq_argmax_cos if c.cfg.l2_code else c_oracle.vq_argmin_cdist
     cids = cq(c.z.reshape(-1, 8).numpy(), c.sd["codebook._codebook.embed"][0].numpy())
     assert np.array_equal(cids, c.ids.reshape(-1).numpy())
+
+
+def test_heavy_batch_fixture_is_consistent_and_pins_the_oracle():
+    """The batch-scale heavy fixture (the reference in fp32 AND fp64 on 8 clips): internal consistency of what the GPU test
+    uses as its yardstick, and the oracle against the reference on one of its clips (fp32, and in fp64 against the stored
+    fp64 latents)."""
+    c = GoldenCase(HEAVY_BATCH_CASE)
+    n = c.ids.numel()
+    assert n == 8 * 5 * 32 * 32 and c.boundary.numel() == n and c.ref_flips == int((c.ids != c.ids64).sum())
+    E = c.sd["codebook.embeddings"].double()
+    z64 = c.z64.reshape(-1, 8)
+    # the stored fp64 ids ARE the nearest codes of the stored fp64 latents, and the boundary distances are positive
+    d = (z64 * z64).sum(1, keepdim=True)[:4096] - 2.0 * z64[:4096] @ E.t() + (E * E).sum(1)[None]
+    assert torch.equal(d.argmin(1), c.ids64.reshape(-1)[:4096])
+    assert float(c.boundary.min()) > 0.0
+    ref_l2 = (c.z.reshape(-1, 8).double() - z64).norm(dim=1)
+    assert abs(float(ref_l2.max()) - c.fp32_noise_l2_max) < 1e-9
+    # the reference's own fp32 run flips nothing: its per-token error is inside every token's cell
+    assert int((c.boundary < ref_l2).sum()) == 0 and c.ref_flips == 0
+    b = 3
+    x = c.x[b:b + 1]
+    with torch.no_grad():
+        taps = {}
+        ids = orc.encode(c.sd, x, False, c.cfg, taps=taps)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in c.sd.items()}
+        taps64 = {}
+        ids64 = orc.encode(sd64, x.double(), False, c.cfg, taps=taps64)
+    assert torch.equal(ids, c.ids[b:b + 1]) and torch.equal(ids64, c.ids64[b:b + 1])
+    assert (taps["z"] - c.z[b:b + 1]).abs().max().item() < 2e-5          # fp32 vs fp32: summation order only
+    assert (taps64["z"] - c.z64[b:b + 1]).abs().max().item() < 2e-6      # fp64 vs fp64 (RoPE table precision)
