@@ -1100,17 +1100,19 @@ __global__ __launch_bounds__(256, 2) void attn_window_h2_kernel(WinH2Params p, i
         for (int i = 0; i < 8; ++i) kf[kb][i] = *reinterpret_cast<const u32x4 *>(p.kp + base + kb * 8192 + i * 1024);
     const float *bh = p.bias_dense + (int64_t)head * 64 * 64;
     const float LOG2E = 1.44269504088896340736f;
+    // V fragments of both key blocks: requested ONCE, before the S^T MFMAs of the first query block (they land under them and
+    // the softmax) and kept for the second -- re-reading them per query block showed as 1.33x the operand bytes on the
+    // memory-side counter (profiles/r04_pmc_FETCH_SIZE.csv)
+    u32x4 vf[2][8];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vf[kb][i] = *reinterpret_cast<const u32x4 *>(p.vp + base + kb * 8192 + i * 1024);
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         u32x4 qf[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const u32x4 *>(p.qp + base + qb * 8192 + i * 1024);
-        // V fragments of both key blocks are requested before the S^T MFMAs: they land under them and the softmax
-        u32x4 vf[2][8];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vf[kb][i] = *reinterpret_cast<const u32x4 *>(p.vp + base + kb * 8192 + i * 1024);
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
