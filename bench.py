@@ -231,6 +231,10 @@ def run(a):
             kw = kernels["attn_window"]
             kw["algorithmic_gbs"] = round(kw["launches_per_step"] * 4.0 * Ltok * 512 * 4 / (kw["ms_per_step"] * 1e-3) / 1e9, 1)
             kw["frac_hbm_peak"] = round(kw["algorithmic_gbs"] / PEAK_HBM_GBS, 4)
+            if win_split:   # 16 flop/B on the packed-operand path: bandwidth is the roof that binds, the matrix-pipe fraction says nothing
+                kw["bound"] = "hbm"
+                kw.pop("frac_of_mode_roof", None)
+                kw.pop("roof_tflops", None)
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
             vq_bytes = Ltok * 40 + cfg.n_codes * 32
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 2)

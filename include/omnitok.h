@@ -226,7 +226,7 @@ typedef struct omnitok_pl_gemm {
     long long *debug_cycles;    /* measurement: shader-clock span of workgroup 0 (NULL = off)                   */
     /* Operand row map (0 = identity): GEMM row m reads plane row (m / a_rpg) * a_gstride + a_goff + m % a_rpg (a_rpg and
      * a_goff multiples of 256: the frame groups of the token tensor, reference omnitokenizer.py:1006-1017 to_pixels_first_frame /
-     * to_pixels take tokens[:, :1] / tokens[:, 1:]).                                                                */
+     * to_pixels take tokens[:, :1] / tokens[:, 1:]).  Needs a_scale == NULL (one static scale, a_scale_const) and no fold. */
     int64_t a_rpg, a_gstride, a_goff;
     /* epilogue 5: fp32 output (+ bias) scattered as pixels -- row m = patch (b, t, gy, gx) of a [B, up_C, up_F, up_H, up_W]
      * video `c`, column n = feature ((ch up_pt + j) up_p + p1) up_p + p2, frame up_f0 + t up_pt + j (the Rearrange

@@ -227,8 +227,10 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
         p.fold_cols = g->fold_cols;
     }
     if (g->a_rpg > 0) {
-        OT_CHECK_ARG(g->a_rpg % 256 == 0 && g->a_goff % 256 == 0 && g->a_gstride % 64 == 0 && g->M % g->a_rpg == 0 && !g->a2,
-                     "gemm_pl: operand row map needs a_rpg, a_goff %% 256 == 0, a_gstride %% 64 == 0 and whole groups");
+        OT_CHECK_ARG(g->a_rpg % 256 == 0 && g->a_goff % 256 == 0 && g->a_gstride % 64 == 0 && g->M % g->a_rpg == 0 && !g->a2 &&
+                         !g->a_scale && !g->fold_stats,
+                     "gemm_pl: operand row map needs a_rpg, a_goff %% 256 == 0, a_gstride %% 64 == 0, whole groups, and one static "
+                     "operand scale (per-row scales / statistics are indexed by the unmapped row)");
         p.a_rpg = g->a_rpg;
         p.a_gstride = g->a_gstride;
         p.a_goff = g->a_goff;

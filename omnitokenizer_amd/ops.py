@@ -313,14 +313,18 @@ def fold_layernorm_weight(weight, gamma, beta=None, rows_fold=None):
 
 
 def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias=None, residual=None, epilogue=0,
-              out_bound=0.0, ln=None, a2=None, a_split_n=0, c_split_n=0, cfg=0, fold=None, attn=None):
+              out_bound=0.0, ln=None, a2=None, a_split_n=0, c_split_n=0, cfg=0, fold=None, attn=None, k_valid=0, a_rows=None,
+              unpatch=None):
     """c = a . w^T from plane operands.  epilogue 0: fp32 [M, N] (+ bias, + residual; c_split_n: two outputs);
     1: GEGLU -> hidden planes [M, N / 2]; 2: (fp32, planes of LayerNorm(c)) with ln = (gamma, beta or None, eps).
     a2 = (planes, scales or None, const): second activation operand for output columns >= a_split_n.
     fold = (stats, b or None, u or None, fold_cols): LayerNorm folded into the weight, operand = centred planes of
     stats_pack(center=True): columns < fold_cols get rstd * acc + b, the others acc + mean * u (epilogues 0, 3, 4).
     epilogue 4 (packed Q | K) and 3 (packed V, N = heads * 64) take attn = dict(n_tokens, heads, q_scale, k_scale, cos, sin,
-    q_mul, q_bound, k_bound, v_bound) and return int32 buffers in the layout of attn_pack."""
+    q_mul, q_bound, k_bound, v_bound) and return int32 buffers in the layout of attn_pack.
+    k_valid: leading k that are not zero padding (the K loop stops there).  a_rows = (rpg, gstride, goff): GEMM row m reads plane
+    row (m // rpg) * gstride + goff + m % rpg.  epilogue 5 takes unpatch = dict(video, f0, t, pt, p): the fp32 result (+ bias) is
+    scattered into `video` [B, C, F, H, W] in place (un-patchify store) and the video is returned."""
     g = _lib.OmnitokPlGemm()
     dev = a_planes.device
     g.a = a_planes.data_ptr()
@@ -378,6 +382,15 @@ def linear_pl(a_planes, w_packed, M, N, K, a_scale=None, a_scale_const=0.0, bias
         g.ln_gamma = ln[0].data_ptr()
         g.ln_beta = ln[1].data_ptr() if ln[1] is not None else None
         g.ln_eps = float(ln[2])
+    g.k_valid = int(k_valid)
+    if a_rows is not None:
+        g.a_rpg, g.a_gstride, g.a_goff = (int(v) for v in a_rows)
+    if epilogue == 5:
+        video = _req(unpatch["video"], "video")
+        g.c = video.data_ptr()
+        g.up_C, g.up_F, g.up_H, g.up_W = video.shape[1], video.shape[2], video.shape[3], video.shape[4]
+        g.up_f0, g.up_t, g.up_pt, g.up_p = int(unpatch["f0"]), int(unpatch["t"]), int(unpatch["pt"]), int(unpatch["p"])
+        outs = [video]
     g.epilogue, g.M, g.N, g.K, g.cfg = epilogue, M, N, K, cfg
     check(_lib.load().omnitok_gemm_pl(ctypes.byref(g), _stream()), "gemm_pl")
     return outs[0] if len(outs) == 1 else tuple(outs)

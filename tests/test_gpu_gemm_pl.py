@@ -345,3 +345,45 @@ def test_layernorm_planes_matches_layernorm(ops):
     bound = float(ref.abs().max()) * 1.01
     got = ops.pl_unpack_planes(ops.layernorm_planes((x), (g), (b), bound), 700, 512) * ops.pl_unscale(bound)
     assert maxerr(got, ref) <= float(ref.abs().max()) * 2.0 ** -21
+
+
+def test_pl_gemm_k_valid_skips_only_zero_padding(ops):
+    """k_valid stops the K loop at the last step that holds non-padding k: with both operands zero beyond it the result is
+    bit-identical to the full loop (FF-out: K = 1408 holds 1365 hidden channels)."""
+    M, N, K, kv = 777, 512, 1408, 1365
+    a, w = rnd(M, K, seed=321), rnd(N, K, seed=322, scale=0.05)
+    a[:, kv:] = 0.0
+    w[:, kv:] = 0.0
+    planes, scales = ops.pl_pack_rows(a)
+    wp = ops.pl_pack_weight(w)
+    full = ops.linear_pl(planes, wp, M, N, K, a_scale=scales)
+    part = ops.linear_pl(planes, wp, M, N, K, a_scale=scales, k_valid=kv)
+    assert torch.equal(full, part)
+    assert maxerr(part, a.double() @ w.double().t()) < 3e-5
+
+
+def test_pl_gemm_unpatchify_store_and_operand_row_map(ops):
+    """to_pixels as one launch (reference omnitokenizer.py:1006-1017): the tokens of frames 1.. of a [B, T, S] token tensor are read
+    through the operand row map and the fp32 result (+ bias) is scattered into the video by the un-patchify epilogue; equal to
+    Linear + omnitok_unpatchify on the same rows, frame 0 of the video untouched."""
+    B, T, gh, gw, D, C, p, pt = 2, 3, 8, 32, 512, 3, 8, 4
+    S = gh * gw
+    tok = rnd(B * T * S, D, seed=331)
+    w, bias = rnd(C * pt * p * p, D, seed=332, scale=0.05), rnd(C * pt * p * p, seed=333)
+    F_, H, W = 1 + (T - 1) * pt, gh * p, gw * p
+    bound = float(tok.abs().max()) * 1.01
+    planes, _ = ops.pl_pack_rows(tok, static_bound=bound)   # the row map needs ONE static operand scale (rows are re-indexed)
+    wp = ops.pl_pack_weight(w)
+    video = torch.full((B, C, F_, H, W), 7.0, device="cuda")
+    M = B * (T - 1) * S
+    ops.linear_pl(planes, wp, M, C * pt * p * p, D, a_scale_const=ops.pl_unscale(bound), bias=bias, epilogue=5,
+                  a_rows=((T - 1) * S, T * S, S), unpatch=dict(video=video, f0=1, t=T - 1, pt=pt, p=p))
+    with pytest.raises(ValueError):   # per-row scales cannot follow the row map
+        ops.linear_pl(planes, wp, M, C * pt * p * p, D, a_scale=torch.ones(B * T * S, device="cuda"), bias=bias, epilogue=5,
+                      a_rows=((T - 1) * S, T * S, S), unpatch=dict(video=video.clone(), f0=1, t=T - 1, pt=pt, p=p))
+    rows = tok.reshape(B, T, S, D)[:, 1:].reshape(M, D)
+    ref_rows = (rows.double() @ w.double().t() + bias.double()).float()
+    ref = torch.full_like(video, 7.0)
+    ops.unpatchify(ref_rows, ref, 1, T - 1, pt, p)
+    assert torch.equal(video[:, :, 0], ref[:, :, 0])          # frame 0 belongs to the other launch
+    assert maxerr(video, ref) < 3e-5
