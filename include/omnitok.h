@@ -50,6 +50,8 @@ const char *omnitok_version(void);
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
  *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
  *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
+ *   "pl_min_tokens" 12288 (default, process-wide) calls with fewer tokens (B * T' * h * w) take the gemm_pl 0 data flow: below
+ *                ~48 row tiles the 256 x 256 plane GEMM leaves most CUs idle (one image 4.1 ms vs 2.0 ms) | 0 always planes
  *   "attn_window_mode" 1 (default, process-wide, with gemm_pl / qkv_pl) window attention on the fp16 matrix cores from packed
  *                operands (omnitok_stats_pack_windows -> packing epilogues -> omnitok_attn_window_h2) | 0 fp32 q|k|v and the
  *                fp32-MFMA kernel omnitok_attn_window_planes

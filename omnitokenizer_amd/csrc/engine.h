@@ -167,7 +167,7 @@ int get_bias_table(omnitok_engine *e, const std::string &prefix, int gh, int gw,
 int gemm_mode_of(const omnitok_engine *e);
 int attn_mode_of(const omnitok_engine *e);
 int attn_vpack_of(const omnitok_engine *e);
-int gemm_pl_of(const omnitok_engine *e);
+int gemm_pl_of(const omnitok_engine *e, int64_t tokens);
 bool x3_ok(const omnitok_engine *e, int N, int K, int flags);
 float *next_bounds(omnitok_engine *e);
 struct VPack {  // packed-V output of the merged q|k|v launch (gemm_h2.hip): planes, first V column, sequence shape, |v| bound

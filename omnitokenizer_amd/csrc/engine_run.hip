@@ -18,7 +18,12 @@ int g_attn_vpack = 1;
 // are written as fp16 hi|lo planes by their producers (attention kernels, the LayerNorm epilogue of to_out, the GEGLU
 // epilogue of FF-in): no row-statistics pass and no in-loop LayerNorm / split in front of the FeedForward.  0: the
 // r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
+// "pl_min_tokens" (default 12288): calls with fewer tokens (B * T' * h * w) than this take the gemm_pl 0 data flow even
+// when gemm_pl is 1 -- the plane GEMM works in 256 x 256 tiles with a deep LDS-DMA ring, and below ~48 row tiles its
+// launches leave most of the 256 CUs idle: one 256^2 image 4.09 ms vs 2.00 ms, 8 images 5.31 vs 4.59 ms, 16 images
+// 7.00 vs 7.59 ms (profiles/r04_small_batch_latency.txt).  0 = always planes (what the parity tests of that path set).
 int g_gemm_pl = 1;
+int g_pl_min_tokens = 12288;
 // "qkv_pl" 1 (default, with gemm_pl): the q|k|v projection as a plane GEMM too -- one pass writes the row statistics and
 // the centred rows x - mean as planes (omnitok_stats_pack), the LayerNorm of the Q columns is folded into the weight and finished in the
 // epilogue, which for spatial attention also does RoPE + l2norm + scales and writes Q and K straight into the attention
@@ -33,7 +38,9 @@ int g_attn_window_mode = 1;
 int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->opt_gemm_mode : g_gemm_mode; }
 int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
 int attn_vpack_of(const omnitok_engine *e) { return e->opt_attn_vpack >= 0 ? e->opt_attn_vpack : g_attn_vpack; }
-int gemm_pl_of(const omnitok_engine *e) { return e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl; }
+int gemm_pl_of(const omnitok_engine *e, int64_t tokens) {
+    return (e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl) && tokens >= g_pl_min_tokens;
+}
 
 bool x3_ok(const omnitok_engine *e, int N, int K, int flags) {
     return gemm_mode_of(e) >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
@@ -108,7 +115,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
     // Plane data flow (gemm_pl.h): attention output -> planes (AO) -> to_out / proj with the residual add and the
     // FeedForward's LayerNorm in its epilogue (x in place, LN(x) planes -> Y) -> FF-in with the GEGLU hidden as planes
     // (HD) -> FF-out (+ residual).  Needs full-row tiles for the LayerNorm epilogue (dim 512 = the reference's only width).
-    bool pl_ok = gemm_pl_of(e) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
+    bool pl_ok = gemm_pl_of(e, L) && gemm_mode_of(e) == 2 && fused && D == 512 && x3_ok(e, 2 * e->inner_pad, D, OMNITOK_GEMM_GEGLU);
     // the plane producers scale by constants derived from the static operand bounds: a degenerate FeedForward LayerNorm
     // (gamma == beta == 0 gives bound 0) or a non-finite bound sends the whole Transformer down the gemm_h2 / x3 branch,
     // which handles missing ranges by itself

@@ -242,6 +242,36 @@ def test_window_attention_paths_agree(models, name):
     assert (res[0][1] - res[1][1]).abs().max().item() < 2 * tol
 
 
+def test_small_calls_take_the_fp32_activation_flow(models):
+    """"pl_min_tokens" (include/omnitok.h, default 12288): a call with fewer tokens runs the gemm_pl 0 data flow (one image:
+    2.0 ms instead of 4.1 ms, profiles/r04_small_batch_latency.txt), a call at or above it the plane data flow -- checked
+    bit for bit against the two flows selected explicitly, on 2 clips (10240 tokens) and 3 clips (15360 tokens)."""
+    from omnitokenizer_amd import _lib
+    c = GoldenCase(HEAVY_BATCH_CASE)
+    m = models(c)
+    x = c.x.cuda()
+
+    def run(n, pl, min_tokens):
+        try:
+            _lib.set_option("gemm_pl", pl)
+            _lib.set_option("pl_min_tokens", min_tokens)
+            ids, z = m.encode(x[:n], c.is_image, return_latents=True)
+            return ids.cpu(), z.cpu(), m.decode(ids, c.is_image).cpu()
+        finally:
+            _lib.set_option("gemm_pl", 1)
+            _lib.set_option("pl_min_tokens", 0)
+
+    for n, planes in ((2, False), (3, True)):
+        tokens = c.ids[:n].numel()
+        assert (tokens >= 12288) == planes
+        auto = run(n, 1, 12288)
+        forced = run(n, 1 if planes else 0, 0)
+        other = run(n, 0 if planes else 1, 0)
+        assert all(torch.equal(a, b) for a, b in zip(auto, forced)), (n, planes)
+        assert not torch.equal(auto[1], other[1])     # the two flows round differently: the switch is observable
+        assert (auto[1] - other[1]).abs().max().item() < 2 * max(Z_TOL, 8.0 * c.fp32_noise_z)
+
+
 def test_two_engines_with_different_modes_in_one_process():
     """The arithmetic / data-flow modes are per-engine fields (omnitok_engine_set_option): two modules of one process run
     different modes side by side, each bit-identical to a run of that mode selected process-wide."""
