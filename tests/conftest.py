@@ -37,6 +37,8 @@ def plane_data_flow_at_every_size():
         yield
         return
     from omnitokenizer_amd import _lib
-    _lib.set_option("pl_min_tokens", 0)
+    # OMNITOK_TEST_PL_MIN_TOKENS=12288 runs the whole suite on the flow small calls take by default instead
+    # (profiles/r04_gpu_tests_small_call_flow.txt)
+    _lib.set_option("pl_min_tokens", int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")))
     yield
     _lib.set_option("pl_min_tokens", 12288)

@@ -259,7 +259,7 @@ def test_small_calls_take_the_fp32_activation_flow(models):
             return ids.cpu(), z.cpu(), m.decode(ids, c.is_image).cpu()
         finally:
             _lib.set_option("gemm_pl", 1)
-            _lib.set_option("pl_min_tokens", 0)
+            _lib.set_option("pl_min_tokens", int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")))  # tests/conftest.py
 
     for n, planes in ((2, False), (3, True)):
         tokens = c.ids[:n].numel()
@@ -284,6 +284,7 @@ def test_two_engines_with_different_modes_in_one_process():
         return m.cuda().eval()
     a, b = build(), build()
     x = c.x.cuda()
+    _lib.set_option("pl_min_tokens", 0)  # the fixture is a small call: keep the plane flow the process default here
     a.set_option("gemm_mode", 0)     # fp32-input MFMA GEMMs ...
     a.set_option("attn_mode", 0)
     b.set_option("gemm_pl", 0)       # ... next to the fp16-split GEMMs with fp32 activations between the kernels
@@ -310,6 +311,7 @@ def test_two_engines_with_different_modes_in_one_process():
         _lib.set_option("gemm_mode", 2)
         _lib.set_option("attn_mode", 1)
         _lib.set_option("gemm_pl", 1)
+        _lib.set_option("pl_min_tokens", int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")))
     with pytest.raises(ValueError):
         a.set_option("h2_tile", 3)   # a tuning knob of the stand-alone kernels, not an engine mode
     for m in (za, zb, zd):
@@ -545,7 +547,14 @@ def test_full_size_properties(models, is_image, batch):
     assert rec.shape == ((batch, 3, 256, 256) if is_image else (batch, 3, 17, 256, 256))
     assert torch.isfinite(rec).all()
     assert torch.equal(rec[4:8], rec[:4])
-    assert torch.equal(m.decode(ids[:2].contiguous(), is_image), rec[:2])
+    # a 2-item call sits below "pl_min_tokens" when the session runs on the default threshold (tests/conftest.py): it then
+    # takes the other data flow, whose pixels agree to rounding instead of bit for bit (ids are equal either way, above)
+    min_tokens = int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0"))
+    rec2 = m.decode(ids[:2].contiguous(), is_image)
+    if (ids[:2].numel() >= min_tokens) == (ids.numel() >= min_tokens):
+        assert torch.equal(rec2, rec[:2])
+    else:
+        assert (rec2 - rec[:2]).abs().max().item() < PIXEL_TOL
     assert torch.equal(m.decode(ids, is_image), rec)
     # the golden item (image case: same shape) is reproduced inside the big batch
     if is_image:
