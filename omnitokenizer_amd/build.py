@@ -19,7 +19,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomnitok.so")
 SOURCES = ["common.cpp", "gemm.hip", "gemm_x3.hip", "gemm_h2.hip", "gemm_pl.hip", "norm.hip", "peg.hip", "attn_spatial.hip", "attn_h2.hip", "attn_temporal.hip",
            "vq.hip", "resample.hip", "engine.hip", "engine_build.hip", "engine_run.hip", "lm.hip", "lm_select.hip", "debug.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_x_common.h"), os.path.join(CSRC, "h2_common.h"), os.path.join(CSRC, "gemm_pl.h"), os.path.join(CSRC, "engine.h"), os.path.join(CSRC, "planes.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_x_common.h"), os.path.join(CSRC, "h2_common.h"), os.path.join(CSRC, "gemm_pl.h"), os.path.join(CSRC, "engine.h"), os.path.join(CSRC, "planes.h"), os.path.join(CSRC, "peg_wide.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok_lm.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok_debug.h"),

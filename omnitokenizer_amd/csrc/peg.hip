@@ -8,11 +8,13 @@
 // (attention.py:319); the engine keeps tokens physically in the layout the
 // reference has at that point, so the same kernel reproduces both cases.
 #include "common.h"
+#include "peg_wide.h"
 
 namespace omnitok {
 
 constexpr int PEG_WSEG = 4;
-int g_peg_variant = 1;  // omnitok_set_option("peg_variant"): 0 register-blocked, 1 LDS-tiled time ring
+int g_peg_variant = 1;  // omnitok_set_option("peg_variant"): 0 register-blocked | 1 LDS-tiled: the 64-channel kernel of peg_wide.h for 2..8 planes
+                        // on grids it accepts, else the time ring below | 2 peg_wide.h whenever the grid allows | 3 time ring only
 
 __global__ __launch_bounds__(256) void peg3d_kernel(const float *__restrict__ x, const float *__restrict__ w27,
                                                     const float *__restrict__ bias, float *__restrict__ y, int B,
@@ -217,7 +219,18 @@ extern "C" int omnitok_peg3d(const float *x, const float *w27, const float *bias
     OT_CHECK_ARG(D % 4 == 0, "peg3d: D %% 4 != 0");
     OT_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(w27) && aligned16(bias), "peg3d: unaligned pointer");
     if (B * T * H * W == 0) return OMNITOK_OK;
-    if (D % 32 == 0 && g_peg_variant == 1 && (int64_t)((W + PT_W - 1) / PT_W) * ((H + PT_H - 1) / PT_H) * (D / 32) * B < (1ll << 31)) {
+    // 64-channel slab: 164 vs 188 us at C3's [32, 5, 32, 32] (tools/probes/peg_wide_probe.hip, bit-identical); no gain at one plane
+    // (221 vs 224 us) and a loss on long walks over large grids (17 planes of 64 x 64: 68 vs 62 us) -- hence the plane-count window
+    const bool wide_ok = D % 64 == 0 && W % pegw::W_T == 0 && H % pegw::H_T == 0 &&
+                         (int64_t)(W / pegw::W_T) * (H / pegw::H_T) * (D / 64) * B < (1ll << 31);
+    if (wide_ok && ((g_peg_variant == 1 && T >= 2 && T <= 8) || g_peg_variant == 2)) {
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(pegw::peg3d_wide_kernel), pegw::LDS_BYTES)) return rc;
+        hipLaunchKernelGGL(pegw::peg3d_wide_kernel, dim3((unsigned)((int64_t)(W / pegw::W_T) * (H / pegw::H_T) * (D / 64) * B)), dim3(256),
+                           pegw::LDS_BYTES, stream, x, w27, bias, y, B, T, H, W, D, causal ? 2 : 1);
+        OT_LAUNCH_CHECK("peg3d_wide");
+        return OMNITOK_OK;
+    }
+    if (D % 32 == 0 && g_peg_variant >= 1 && (int64_t)((W + PT_W - 1) / PT_W) * ((H + PT_H - 1) / PT_H) * (D / 32) * B < (1ll << 31)) {
         if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(peg3d_lds_kernel), PT_LDS_BYTES)) return rc;
         const int wtiles = (W + PT_W - 1) / PT_W, htiles = (H + PT_H - 1) / PT_H;
         hipLaunchKernelGGL(peg3d_lds_kernel, dim3((unsigned)((int64_t)wtiles * htiles * (D / 32) * B)), dim3(256), PT_LDS_BYTES,

@@ -140,7 +140,7 @@ def test_patchify_ln_and_unpatchify(ops, pt, frames):
 @pytest.mark.parametrize("shape", [(2, 5, 8, 8), (1, 1, 32, 32), (3, 3, 16, 16), (1, 17, 8, 8), (1, 2, 64, 64),
                                    (2, 4, 6, 40)])
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("variant", [0, 1], ids=["regblock", "lds_ring"])
+@pytest.mark.parametrize("variant", [0, 2, 3, 1], ids=["regblock", "wide_slab", "lds_ring", "auto"])
 def test_peg3d(ops, shape, causal, variant):
     from omnitokenizer_amd import _lib
     _lib.set_option("peg_variant", variant)
@@ -157,6 +157,34 @@ def test_peg3d(ops, shape, causal, variant):
     ref_t = orc.peg(xt, w, b, shape, causal) + xt
     out_t = ops.peg3d(dev(xt), ops.pack_peg_weight(dev(w)), dev(b), shape, causal)
     assert maxerr(out_t, ref_t) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 1, 4, 16), (1, 6, 16, 32), (1, 7, 8, 16), (1, 17, 8, 16), (3, 2, 64, 16)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_peg3d_wide_slab_kernel_is_bit_identical(ops, shape, causal):
+    """csrc/peg_wide.h (64-channel slab, two ring slots, every plane read from LDS once and accumulated into the three output
+    planes it feeds) against the time-ring kernel and the oracle on grids it accepts (W % 16 == 0, H % 4 == 0): one plane, plane
+    counts inside and outside the window the default rule uses it for, one-tile and multi-tile grids.  Same order of planes and
+    taps per output, so bit for bit."""
+    from omnitokenizer_amd import _lib
+    B, T, H, W = shape
+    D = 512
+    x = rnd(B * T, H * W, D, seed=35)
+    w = (torch.rand(D, 1, 3, 3, 3, generator=torch.Generator().manual_seed(36)) * 2 - 1) / math.sqrt(27)
+    b = rnd(D, seed=37) * 0.05
+    wp = ops.pack_peg_weight(dev(w))
+    try:
+        _lib.set_option("peg_variant", 2)
+        out = [ops.peg3d(dev(x), wp, dev(b), shape, causal) for _ in range(3)]
+        _lib.set_option("peg_variant", 3)
+        want = ops.peg3d(dev(x), wp, dev(b), shape, causal)
+        _lib.set_option("peg_variant", 1)
+        auto = ops.peg3d(dev(x), wp, dev(b), shape, causal)
+    finally:
+        _lib.set_option("peg_variant", 1)
+    assert maxerr(want, orc.peg(x, w, b, shape, causal) + x) < 1e-5
+    for o in out + [auto]:
+        assert torch.equal(o, want)
 
 
 def test_fused_token_transposes(ops):

@@ -31,7 +31,7 @@ FAMILIES = {
     "attn_temporal": ["attn_temporal_reg"],
     "attn_window": ["attn_window_h2_kernel", "attn_window_kernel"],
     "vq_argmin": ["vq_argmin_kernel"],
-    "peg3d": ["peg3d_lds_kernel"],
+    "peg3d": ["peg3d_wide_kernel", "peg3d_lds_kernel"],   # r04: the 64-channel kernel at C3 (5 planes)
     "stats_pack": ["stats_pack_kernel"],
 }
 
