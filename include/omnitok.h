@@ -65,7 +65,7 @@ const char *omnitok_version(void);
  * staged in LDS; all bit-exact, profiles/r03_vq_variants.txt), "pl_stagger" (start delay step of persistent GEMM workgroups in
  * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant" (1 default: LDS-tiled -- the 64-channel kernel of peg_wide.h for
  * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, else the 32-channel time ring | 2 the 64-channel kernel whenever
- * the grid allows | 3 time ring only | 0 register-blocked; bit-identical to each other), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
+ * the grid allows | 3 time ring only (1, 2, 3 bit-identical) | 0 register-blocked), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* ------------------------------------------------------------------------------------------
