@@ -1,0 +1,351 @@
+// Stand-alone probe for the out-projection (gemm_pl epilogue 2: c = a . W^T + bias + residual in place, LayerNorm(c) -> hi|lo
+// planes; N = K = 512).  The in-tree kernel holds a 128 x 512 tile per workgroup with the WEIGHT stages in LDS (3 x 40 KiB + 32 KiB
+// of epilogue scratch: one workgroup per CU), so its HBM-bound epilogue (1.34 GB per launch) and its K loop never overlap:
+// 0.35 ms per launch at C3, 16 launches per step (DESIGN (e) "Closed by measurement").  Here: a 64 x 512 tile per workgroup of four
+// waves, the activation stages (4 KiB per K step) through LDS by DMA as before, but the weight fragments -- every wave needs only
+// its own 128 columns -- straight from global memory (L2) into registers in MFMA operand order.  LDS per workgroup: 16 KiB of
+// stages + 2 KiB of row statistics, registers ~250: TWO workgroups per CU, whose epilogues and K loops interleave.  Price: every
+// workgroup streams all of W (1 MiB) for 64 rows instead of 128: 2.7 GB of L2 -> CU weight traffic per launch instead of 1.3.
+// The probe reports the in-tree kernel (through the C ABI) and this structure on the same operands, and the same kernel forced to one
+// workgroup per CU (dynamic LDS padding) to separate the effect of co-residency.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-fast-math -Iinclude tools/probes/rowln_direct_probe.hip -Lomnitokenizer_amd/lib \
+//         -lomnitok -Wl,-rpath,'$ORIGIN/../../omnitokenizer_amd/lib' -o tools/_bin/rowln_direct_probe
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "omnitok.h"
+
+typedef _Float16 f16;
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_t;
+typedef __attribute__((address_space(1))) const void glob_t;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#define OK(x) do { if ((x) != 0) { printf("%s: %s\n", #x, omnitok_last_error()); exit(1); } } while (0)
+#define WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+
+constexpr int K = 512, N = 512, TM = 64, KS = K / 16, NW = 4;
+constexpr int R = 4;                      // activation stages of 4 KiB
+constexpr int A_STAGE = 4096;
+constexpr int LDS_STATS = R * A_STAGE;    // [64 rows][4 waves] floats
+constexpr int LDS_BYTES = LDS_STATS + TM * NW * 4;
+
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0) only
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+struct Params {
+    const unsigned char *a;   // activation planes, in-tree layout [rows/64][K/32][hi|lo][4 k groups][64 rows][8] fp16
+    const unsigned char *wp;  // weight fragments [k step 32][column block 16][hi|lo][lane 64] x 16 B (MFMA A operand order)
+    const float *w_scale, *bias, *gamma, *beta;
+    float *x;                 // residual in, c out (in place), [M, 512]
+    unsigned char *out;       // LayerNorm(c) planes, in-tree layout
+    float a_sc, out_scale, eps;
+    long M;
+};
+
+// D = how many K steps the loads run ahead (activation DMA and weight fragments alike)
+template <int D>
+__global__ __launch_bounds__(256, 2) void rowln_direct(Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int m32 = lane & 31, h = lane >> 5;
+    const long tile = blockIdx.x;
+    // activation piece of this wave: plane w >> 1, k group (of the step's two) w & 1
+    const unsigned char *a_src = p.a + tile * (K / 32) * 8192 + ((w >> 1) * 4 + (w & 1)) * 1024 + lane * 16;
+    auto a_dma = [&](int ks) {
+        const unsigned char *src = a_src + (ks >> 1) * 8192 + (ks & 1) * 2048;
+        __builtin_amdgcn_global_load_lds((glob_t *)src, (lds_t *)(smem + (ks % R) * A_STAGE + w * 1024), 16, 0, 0);
+    };
+    const f16x8 *w_src = reinterpret_cast<const f16x8 *>(p.wp) + (w * 4 * 2) * 64 + lane;
+    f16x8 wf[D + 1][4][2];
+    auto w_load = [&](int ks, int buf) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) wf[buf][cb][pl] = w_src[((long)ks * 16 * 2 + cb * 2 + pl) * 64];
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][mi][i] = 0.0f;
+
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+        w_load(s, s);
+        a_dma(s);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {  // fully unrolled: the fragment buffer index must be static
+        if (ks + D < KS) {
+            w_load(ks + D, (ks + D) % (D + 1));
+            a_dma(ks + D);
+            WAIT_VM(9 * D);  // everything up to this step's activation piece (and the fragments issued just before it) has landed
+        } else {
+            WAIT_VM(0);
+        }
+        lds_barrier();
+        const unsigned char *st = smem + (ks % R) * A_STAGE;
+        f16x8 xh[2], xl[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            xh[mi] = *reinterpret_cast<const f16x8 *>(st + (0 * 2 + h) * 1024 + (mi * 32 + m32) * 16);
+            xl[mi] = *reinterpret_cast<const f16x8 *>(st + (1 * 2 + h) * 1024 + (mi * 32 + m32) * 16);
+        }
+        const int b = ks % (D + 1);
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                acc[cb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b][cb][0], xh[mi], acc[cb][mi], 0, 0, 0);
+                acc[cb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b][cb][0], xl[mi], acc[cb][mi], 0, 0, 0);
+                acc[cb][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[b][cb][1], xh[mi], acc[cb][mi], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: lane = row (mi * 32 + m32) x 16 consecutive columns of each of its wave's four 32-column blocks --------------
+    float *stats = reinterpret_cast<float *>(smem + LDS_STATS);
+    float s1[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int col = (w * 4 + cb) * 32 + h * 16;
+        f32x4 ws[4], bs[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ws[q] = *reinterpret_cast<const f32x4 *>(p.w_scale + col + 4 * q);
+            bs[q] = *reinterpret_cast<const f32x4 *>(p.bias + col + 4 * q);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            float *xr = p.x + (tile * TM + mi * 32 + m32) * (long)N + col;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 r = *reinterpret_cast<const f32x4 *>(xr + 4 * q);
+                f32x4 c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    c[e] = acc[cb][mi][4 * q + e] * p.a_sc * ws[q][e] + bs[q][e] + r[e];
+                    acc[cb][mi][4 * q + e] = c[e];
+                    s1[mi] += c[e];
+                }
+                *reinterpret_cast<f32x4 *>(xr + 4 * q) = c;
+            }
+        }
+    }
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        lds_barrier();  // (pass 1: every wave has read the sums of pass 0)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            float v = s1[mi];
+            v += __shfl_xor(v, 32);
+            if (h == 0) stats[(mi * 32 + m32) * NW + w] = v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const f32x4 t = *reinterpret_cast<const f32x4 *>(stats + (mi * 32 + m32) * NW);
+            const float tot = (t[0] + t[1]) + (t[2] + t[3]);
+            if (pass == 0) {
+                mean[mi] = tot / (float)N;
+                float q2 = 0.0f;
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float d = acc[cb][mi][i] - mean[mi];
+                        q2 += d * d;
+                    }
+                s1[mi] = q2;
+            } else {
+                rstd[mi] = 1.0f / sqrtf(tot / (float)N + p.eps);
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const int kb = w * 4 + cb, col = kb * 32 + h * 16;
+        f32x4 g[4], be[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            g[q] = *reinterpret_cast<const f32x4 *>(p.gamma + col + 4 * q);
+            be[q] = *reinterpret_cast<const f32x4 *>(p.beta + col + 4 * q);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            unsigned char *ob = p.out + (tile * (N / 32) + kb) * 8192 + (mi * 32 + m32) * 16;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {  // two k groups of 8 columns
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int i = half * 8 + e;
+                    const float y = ((acc[cb][mi][i] - mean[mi]) * rstd[mi] * g[i >> 2][i & 3] + be[i >> 2][i & 3]) * p.out_scale;
+                    hi[e] = (f16)y;
+                    lo[e] = (f16)(y - (float)hi[e]);
+                }
+                const int kg = h * 2 + half;
+                *reinterpret_cast<f16x8 *>(ob + (0 * 4 + kg) * 1024) = hi;
+                *reinterpret_cast<f16x8 *>(ob + (1 * 4 + kg) * 1024) = lo;
+            }
+        }
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+static float time_ms(void (*fn)(void *), void *ctx, int reps) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) fn(ctx);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) fn(ctx);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+struct Probe { Params p; int lds; int depth; };
+struct InTree { omnitok_pl_gemm g; };
+
+int main() {
+    const long M = 163840;
+    unsigned rng = 2463534242u;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 17; rng ^= rng << 5; return (rng >> 8) / 8388608.0f - 1.0f; };
+    std::vector<float> hx((size_t)M * N), hw((size_t)N * K), hb(N), hg(N), hbe(N);
+    std::vector<float> ha((size_t)M * K);
+    for (auto &v : ha) v = rnd();
+    for (auto &v : hx) v = rnd() * 2.0f;
+    for (auto &v : hw) v = rnd() * 0.06f;
+    for (int n = 0; n < N; ++n) { hb[n] = rnd() * 0.1f; hg[n] = 1.0f + 0.2f * rnd(); hbe[n] = 0.1f * rnd(); }
+
+    float *da, *dx0, *dx1, *dx2, *dw, *dbias, *dgamma, *dbeta, *dwscale_in, *dwscale_pr;
+    unsigned char *a_planes, *w_in, *w_pr, *out_in, *out_pr;
+    CK(hipMalloc(&da, (size_t)M * K * 4)); CK(hipMalloc(&dx0, (size_t)M * N * 4)); CK(hipMalloc(&dx1, (size_t)M * N * 4));
+    CK(hipMalloc(&dx2, (size_t)M * N * 4));
+    CK(hipMalloc(&dw, (size_t)N * K * 4)); CK(hipMalloc(&dbias, N * 4)); CK(hipMalloc(&dgamma, N * 4)); CK(hipMalloc(&dbeta, N * 4));
+    CK(hipMalloc(&dwscale_in, N * 4)); CK(hipMalloc(&dwscale_pr, N * 4));
+    const long pb = omnitok_pl_planes_bytes(M, K, 256);
+    CK(hipMalloc(&a_planes, pb)); CK(hipMalloc(&out_in, pb)); CK(hipMalloc(&out_pr, pb));
+    CK(hipMalloc(&w_in, (size_t)N * K * 4)); CK(hipMalloc(&w_pr, (size_t)N * K * 4));
+    CK(hipMemcpy(da, ha.data(), (size_t)M * K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dx0, hx.data(), (size_t)M * N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), (size_t)N * K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbias, hb.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dgamma, hg.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dbeta, hbe.data(), N * 4, hipMemcpyHostToDevice));
+    const float a_bound = 1.0f;
+    OK(omnitok_pl_pack_rows(da, K, M, K, (M + 255) / 256 * 256, a_planes, nullptr, a_bound, nullptr));
+    OK(omnitok_pl_pack_weight(dw, K, N, K, N, w_in, dwscale_in, nullptr));
+    const float a_sc = omnitok_pl_unscale(a_bound);
+
+    // the probe's weight fragments: one power-of-two scale for the whole matrix (|w| <= 0.06 -> x 2^18 stays below fp16's 65504),
+    // MFMA row n_phys of a 32-column block holds logical column h * 16 + i, n_phys = (i / 4) * 8 + h * 4 + i % 4
+    const float wsc = 262144.0f;
+    std::vector<f16> hwp((size_t)N * K * 2);
+    for (int ks = 0; ks < KS; ++ks)
+        for (int cbk = 0; cbk < 16; ++cbk)
+            for (int ln = 0; ln < 64; ++ln) {
+                const int n_phys = ln & 31, kg = ln >> 5;
+                const int i4 = n_phys / 8, hh = (n_phys % 8) / 4, i = i4 * 4 + n_phys % 4;
+                const int col = cbk * 32 + hh * 16 + i;
+                for (int e = 0; e < 8; ++e) {
+                    const float v = hw[(size_t)col * K + ks * 16 + kg * 8 + e] * wsc;
+                    const f16 hi = (f16)v, lo = (f16)(v - (float)hi);
+                    hwp[((((size_t)ks * 16 + cbk) * 2 + 0) * 64 + ln) * 8 + e] = hi;
+                    hwp[((((size_t)ks * 16 + cbk) * 2 + 1) * 64 + ln) * 8 + e] = lo;
+                }
+            }
+    CK(hipMemcpy(w_pr, hwp.data(), hwp.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> hws(N, 1.0f / wsc);
+    CK(hipMemcpy(dwscale_pr, hws.data(), N * 4, hipMemcpyHostToDevice));
+
+    const float out_bound = 8.0f;
+    Probe pr{};
+    pr.p = Params{a_planes, w_pr, dwscale_pr, dbias, dgamma, dbeta, dx1, out_pr, a_sc, 1.0f / omnitok_pl_unscale(out_bound), 1e-5f, M};
+    InTree it{};
+    memset(&it.g, 0, sizeof(it.g));
+    it.g.a = a_planes; it.g.a_scale_const = a_sc; it.g.w = w_in; it.g.w_scale = dwscale_in; it.g.bias = dbias;
+    it.g.residual = dx2; it.g.ldr = N; it.g.c = dx2; it.g.ldc = N; it.g.out_planes = out_in; it.g.out_planes_k = N;
+    it.g.out_bound = out_bound; it.g.ln_gamma = dgamma; it.g.ln_beta = dbeta; it.g.ln_eps = 1e-5f; it.g.epilogue = 2;
+    it.g.M = M; it.g.N = N; it.g.K = K;
+
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowln_direct<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void *>(rowln_direct<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    auto launch = [](void *c) {
+        Probe *q = (Probe *)c;
+        if (q->depth == 2) hipLaunchKernelGGL(rowln_direct<2>, dim3((unsigned)(q->p.M / TM)), dim3(256), q->lds, 0, q->p);
+        else hipLaunchKernelGGL(rowln_direct<1>, dim3((unsigned)(q->p.M / TM)), dim3(256), q->lds, 0, q->p);
+    };
+    auto launch_in = [](void *c) { InTree *q = (InTree *)c; if (omnitok_gemm_pl(&q->g, nullptr)) { printf("gemm_pl: %s\n", omnitok_last_error()); exit(1); } };
+
+    // ---- correctness: one application on fresh residuals, against fp64 on sampled rows and against the in-tree kernel ----------
+    CK(hipMemcpy(dx1, dx0, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(dx2, dx0, (size_t)M * N * 4, hipMemcpyDeviceToDevice));
+    pr.lds = LDS_BYTES; pr.depth = 2;
+    launch(&pr);
+    launch_in(&it);
+    CK(hipDeviceSynchronize());
+    {
+        const long rows[] = {0, 1, 63, 64, 12345, M - 1};
+        double worst = 0, worst_in = 0, worst_ln = 0;
+        std::vector<float> c1(N), c2(N);
+        std::vector<f16> pl(8192 * 16 / 2);
+        for (long m : rows) {
+            CK(hipMemcpy(c1.data(), dx1 + m * N, N * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(c2.data(), dx2 + m * N, N * 4, hipMemcpyDeviceToHost));
+            std::vector<double> ref(N);
+            double mu = 0;
+            for (int n = 0; n < N; ++n) {
+                double s = 0;
+                for (int k = 0; k < K; ++k) s += (double)ha[(size_t)m * K + k] * hw[(size_t)n * K + k];
+                ref[n] = s + hb[n] + hx[(size_t)m * N + n];
+                mu += ref[n];
+                worst = fmax(worst, fabs(ref[n] - c1[n]));
+                worst_in = fmax(worst_in, fabs(ref[n] - c2[n]));
+            }
+            mu /= N;
+            double var = 0;
+            for (int n = 0; n < N; ++n) var += (ref[n] - mu) * (ref[n] - mu);
+            const double rs = 1.0 / sqrt(var / N + 1e-5);
+            // the probe's LayerNorm planes of this row: block (m / 64), k block n / 32, sub-block plane * 4 + (n % 32) / 8
+            CK(hipMemcpy(pl.data(), out_pr + (m / 64) * (N / 32) * 8192, (size_t)(N / 32) * 8192, hipMemcpyDeviceToHost));
+            for (int n = 0; n < N; ++n) {
+                const size_t o = ((size_t)(n / 32) * 8 + (n % 32) / 8) * 512 + (m % 64) * 8 + n % 8;
+                const double y = ((double)pl[o] + (double)pl[o + 4 * 512]) * omnitok_pl_unscale(out_bound);
+                worst_ln = fmax(worst_ln, fabs(y - ((ref[n] - mu) * rs * hg[n] + hbe[n])));
+            }
+        }
+        printf("check on 6 rows vs fp64: |c - ref| probe %.2e, in-tree %.2e; |LayerNorm planes - ref| probe %.2e\n", worst, worst_in, worst_ln);
+    }
+
+    // ---- time: every launch adds onto x in place; magnitudes grow slowly (bias + product per launch), irrelevant for the rate ------
+    const double gf = 2.0 * M * N * K * 1e-9, gb = ((double)M * K * 4 + 3.0 * M * N * 4) * 1e-9;
+    auto report = [&](const char *name, float ms) {
+        printf("%-64s %7.1f us  %6.1f TF fp32-eq  %5.2f TB/s algorithmic\n", name, ms * 1e3, gf / ms, gb / ms);
+    };
+    for (int i = 0; i < 600; ++i) launch_in(&it);  // ~0.25 s at full load first: the shader clock settles at its power-capped value
+    CK(hipDeviceSynchronize());
+    for (int round = 0; round < 3; ++round) {
+        report("in-tree epilogue 2 (128 x 512 tile, W through LDS, 1 workgroup / CU)", time_ms(launch_in, &it, 100));
+        pr.depth = 2; pr.lds = LDS_BYTES;
+        report("probe: 64 x 512, W fragments from L2, loads 2 steps ahead, 2 / CU", time_ms(launch, &pr, 100));
+        pr.lds = 90 * 1024;
+        report("probe: same kernel forced to 1 workgroup / CU (LDS padding)", time_ms(launch, &pr, 100));
+        pr.depth = 1; pr.lds = LDS_BYTES;
+        report("probe: loads 1 step ahead, 2 / CU", time_ms(launch, &pr, 100));
+        pr.lds = 90 * 1024;
+        report("probe: loads 1 step ahead, forced to 1 / CU", time_ms(launch, &pr, 100));
+    }
+    return 0;
+}
