@@ -334,6 +334,18 @@ int main() {
     auto report = [&](const char *name, float ms) {
         printf("%-64s %7.1f us  %6.1f TF fp32-eq  %5.2f TB/s algorithmic\n", name, ms * 1e3, gf / ms, gb / ms);
     };
+    // the two-kernel alternative, all in-tree: fp32 epilogue (residual in place) with 256 x 256 tiles (cfg 1) or 128 x 256 tiles at
+    // two workgroups per CU (cfg 2), then omnitok_layernorm_planes over the result (one more read of c)
+    static InTree f32a, f32b;
+    f32a = it; f32a.g.epilogue = 0; f32a.g.out_planes = nullptr; f32a.g.out_planes_k = 0; f32a.g.ln_gamma = nullptr; f32a.g.ln_beta = nullptr; f32a.g.cfg = 1;
+    f32b = f32a; f32b.g.cfg = 2;
+    struct LnCtx { const float *x; long rows; const float *g, *b; float bound; void *planes; long m_pad; };
+    static LnCtx lc;
+    lc = LnCtx{dx2, M, dgamma, dbeta, 1.0e4f, out_in, (M + 255) / 256 * 256};
+    auto launch_ln = [](void *c) {
+        LnCtx *q = (LnCtx *)c;
+        if (omnitok_layernorm_planes(q->x, q->rows, 512, 1e-5f, q->g, q->b, q->bound, q->planes, q->m_pad, nullptr)) { printf("ln_planes: %s\n", omnitok_last_error()); exit(1); }
+    };
     for (int i = 0; i < 600; ++i) launch_in(&it);  // ~0.25 s at full load first: the shader clock settles at its power-capped value
     CK(hipDeviceSynchronize());
     for (int round = 0; round < 3; ++round) {
@@ -346,6 +358,11 @@ int main() {
         report("probe: loads 1 step ahead, 2 / CU", time_ms(launch, &pr, 100));
         pr.lds = 90 * 1024;
         report("probe: loads 1 step ahead, forced to 1 / CU", time_ms(launch, &pr, 100));
+        const float t1 = time_ms(launch_in, &f32a, 100), t2 = time_ms(launch_in, &f32b, 100), t3 = time_ms(launch_ln, &lc, 100);
+        report("in-tree fp32 epilogue + residual, 256 x 256 tiles (cfg 1)", t1);
+        report("in-tree fp32 epilogue + residual, 128 x 256 tiles, 2 / CU (cfg 2)", t2);
+        report("in-tree omnitok_layernorm_planes over c", t3);
+        printf("    two kernels: %.1f us (cfg 1) / %.1f us (cfg 2)\n", (t1 + t3) * 1e3, (t2 + t3) * 1e3);
     }
     return 0;
 }
