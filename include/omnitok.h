@@ -64,8 +64,9 @@ const char *omnitok_version(void);
  * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
  * staged in LDS; all bit-exact, profiles/r03_vq_variants.txt), "pl_stagger" (start delay step of persistent GEMM workgroups in
  * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant" (1 default: LDS-tiled -- the 64-channel kernel of peg_wide.h for
- * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, else the 32-channel time ring | 2 the 64-channel kernel whenever
- * the grid allows | 3 time ring only (1, 2, 3 bit-identical) | 0 register-blocked), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
+ * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, its one-plane form (9 taps, four workgroups per CU) for images,
+ * else the 32-channel time ring | 2 the 64-channel walk kernel whenever the grid allows | 3 time ring only (1, 2, 3 bit-identical)
+ * | 0 register-blocked), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* ------------------------------------------------------------------------------------------
@@ -86,6 +87,13 @@ int omnitok_layernorm(const float *x, const float *gamma, const float *beta, flo
  * (reference omnitokenizer.py:894-903, 1072-1084). */
 int omnitok_layernorm_transposed(const float *x, const float *gamma, const float *beta, float *y, int64_t n, int a,
                                  int c, int dim, float eps, omnitok_stream_t stream);
+/* The encoder's last norm_out LayerNorm (optionally with the token transpose above: transpose != 0) FUSED with pre_vq:
+ * z[row', 0:8] = l2norm(LayerNorm(x[row]) . w[8, dim]^T + b) (reference omnitokenizer.py:143-148 pre_vq_conv, :251-252
+ * F.normalize; l2 == 0 skips the normalisation), row' = the LayerNorm's output row.  The normalised tokens are not
+ * written.  Bit-identical to omnitok_layernorm[_transposed] followed by omnitok_pre_vq.  dim % 64 == 0, dim <= 1024. */
+int omnitok_layernorm_prevq(const float *x, const float *gamma, const float *beta, const float *w, const float *b,
+                            float *z, int64_t n, int a, int c, int dim, float eps, int transpose, int l2,
+                            omnitok_stream_t stream);
 
 /* Epilogue flags of omnitok_gemm */
 #define OMNITOK_GEMM_BIAS 1      /* + bias[n]                                               */

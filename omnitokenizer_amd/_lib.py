@@ -98,6 +98,7 @@ _PROTOS = {
     "omnitok_gather_rows": [P, P, c_int, P, I64, c_int, P, P],
     "omnitok_gather_rows_transposed": [P, P, c_int, P, I64, c_int, c_int, c_int, P, P],
     "omnitok_layernorm_transposed": [P, P, P, P, I64, c_int, c_int, c_int, c_float, P],
+    "omnitok_layernorm_prevq": [P, P, P, P, P, P, I64, c_int, c_int, c_int, c_float, c_int, c_int, P],
     "omnitok_token_resample": [P, P, c_int, I64, c_int, c_int, c_int, c_int, P],
     "omnitok_vae_sample": [P, P, P, P, P, P, I64, I64, c_int, c_int, P],
     "omnitok_post_vq": [P, c_int, I64, I64, c_int, P, P, P, c_int, P],

@@ -69,6 +69,8 @@ extern int g_attn_h2_dbg;
 extern int g_attn_vpack;
 extern int g_gemm_pl;
 extern int g_pl_min_tokens;
+extern int g_temporal_chunk;
+extern int g_prevq_fuse;
 extern int g_qkv_pl;
 extern int g_attn_window_mode;
 extern int g_pl_cfg;
@@ -93,6 +95,8 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "attn_vpack")) omnitok::g_attn_vpack = value;
     else if (!strcmp(name, "gemm_pl")) omnitok::g_gemm_pl = value;
     else if (!strcmp(name, "pl_min_tokens")) omnitok::g_pl_min_tokens = value;
+    else if (!strcmp(name, "temporal_chunk")) omnitok::g_temporal_chunk = value;
+    else if (!strcmp(name, "prevq_fuse")) omnitok::g_prevq_fuse = value;
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
     else if (!strcmp(name, "pl_stagger")) omnitok::g_pl_stagger = value;
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;

@@ -8,6 +8,7 @@
 #include <map>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -108,6 +109,7 @@ struct omnitok_engine {
     // arithmetic / data-flow modes of THIS engine: -1 = follow the process default (omnitok_set_option), else the value
     // given to omnitok_engine_set_option.  Two engines of one process can run different modes.
     int opt_gemm_mode = -1, opt_attn_mode = -1, opt_attn_vpack = -1, opt_gemm_pl = -1;
+    int opt_pl_min_tokens = -1, opt_temporal_chunk = -1;
     bool finalized = false;
     int inner_pad = 0;
     TransformerW enc_s, enc_t, dec_s, dec_t;
@@ -145,7 +147,7 @@ namespace omnitok {
 constexpr int N_BOUND_LAUNCHES = 64;  // row-statistics launches with ranges per encode / decode
 
 // process defaults of the per-engine modes (omnitok_set_option; engine_run.hip)
-extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl;
+extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl, g_pl_min_tokens, g_temporal_chunk, g_prevq_fuse;
 
 Geo geometry(const omnitok_config &c);
 bool walk_enc_grid(const char *block, int *gh, int *gw, int64_t *peak);
@@ -179,9 +181,15 @@ int eg_gemm(omnitok_engine *e, const float *a, int64_t lda, const float *w, int6
             const float *ln_stats = nullptr, const float *ln_g = nullptr, const float *ln_b = nullptr,
             int ln_cols = 0, float ln_bound = 0.0f, float *c2 = nullptr, int64_t ldc2 = 0, int split_col = 0,
             const VPack *vpk = nullptr, bool *vpacked = nullptr);
+// pre_vq fused behind the last norm_out of the encoder (omnitok_layernorm_prevq): z [L, 8] instead of LayerNorm rows in X
+struct PreVqFuse {
+    const float *w, *b;
+    float *z;
+    int l2;
+};
 // out_planes: the final LayerNorm goes to Y as hi|lo operand planes (static scale of tw.out_bound) instead of fp32 rows in X
 int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
-                    hipStream_t stream, bool transpose_out = false, bool out_planes = false);
+                    hipStream_t stream, bool transpose_out = false, bool out_planes = false, const PreVqFuse *pv = nullptr);
 int reset_bounds(omnitok_engine *e, int B, hipStream_t stream);
 void workspace_widths(const omnitok_engine *e, int64_t (&wd)[8]);
 int64_t workspace_bytes_for(const omnitok_engine *e, int64_t L);

@@ -147,8 +147,10 @@ static int check_attention_grid(const char *who, const std::string &block, int g
 
 // encoder up to the pre_vq input: leaves tokens [B, T', h, w, D] in e->X  (reference
 // omnitokenizer.py:881-947 OmniTokenizer_Encoder.forward / encode)
+// fuse_prevq: when nothing sits between the temporal Transformer's norm_out and pre_vq (no deferred pools) the two run as
+// one pass and the latent z lands in e->Z (*prevq_done = true); X then does NOT hold the normalised tokens.
 static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H, int W_, int *T_out, int *S_out,
-                         hipStream_t stream) {
+                         hipStream_t stream, bool fuse_prevq = false, bool *prevq_done = nullptr) {
     if (!e->finalized) {
         set_error("encode: engine not finalised (load the weights first)");
         return OMNITOK_ERR_STATE;
@@ -208,7 +210,11 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
     if (int rc = run_transformer(e, e->enc_s, B, T, &gh, &gw, true, stream, true)) return rc;
     const int S2 = gh * gw;  // pooling blocks shrink the grid, omnitokenizer.py:898-899
     const int64_t L2 = (int64_t)B * T * S2;
-    if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream, true)) return rc;
+    const bool fuse = fuse_prevq && g_prevq_fuse && !g.defer_s && !(g.defer_t && T > 1) && D % 64 == 0 && D <= 1024 &&
+                      c.codebook_dim == 8;
+    const PreVqFuse pvf{fuse ? W(e, k_pre_w(c)) : nullptr, fuse ? W(e, k_pre_b(c)) : nullptr, e->Z.p, c.l2_code};
+    if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream, true, false, fuse ? &pvf : nullptr)) return rc;
+    if (prevq_done) *prevq_done = fuse;
     // ---- deferred pools (reference omnitokenizer.py:907-914) ---------------------------------
     if (g.defer_s) {
         OT_RUN("pool", 1.25 * L2 * D * 4.0,
@@ -243,13 +249,15 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
         return OMNITOK_ERR_STATE;
     }
     int T = 0, S = 0;
-    if (int rc = encode_tokens(e, x, B, F, H, W_, &T, &S, stream)) return rc;
+    bool prevq_done = false;
+    if (int rc = encode_tokens(e, x, B, F, H, W_, &T, &S, stream, true, &prevq_done)) return rc;
     const omnitok_config &c = e->cfg;
     const int D = c.dim;
     const int64_t L = (int64_t)B * T * S;
     // ---- pre_vq + l2norm + nearest code (reference omnitokenizer.py:248-255) ----------------
-    OT_RUN("pre_vq", (double)L * D * 4.0,
-           omnitok_pre_vq(e->X.p, W(e, k_pre_w(c)), W(e, k_pre_b(c)), e->Z.p, L, D, 8, c.l2_code, stream));
+    if (!prevq_done)
+        OT_RUN("pre_vq", (double)L * D * 4.0,
+               omnitok_pre_vq(e->X.p, W(e, k_pre_w(c)), W(e, k_pre_b(c)), e->Z.p, L, D, 8, c.l2_code, stream));
     if (c.external_codebook) {
         // cosine similarity (l2_code): first argmax of the dot (vector_quantize_pytorch.py:646-650);
         // otherwise EuclideanCodebook: first argmax of -cdist (:463)
@@ -496,8 +504,13 @@ extern "C" int omnitok_engine_set_option(omnitok_engine *e, const char *name, in
         e->opt_attn_vpack = value;
     } else if (n == "gemm_pl") {
         e->opt_gemm_pl = value;
+    } else if (n == "pl_min_tokens") {
+        e->opt_pl_min_tokens = value;
+    } else if (n == "temporal_chunk") {
+        e->opt_temporal_chunk = value;
     } else {
-        set_error("engine_set_option: %s is not a per-engine option (gemm_mode, attn_mode, attn_vpack, gemm_pl)", name);
+        set_error("engine_set_option: %s is not a per-engine option (gemm_mode, attn_mode, attn_vpack, gemm_pl, pl_min_tokens, "
+                  "temporal_chunk)", name);
         return OMNITOK_ERR_INVALID;
     }
     return OMNITOK_OK;

@@ -22,8 +22,18 @@ int g_attn_vpack = 1;
 // when gemm_pl is 1 -- the plane GEMM works in 256 x 256 tiles with a deep LDS-DMA ring, and below ~48 row tiles its
 // launches leave most of the 256 CUs idle: one 256^2 image 4.09 ms vs 2.00 ms, 8 images 5.31 vs 4.59 ms, 16 images
 // 7.00 vs 7.59 ms (profiles/r04_small_batch_latency.txt).  0 = always planes (what the parity tests of that path set).
+// The threshold is also a per-engine option (omnitok_engine_set_option "pl_min_tokens", -1 = this process default): a
+// clip-sharded job pins it from the GLOBAL batch so that every rank takes the same data flow whatever its shard size.
 int g_gemm_pl = 1;
 int g_pl_min_tokens = 12288;
+// "temporal_chunk" (clips per chunk, 0 = off): a temporal 't' block runs its q|k|v plane GEMM and the temporal attention
+// kernel chunk by chunk -- GEMM(chunk) -> attention(chunk) back to back through ONE chunk-sized fp32 q|k|v buffer (31.5 MB
+// per 17x256^2 clip), so that the attention kernel's reads hit the 256 MiB Infinity Cache instead of HBM
+// (profiles/r05_temporal_chunk.txt).  Results are bit-identical to the unchunked launch: tiles never straddle a clip.
+int g_temporal_chunk = 0;
+// "prevq_fuse" 1 (default): omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (omnitok_layernorm_prevq,
+// bit-identical) whenever nothing sits between the two (no deferred pools); 0: LayerNorm store, then omnitok_pre_vq.
+int g_prevq_fuse = 1;
 // "qkv_pl" 1 (default, with gemm_pl): the q|k|v projection as a plane GEMM too -- one pass writes the row statistics and
 // the centred rows x - mean as planes (omnitok_stats_pack), the LayerNorm of the Q columns is folded into the weight and finished in the
 // epilogue, which for spatial attention also does RoPE + l2norm + scales and writes Q and K straight into the attention
@@ -39,8 +49,10 @@ int gemm_mode_of(const omnitok_engine *e) { return e->opt_gemm_mode >= 0 ? e->op
 int attn_mode_of(const omnitok_engine *e) { return e->opt_attn_mode >= 0 ? e->opt_attn_mode : g_attn_mode; }
 int attn_vpack_of(const omnitok_engine *e) { return e->opt_attn_vpack >= 0 ? e->opt_attn_vpack : g_attn_vpack; }
 int gemm_pl_of(const omnitok_engine *e, int64_t tokens) {
-    return (e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl) && tokens >= g_pl_min_tokens;
+    const int min_tokens = e->opt_pl_min_tokens >= 0 ? e->opt_pl_min_tokens : g_pl_min_tokens;
+    return (e->opt_gemm_pl >= 0 ? e->opt_gemm_pl : g_gemm_pl) && tokens >= min_tokens;
 }
+static int temporal_chunk_of(const omnitok_engine *e) { return e->opt_temporal_chunk >= 0 ? e->opt_temporal_chunk : g_temporal_chunk; }
 
 bool x3_ok(const omnitok_engine *e, int N, int K, int flags) {
     return gemm_mode_of(e) >= 1 && N % 32 == 0 && K % 32 == 0 && !(flags & OMNITOK_GEMM_LEAKY) &&
@@ -103,7 +115,7 @@ static int eg_gemm_pl(omnitok_engine *e, omnitok_pl_gemm g, const float *w, hipS
 // transpose_out: the final LayerNorm stores its rows in the OTHER stage's token order ('(b t)(h w)' <-> '(b h w) t'),
 // i.e. the rearrange that follows every Transformer on the path is fused into the norm_out store.
 int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int *ghp, int *gwp, bool spatial,
-                           hipStream_t stream, bool transpose_out, bool out_planes) {
+                           hipStream_t stream, bool transpose_out, bool out_planes, const PreVqFuse *pv) {
     const omnitok_config &c = e->cfg;
     const int D = c.dim, heads = c.heads;
     int gh = *ghp, gw = *gwp;
@@ -266,6 +278,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
             bool ao_planes = false;  // the attention kernel wrote its output as planes (AO) with row scales (ST)
             // Q from LN(x), K/V from the raw x (reference attention.py:404-412)
             bool qk_packed = false;  // the q|k launch wrote the packed Q / K planes itself (no attn_pack pass)
+            bool temporal_done = false;  // the chunked temporal stage ran GEMM and attention already
             const bool qkv_pl = pl && g_qkv_pl && ly.t.wqkv_fold && e->plw.count(ly.t.wqkv_fold) && bs;
             if (qkv_pl) {
                 const int64_t Lp = (L + 255) / 256 * 256;
@@ -331,7 +344,37 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                     g.c2 = KV;
                     g.ldc2 = 2 * D;
                     g.c_split_n = D;
-                    OT_RUN("gemm_qkv", gemm_f * 3 * D, omnitok_gemm_pl(&g, stream));
+                    const int chunk = (!spatial && T > 1) ? temporal_chunk_of(e) : 0;
+                    if (chunk > 0 && chunk < B && T <= 17 && S % 16 == 0 && rpc % 256 == 0) {
+                        // "temporal_chunk": GEMM(chunk) -> attention(chunk) through one chunk-sized q|k|v buffer that stays
+                        // in the Infinity Cache between the two kernels.  A clip is a whole number of 256-row tiles and of
+                        // 64-row plane blocks, so every launch computes exactly what the full launch computes for its rows.
+                        const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
+                        float *Qc = e->QKV.p, *KVc = e->QKV.p + (int64_t)chunk * rpc * D;
+                        for (int c0 = 0; c0 < B; c0 += chunk) {
+                            const int nb = std::min(chunk, B - c0);
+                            const int64_t r0 = (int64_t)c0 * rpc, Lc = (int64_t)nb * rpc;
+                            const int64_t pl_off = (r0 >> 6) * (int64_t)(D >> 5) * 8192;  // bytes: 8 KiB per 64 rows x 32 k
+                            omnitok_pl_gemm gc = g;
+                            gc.a = static_cast<const char *>(g.a) + pl_off;
+                            gc.a_scale = a_sc + r0;
+                            gc.fold_stats = e->ST.p + 2 * r0;
+                            gc.c = Qc;
+                            gc.c2 = KVc;
+                            gc.M = Lc;
+                            OT_RUN("gemm_qkv", 2.0 * (double)Lc * D * 3 * D, omnitok_gemm_pl(&gc, stream));
+                            // out_scale rows [r0, r0 + Lc) of ST: behind every (mean, rstd) pair a later chunk still reads
+                            OT_RUN("attn_temporal", 4.0 * Lc * D * 4.0,
+                                   omnitok_attn_temporal_planes(Qc, D, KVc, KVc + D, 2 * D, nullptr, D,
+                                                                reinterpret_cast<char *>(e->AO.p) + pl_off, e->ST.p + r0, ab_ao.stat,
+                                                                ab_ao.dev + 2 * c0, 2, S, (int64_t)nb * S, T, heads, ly.t.q_scale,
+                                                                ly.t.k_scale, 8.0f, c.causal_temporal, alibi, stream));
+                        }
+                        temporal_done = true;
+                        ao_planes = true;
+                    } else {
+                        OT_RUN("gemm_qkv", gemm_f * 3 * D, omnitok_gemm_pl(&g, stream));
+                    }
                 }
             } else if (fused && D % 256 == 0) {
                 // one launch on the merged weight: the LayerNorm is applied while the A tile is staged,
@@ -386,7 +429,7 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                            omnitok_attn_spatial(Q, ldq, KV, KV + D, ldkv, e->AO.p, D, B * T, S, heads, bias, gh, gw,
                                                 stream));
                 }
-            } else {
+            } else if (!temporal_done) {
                 const float *alibi = (c.legacy_attention && c.causal_temporal) ? e->alibi : nullptr;
                 const bool tp = pl && bs && T <= 17 && S % 16 == 0;
                 OT_RUN("attn_temporal", 4.0 * L * D * 4.0,
@@ -568,6 +611,14 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
     if (out_planes) {  // the consumer is a plane GEMM (to_pixels): LayerNorm + operand split in one pass, rows stay in place
         OT_RUN("layernorm", 2.0 * L * D * 4.0,
                omnitok_layernorm_planes(e->X.p, L, D, 1e-5f, tw.og, tw.ob, tw.out_bound, e->Y.p, (L + 255) / 256 * 256, stream));
+        *ghp = gh;
+        *gwp = gw;
+        return OMNITOK_OK;
+    }
+    if (pv) {  // encoder end: LayerNorm -> pre_vq -> l2norm in one pass, z rows in the order the LayerNorm would have stored
+        OT_RUN("pre_vq", 1.0 * L * D * 4.0,
+               omnitok_layernorm_prevq(e->X.p, tw.og, tw.ob, pv->w, pv->b, pv->z, B, spatial ? T : S, spatial ? S : T, D, 1e-5f,
+                                       transpose_out && T > 1, pv->l2, stream));
         *ghp = gh;
         *gwp = gw;
         return OMNITOK_OK;

@@ -67,6 +67,80 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         }
 }
 
+// The encoder's last norm_out LayerNorm with pre_vq (Linear dim -> 8, + bias, F.normalize; reference omnitokenizer.py:143-148,
+// 251-252) applied to the normalised row while it is still on chip: the row goes through a wave-private LDS block instead of
+// a 2 KiB HBM write + read per token.  Arithmetic = layernorm_kernel followed by pre_vq_kernel (vq.hip), operation for
+// operation (same lane -> element maps, same reduction trees), so z is bit-identical to the two-pass flow
+// (tests/test_gpu_ops.py::test_layernorm_prevq_matches_two_pass).  One row per wave; the four 16-lane DPP rows of the wave
+// take two of the eight output channels each.  z row = the (optionally transposed) output row of the LayerNorm.
+__global__ __launch_bounds__(256) void layernorm_prevq_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta, const float *__restrict__ w,
+                                                             const float *__restrict__ b, float *__restrict__ z, int64_t rows,
+                                                             int dim, float eps, int tr_a, int tr_c, int l2) {
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][256 * LN_MAX_V4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row_raw = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = row_raw < rows;
+    const int64_t row = live ? row_raw : rows - 1;
+    const int nv = (dim / 4 + 63) / 64;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
+    f32x4 v[LN_MAX_V4];
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = xr[lane + 64 * i];
+    float mean, rstd;
+    row_stats(v, nv, lane, dim, eps, mean, rstd);
+    int64_t orow = row;
+    if (tr_a > 0) {
+        const int64_t c = row % tr_c, ba = row / tr_c;
+        orow = ((ba / tr_a) * tr_c + c) * tr_a + ba % tr_a;
+    }
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
+    f32x4 *yr = reinterpret_cast<f32x4 *>(rowbuf[wave]);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i)
+        if (i < nv && (lane + 64 * i) * 4 < dim) {
+            const f32x4 g = g4[lane + 64 * i];
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e];
+            if (beta) {
+                const f32x4 bb = b4[lane + 64 * i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] += bb[e];
+            }
+            yr[lane + 64 * i] = o;
+        }
+    __syncthreads();
+    // pre_vq: DPP row g of the wave computes channels 2g, 2g + 1 with pre_vq_kernel's lane -> element map
+    const int l16 = lane & 15, grp = lane >> 4;
+    float acc[2] = {0.0f, 0.0f};
+    for (int i = l16 * 4; i < dim; i += 64) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(rowbuf[wave] + i);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + (2 * grp + cc) * dim + i);
+            acc[cc] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        }
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) acc[cc] = row16_allsum(acc[cc]) + b[2 * grp + cc];
+    float zc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) zc[c] = __shfl(acc[c & 1], (c >> 1) * 16);
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ss += zc[c] * zc[c];
+    if (l2) {
+        const float den = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(p=2, eps=1e-12), omnitokenizer.py:252
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zc[c] = zc[c] / den;
+    }
+    if (live && lane == 0) *reinterpret_cast<f32x4 *>(z + orow * 8) = f32x4{zc[0], zc[1], zc[2], zc[3]};
+    if (live && lane == 1) *reinterpret_cast<f32x4 *>(z + orow * 8 + 4) = f32x4{zc[4], zc[5], zc[6], zc[7]};
+}
+
 // statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
 // A operand (gemm_x3.hip / gemm_h2.hip), so LN(x) is never written to HBM.  One row per wave.
 __global__ __launch_bounds__(256) void row_stats_kernel(const float *__restrict__ x, int64_t rows, int dim, float eps,
@@ -432,6 +506,22 @@ extern "C" int omnitok_layernorm_transposed(const float *x, const float *gamma, 
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, y,
                        rows, dim, eps, (int64_t)0, (int64_t)0, (int64_t)0, a, c);
     OT_LAUNCH_CHECK("layernorm_transposed");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_layernorm_prevq(const float *x, const float *gamma, const float *beta, const float *w, const float *b,
+                                       float *z, int64_t n, int a, int c, int dim, float eps, int transpose, int l2,
+                                       omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && gamma && w && b && z, "layernorm_prevq: null pointer");
+    OT_CHECK_ARG(dim > 0 && dim % 64 == 0 && dim <= 256 * LN_MAX_V4 && a > 0 && c > 0, "layernorm_prevq: bad shape");
+    OT_CHECK_ARG(aligned16(x) && aligned16(z) && aligned16(gamma) && aligned16(w) && (!beta || aligned16(beta)),
+                 "layernorm_prevq: pointers must be 16-byte aligned");
+    const int64_t rows = n * a * c;
+    if (rows == 0) return OMNITOK_OK;
+    hipLaunchKernelGGL(layernorm_prevq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, w, b, z,
+                       rows, dim, eps, transpose ? a : 0, c, l2);
+    OT_LAUNCH_CHECK("layernorm_prevq");
     return OMNITOK_OK;
 }
 

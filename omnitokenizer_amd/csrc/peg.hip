@@ -223,6 +223,14 @@ extern "C" int omnitok_peg3d(const float *x, const float *w27, const float *bias
     // (221 vs 224 us) and a loss on long walks over large grids (17 planes of 64 x 64: 68 vs 62 us) -- hence the plane-count window
     const bool wide_ok = D % 64 == 0 && W % pegw::W_T == 0 && H % pegw::H_T == 0 &&
                          (int64_t)(W / pegw::W_T) * (H / pegw::H_T) * (D / 64) * B < (1ll << 31);
+    if (wide_ok && T == 1 && (g_peg_variant == 1 || g_peg_variant == 4)) {
+        // images: the one-plane kernel (9 taps, four workgroups per CU); "peg_variant" 2 keeps the walk kernel for the A/B
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(pegw::peg2d_wide_kernel), pegw::LDS_BYTES_2D)) return rc;
+        hipLaunchKernelGGL(pegw::peg2d_wide_kernel, dim3((unsigned)((int64_t)(W / pegw::W_T) * (H / pegw::H_T) * (D / 64) * B)), dim3(256),
+                           pegw::LDS_BYTES_2D, stream, x, w27, bias, y, B, H, W, D, causal ? 2 : 1);
+        OT_LAUNCH_CHECK("peg2d_wide");
+        return OMNITOK_OK;
+    }
     if (wide_ok && ((g_peg_variant == 1 && T >= 2 && T <= 8) || g_peg_variant == 2)) {
         if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(pegw::peg3d_wide_kernel), pegw::LDS_BYTES)) return rc;
         hipLaunchKernelGGL(pegw::peg3d_wide_kernel, dim3((unsigned)((int64_t)(W / pegw::W_T) * (H / pegw::H_T) * (D / 64) * B)), dim3(256),

@@ -146,5 +146,85 @@ __global__ __launch_bounds__(256, 2) void peg3d_wide_kernel(const float *__restr
         __syncthreads();  // every wave is done with both slots' reads of this step before the next plane is stored
     }
 }
+
+// One plane per clip (T == 1: images, reference attention.py:298-338 on a [B, 1, H, W, D] view): the walk above degenerates to
+// load -> compute -> store with two workgroups per CU and nothing overlapping (0.40 of HBM peak at C2).  Here only the
+// plane's own 9 taps (time tap dt = 2 causal / 1 non-causal) and ONE output set are live: ~100 registers and one ring slot, so
+// four workgroups per CU overlap each other's phases.  Same tile, same loader, and every output receives its taps in the order
+// (dh, dw) the walk gives them: bit-identical to peg3d_wide_kernel / peg3d_lds_kernel.
+constexpr int LDS_BYTES_2D = PLANE_V4 * 16;                   // 27648: up to five workgroups per CU
+
+__global__ __launch_bounds__(256, 4) void peg2d_wide_kernel(const float *__restrict__ x, const float *__restrict__ w27,
+                                                             const float *__restrict__ bias, float *__restrict__ y,
+                                                             int B, int H, int W, int D, int dt) {
+    extern __shared__ __attribute__((aligned(16))) float pegw_smem[];
+    f32x4 *pl = reinterpret_cast<f32x4 *>(pegw_smem);
+    const int tid = threadIdx.x;
+    const int c4 = tid & 15, wcol = tid >> 4;
+    const int wtiles = W / W_T, htiles = H / H_T;
+    const int per = wtiles * htiles, ngroups = gridDim.x / per;
+    const int n = blockIdx.x;
+    int grp, tile;
+    {
+        const int xcd = n & 7, j = n >> 3;
+        const int full = (ngroups / 8) * 8;
+        const int g = xcd + 8 * (j / per);
+        if (g < full) {
+            grp = g;
+            tile = j % per;
+        } else {
+            const int rest = n - full * per;
+            grp = full + rest / per;
+            tile = rest % per;
+        }
+    }
+    const int w0 = (tile % wtiles) * W_T, h0 = (tile / wtiles) * H_T;
+    const int nslab = D >> 6;
+    const int slab = grp % nslab, b = grp / nslab;
+    const int d4n = D >> 2;
+    const int ch4 = slab * C4 + c4;
+    const f32x4 *xb = reinterpret_cast<const f32x4 *>(x) + (int64_t)b * H * W * d4n;
+    const f32x4 *zero = reinterpret_cast<const f32x4 *>(peg_wide_zero);
+    f32x4 stage[LOADS];
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k) {
+        const int i = tid + 256 * k;
+        const int pos = i >> 4, q = i & 15;
+        const int r = pos / HW, c = pos - r * HW;
+        const int hh = h0 - 1 + r, ww = w0 - 1 + c;
+        const bool in = i < PLANE_V4 && hh >= 0 && hh < H && ww >= 0 && ww < W;
+        stage[k] = *(in ? xb + (hh * W + ww) * d4n + slab * C4 + q : zero);
+    }
+    f32x4 wt[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k] = reinterpret_cast<const f32x4 *>(w27)[(dt * 9 + k) * d4n + ch4];
+    const f32x4 bv = reinterpret_cast<const f32x4 *>(bias)[ch4];
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k) {
+        const int i = tid + 256 * k;
+        if (i < PLANE_V4) pl[i] = stage[k];
+    }
+    __syncthreads();
+    f32x4 o[H_T];
+#pragma unroll
+    for (int r = 0; r < H_T; ++r) o[r] = bv;
+#pragma unroll
+    for (int r = 0; r < HH; ++r) {
+        f32x4 v[3];
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw) v[dw] = pl[(r * HW + wcol + dw) * C4 + c4];
+#pragma unroll
+        for (int dw = 0; dw < 3; ++dw)
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+                if (r - dh >= 0 && r - dh < H_T) o[r - dh] += v[dw] * wt[dh * 3 + dw];
+    }
+    f32x4 *yo = reinterpret_cast<f32x4 *>(y) + (((int64_t)b * H + h0) * W + w0 + wcol) * d4n + ch4;
+#pragma unroll
+    for (int r = 0; r < H_T; ++r) {
+        const f32x4 xc = pl[((r + 1) * HW + wcol + 1) * C4 + c4];
+        yo[(int64_t)r * W * d4n] = o[r] + xc;
+    }
+}
 }  // namespace pegw
 }  // namespace omnitok

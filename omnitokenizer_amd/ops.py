@@ -79,6 +79,19 @@ def layernorm_transposed(x, gamma, beta, n, a, c, eps=1e-5):
     return y
 
 
+def layernorm_prevq(x, gamma, beta, w, b, n, a, c, transpose=True, l2=True, eps=1e-5):
+    """z [n*a*c, 8] = l2norm(LayerNorm(x) @ w.T + b), rows in (n, c, a) order when transpose (the encoder's last norm_out
+    fused with pre_vq, reference omnitokenizer.py:143-148, 251-252); bit-identical to layernorm[_transposed] + pre_vq."""
+    x = _req(x, "x")
+    dim = x.shape[-1]
+    assert x.numel() == n * a * c * dim
+    z = torch.empty(n * a * c, 8, device=x.device, dtype=torch.float32)
+    _opt(beta, "beta", dim)
+    check(_lib.load().omnitok_layernorm_prevq(_p(x), _p(_req(gamma, "gamma")), _p(beta), _p(_req(w, "w")), _p(_req(b, "b")),
+                                              _p(z), n, a, c, dim, eps, int(transpose), int(l2), _stream()), "layernorm_prevq")
+    return z
+
+
 def linear(x, weight, bias=None, residual=None, leaky=False):
     """y = x @ weight.T (+bias) (+leaky_relu 0.1) (+residual); weight [N, K], K % 32 == 0."""
     x = _req(x, "x")

@@ -46,7 +46,8 @@ def assert_ids_match_or_near_tie(ids, ids_ref, z_ours, codebook, name):
     bad = (ids != ids_ref).nonzero().flatten()
     if bad.numel() == 0:
         return 0
-    assert bad.numel() <= max(1, ids.numel() // 1000), f"{name}: {bad.numel()} of {ids.numel()} ids differ"
+    # allowance: the observed order of magnitude (3 of 163 840 on the full bench batch = 1.8e-5), not a percentage
+    assert bad.numel() <= max(1, ids.numel() // 10000), f"{name}: {bad.numel()} of {ids.numel()} ids differ"
     z = z_ours.reshape(-1, z_ours.shape[-1]).cpu().double()[bad]
     E = codebook.double()
     d_ours = ((z - E[ids[bad]]) ** 2).sum(1)
@@ -270,6 +271,40 @@ def test_small_calls_take_the_fp32_activation_flow(models):
         assert all(torch.equal(a, b) for a, b in zip(auto, forced)), (n, planes)
         assert not torch.equal(auto[1], other[1])     # the two flows round differently: the switch is observable
         assert (auto[1] - other[1]).abs().max().item() < 2 * max(Z_TOL, 8.0 * c.fp32_noise_z)
+
+
+def test_prevq_fusion_and_temporal_chunks_are_bit_identical(models):
+    """Two r05 data-flow changes that must not change a bit: "prevq_fuse" (pre_vq inside the encoder's last LayerNorm pass)
+    and "temporal_chunk" (the temporal q|k|v GEMM + attention run chunk by chunk through an Infinity-Cache-sized buffer;
+    process option and per-engine option).  8 distinct 17x256^2 clips, ragged last chunk (3 + 3 + 2) included."""
+    from omnitokenizer_amd import _lib
+    c = GoldenCase(HEAVY_BATCH_CASE)
+    m = models(c)
+    x = c.x.cuda()
+
+    def run(**opts):
+        try:
+            for k, v in opts.items():
+                _lib.set_option(k, v)
+            ids, z = m.encode(x, c.is_image, return_latents=True)
+            return ids.cpu(), z.cpu(), m.decode(ids, c.is_image).cpu()
+        finally:
+            _lib.set_option("prevq_fuse", 1)
+            _lib.set_option("temporal_chunk", 0)
+
+    base = run(prevq_fuse=0, temporal_chunk=0)
+    for opts in (dict(prevq_fuse=1), dict(temporal_chunk=4), dict(temporal_chunk=3), dict(temporal_chunk=1),
+                 dict(temporal_chunk=8), dict(temporal_chunk=100)):
+        got = run(**opts)
+        assert all(torch.equal(a, b) for a, b in zip(base, got)), opts
+    m._sync_engine()
+    lib = _lib.load()
+    try:
+        assert lib.omnitok_engine_set_option(m._engine, b"temporal_chunk", 2) == 0
+        got = run()
+    finally:
+        lib.omnitok_engine_set_option(m._engine, b"temporal_chunk", -1)
+    assert all(torch.equal(a, b) for a, b in zip(base, got))
 
 
 def test_two_engines_with_different_modes_in_one_process():

@@ -159,7 +159,8 @@ def test_peg3d(ops, shape, causal, variant):
     assert maxerr(out_t, ref_t) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 1, 4, 16), (1, 6, 16, 32), (1, 7, 8, 16), (1, 17, 8, 16), (3, 2, 64, 16)])
+@pytest.mark.parametrize("shape", [(2, 5, 32, 32), (1, 1, 4, 16), (5, 1, 32, 32), (3, 1, 8, 48), (1, 6, 16, 32), (1, 7, 8, 16), (1, 17, 8, 16),
+                                   (3, 2, 64, 16)])
 @pytest.mark.parametrize("causal", [True, False])
 def test_peg3d_wide_slab_kernel_is_bit_identical(ops, shape, causal):
     """csrc/peg_wide.h (64-channel slab, two ring slots, every plane read from LDS once and accumulated into the three output
@@ -338,6 +339,25 @@ def test_attn_temporal(ops, T, causal, alibi):
     out = ops.attn_temporal(dev(q), kvd[:, : h * d], kvd[:, h * d:], cols, T, h, dev(qs), dev(ks), causal,
                             None if slopes is None else dev(slopes))
     assert maxerr(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 5), (2, 16, 17), (5, 7, 1), (1, 1, 3)])
+@pytest.mark.parametrize("l2", [True, False])
+def test_layernorm_prevq_matches_two_pass(ops, shape, l2):
+    """The encoder's last LayerNorm fused with pre_vq (omnitok_layernorm_prevq) == layernorm[_transposed] followed by
+    pre_vq, bit for bit (with and without the token transpose, ragged row counts, beta = None)."""
+    n, a, c = shape
+    D = 512
+    x = dev(rnd(n * a * c, D, seed=171) * 3 + 0.5)
+    g, b = dev(rnd(D, seed=172) * 0.3 + 1), dev(rnd(D, seed=173) * 0.2)
+    w, wb = dev(rnd(8, D, seed=174) * 0.05), dev(rnd(8, seed=175) * 0.1)
+    for beta in (b, None):
+        want = ops.pre_vq(ops.layernorm_transposed(x, g, beta, n, a, c), w, wb, l2)
+        got = ops.layernorm_prevq(x, g, beta, w, wb, n, a, c, True, l2)
+        assert torch.equal(got, want)
+        want = ops.pre_vq(ops.layernorm(x, g, beta), w, wb, l2)
+        got = ops.layernorm_prevq(x, g, beta, w, wb, n, a, c, False, l2)
+        assert torch.equal(got, want)
 
 
 def test_pre_vq_and_dequant(ops):
