@@ -108,6 +108,10 @@ def run(a):
          else synth.synth_video(B, a.frames, a.resolution, seed=1234 + rank)).cuda().contiguous()
     n_total = B * world
 
+    if world > 1:  # one data flow for every rank, decided from the global batch (ragged shards would otherwise differ)
+        from omnitokenizer_amd import dist as od
+        t_, h_, w_ = model.latent_dims(a.frames, a.resolution, a.resolution)
+        od.pin_data_flow(model, n_total, t_ * h_ * w_)
     res = launch.timed_sharded_steps(info, lambda xs: model.encode(xs, is_image),
                                      lambda i: model.decode(i, is_image), x, a.steps, a.warmup,
                                      native_gather=a.native_gather)
@@ -335,14 +339,34 @@ def run(a):
                         best_thr, best_t = thr, t
             ncpu_used = best_thr
             torch.set_num_threads(ncpu_used)
+            # what is timed: the REFERENCE ITSELF wherever it is mounted (the build container: /root/reference through the
+            # stub harness of SURVEY.md 8(c), kind "reference"); on the GPU box, which has no /root/reference, the oracle
+            # port (kind "port", calibrated against the reference below)
+            from oracle import ref_harness as rh
+            ref_model = None
+            if rh.reference_available():
+                try:
+                    ref_model = rh.build_reference_model(args)
+                    ref_model.load_state_dict(sd, strict=False)
+                except Exception:  # noqa: BLE001
+                    ref_model = None
+            xin = xs[:, :, 0].contiguous() if (is_image and xs.dim() == 5) else xs
+
+            def cpu_step():
+                if ref_model is not None:
+                    with rh.attention_mode(cfg.attention_mode):
+                        return ref_model.decode(ref_model.encode(xin, is_image), is_image)
+                return orc.decode(sd, orc.encode(sd, xs, is_image, cfg), is_image, cfg)
             with torch.no_grad():
                 taps = {}
                 ids_ref = orc.encode(sd, xs, is_image, cfg, taps=taps)   # warm-up, also the parity reference
                 rec_ref = orc.decode(sd, ids_ref, is_image, cfg)
+                if ref_model is not None:
+                    cpu_step()
                 reps, spent = 0, 0.0
                 while reps < 1 or (spent < a.cpu_seconds and reps < 50):
                     t = time.perf_counter()
-                    orc.decode(sd, orc.encode(sd, xs, is_image, cfg), is_image, cfg)
+                    cpu_step()
                     spent += time.perf_counter() - t
                     reps += 1
             per = spent / reps
@@ -359,12 +383,15 @@ def run(a):
             except Exception:
                 ref_over_port, cal_src = None, None
             out["cpu_baseline"] = {"value": round(tokens_per_clip / per, 1), "unit": "patches/s", "cores": ncpu_used,
-                                   "kind": "port", "reference_over_port": ref_over_port,
+                                   "kind": "reference" if ref_model is not None else "port",
+                                   "reference_over_port": ref_over_port,
                                    "reference_over_port_source": cal_src,
                                    "host_logical_cpus": ncpu, "cpu": cpu_model,
                                    "sample": f"1 clip {a.frames}x{a.resolution}x{a.resolution} encode+decode, "
-                                             f"{reps} timed reps after 1 warm-up, torch CPU fp32 oracle "
-                                             f"(ATen/MKL, {ncpu_used} threads = best of a 8..128 probe)"}
+                                             f"{reps} timed reps after 1 warm-up, "
+                                             + ("the unmodified reference (oracle/ref_harness.py)" if ref_model is not None
+                                                else "torch CPU fp32 oracle port")
+                                             + f" (ATen/MKL, {ncpu_used} threads = best of a 8..128 probe)"}
             g_ids, g_z = model.encode(x[:1].contiguous(), is_image, return_latents=True)
             g_rec = model.decode(ids_ref.cuda(), is_image).cpu()
             out["parity"] = {"id_flips_vs_oracle": int((g_ids.cpu() != ids_ref).sum()), "ids": int(ids_ref.numel()),
@@ -376,7 +403,7 @@ def run(a):
         if world == 1 and wl_name == "C3" and B == 32 and a.gemm_mode == 2 and not a.option and not a.no_also:
             out["also"] = also_extras(model, x, sd, a)
         print(json.dumps(out), flush=True)
-    launch.finish(info)
+    launch.finish(info, native_timed=bool(a.native_gather))
 
 
 def _time_steps(model, x, is_image, steps, warmup=1):
@@ -435,20 +462,46 @@ def also_extras(model, x, sd, a):
     except Exception as e:  # noqa: BLE001
         also["c5"] = {"error": repr(e)}
     try:
+        # interactive sizes (the callers transformer_eval.py:71,120 / Diffusion/DiT/sample_ddp.py:162 decode a handful of
+        # samples): encode + decode latency of ONE image and ONE clip with the same weights, synchronised per call
+        lat = {}
+        for tag, xs_, img in (("1img", synth.synth_image(1, 256, seed=7).cuda(), True),
+                              ("1clip", synth.synth_video(1, 17, 256, seed=7).cuda(), False)):
+            for _ in range(3):
+                model.decode(model.encode(xs_, img), img)
+            torch.cuda.synchronize()
+            reps = 20
+            t = time.perf_counter()
+            for _ in range(reps):
+                model.decode(model.encode(xs_, img), img)
+                torch.cuda.synchronize()
+            lat[f"latency_{tag}_ms"] = round((time.perf_counter() - t) / reps * 1e3, 3)
+        also.update(lat)
+        also["latency_note"] = "encode+decode of one 256x256 image / one 17x256x256 clip, host-synchronised per call, 20 reps"
+    except Exception as e:  # noqa: BLE001
+        also["latency_error"] = repr(e)
+    try:
         from tests.helpers import GoldenCase
         c = GoldenCase("heavy_s2_sdpa_r256_vid17")
         mh = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
         mh.load_state_dict(c.sd, strict=True)
         mh = mh.cuda().eval()
         r = {}
-        for tag, gm, am in (("default", -1, -1), ("strict_fp32", 0, 0)):
+        # the fixture is ONE clip = 5120 tokens, below "pl_min_tokens": on the process default it runs the small-call flow
+        # (fp32 activations), NOT the plane flow the timed C3 batch runs -- so the plane flow gets its own arm
+        # (per-engine pl_min_tokens = 0) and every arm says which flow it ran
+        for tag, gm, am, mt in (("default_plane_flow", -1, -1, 0), ("default_small_call_flow", -1, -1, 1 << 30),
+                                ("strict_fp32", 0, 0, -1)):
             mh.set_option("gemm_mode", gm)
             mh.set_option("attn_mode", am)
+            mh.set_option("pl_min_tokens", mt)
             ids, z = mh.encode(c.x.cuda(), False, return_latents=True)
             rec = mh.decode(c.ids.cuda(), False)
             zerr = float((z.cpu() - c.z).abs().max())
             perr = float((c.strided(rec.cpu()) - c.recon).abs().max())
-            r[tag] = {"id_flips_vs_reference": int((ids.cpu() != c.ids).sum()), "ids": int(c.ids.numel()),
+            r[tag] = {"flow": {0: "planes (what the timed C3 step runs)", 1 << 30: "fp32 activations (calls below pl_min_tokens)"}.get(
+                          mt, "fp32-input MFMA kernels"),
+                      "id_flips_vs_reference": int((ids.cpu() != c.ids).sum()), "ids": int(c.ids.numel()),
                       "z_max_abs_err": zerr, "z_err_over_reference_fp32_noise": round(zerr / c.fp32_noise_z, 2),
                       "pixel_max_abs_err": perr, "pixel_err_over_reference_fp32_noise": round(perr / c.fp32_noise_pix, 2)}
         r["fixture"] = ("tests/golden/heavy_s2_sdpa_r256_vid17.npz: the reference's own outputs on heavy-tailed weights, one "

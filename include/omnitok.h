@@ -50,8 +50,13 @@ const char *omnitok_version(void);
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
  *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
  *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
- *   "pl_min_tokens" 12288 (default, process-wide) calls with fewer tokens (B * T' * h * w) take the gemm_pl 0 data flow: below
- *                ~48 row tiles the 256 x 256 plane GEMM leaves most CUs idle (one image 4.1 ms vs 2.0 ms) | 0 always planes
+ *   "pl_min_tokens" 12288 (default) calls with fewer tokens (B * T' * h * w) take the gemm_pl 0 data flow: below
+ *                ~48 row tiles the 256 x 256 plane GEMM leaves most CUs idle (one image 4.1 ms vs 2.0 ms) | 0 always planes.
+ *                Also a per-engine option (omnitok_engine_set_option): the two flows round differently (both inside the
+ *                parity bars), so a clip's latent bits depend on the size of the call it is in unless the engine pins it
+ *   "temporal_chunk" 0 (default; also per engine) > 0: temporal blocks run GEMM(chunk of clips) -> attention(chunk) through
+ *                one chunk-sized q|k|v buffer (bit-identical; measured slower at C3, profiles/r05_temporal_chunk.txt)
+ *   "prevq_fuse" 1 (default) omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (bit-identical) | 0 two passes
  *   "attn_window_mode" 1 (default, process-wide, with gemm_pl / qkv_pl) window attention on the fp16 matrix cores from packed
  *                operands (omnitok_stats_pack_windows -> packing epilogues -> omnitok_attn_window_h2) | 0 fp32 q|k|v and the
  *                fp32-MFMA kernel omnitok_attn_window_planes
@@ -69,6 +74,9 @@ const char *omnitok_version(void);
  * | 0 register-blocked), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
+/* Reads the process default of a data-flow option ("gemm_mode", "attn_mode", "gemm_pl", "pl_min_tokens", "temporal_chunk",
+ * "prevq_fuse"): what a clip-sharded job consults to pin ONE flow for all its ranks (omnitokenizer_amd/dist.py pin_data_flow). */
+int omnitok_get_option(const char *name, int *value);
 /* ------------------------------------------------------------------------------------------
  * Per-operator entry points (each is one HIP kernel family; the engine below chains them).
  * They are exported so that every operator is parity-tested against the oracle on its own.
@@ -90,7 +98,7 @@ int omnitok_layernorm_transposed(const float *x, const float *gamma, const float
 /* The encoder's last norm_out LayerNorm (optionally with the token transpose above: transpose != 0) FUSED with pre_vq:
  * z[row', 0:8] = l2norm(LayerNorm(x[row]) . w[8, dim]^T + b) (reference omnitokenizer.py:143-148 pre_vq_conv, :251-252
  * F.normalize; l2 == 0 skips the normalisation), row' = the LayerNorm's output row.  The normalised tokens are not
- * written.  Bit-identical to omnitok_layernorm[_transposed] followed by omnitok_pre_vq.  dim % 64 == 0, dim <= 1024. */
+ * written.  Bit-identical to omnitok_layernorm[_transposed] followed by omnitok_pre_vq.  dim 256, 512 or 1024. */
 int omnitok_layernorm_prevq(const float *x, const float *gamma, const float *beta, const float *w, const float *b,
                             float *z, int64_t n, int a, int c, int dim, float eps, int transpose, int l2,
                             omnitok_stream_t stream);

@@ -162,6 +162,7 @@ _PROTOS = {
     "omnitok_comm_allgather_i32": [P, P, P, I64, P],
     "omnitok_comm_allgather_ids": [P, P, P, I64, P],
     "omnitok_set_option": [c_char_p, c_int],
+    "omnitok_get_option": [c_char_p, POINTER(c_int)],
     "omnitok_debug_set_gemm_trace": [P],
     "omnitok_debug_mfma_peak": [P, P, c_int, c_int, c_int, P, P],
     "omnitok_last_error": [],
@@ -205,6 +206,12 @@ def load():
         if lib.omnitok_set_option(k.strip().encode(), int(v)) != 0:
             raise OmnitokError(lib.omnitok_last_error().decode())
     return lib
+
+
+def get_option(name: str) -> int:
+    v = c_int()
+    check(load().omnitok_get_option(name.encode(), ctypes.byref(v)), "get_option")
+    return v.value
 
 
 def set_option(name: str, value: int):

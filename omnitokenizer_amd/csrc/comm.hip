@@ -83,6 +83,19 @@ __global__ void widen_ids_kernel(const int32_t *__restrict__ in, int64_t *__rest
 
 }  // namespace
 
+// The communicator is bound to the device it was created on (ncclCommInitRank): staging memory and the narrow / widen
+// launches must land there even when the caller's current device is another one (one process driving several GPUs).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
 struct omnitok_comm {
     NcclComm comm = nullptr;
     int rank = 0, world = 1, device = 0;
@@ -130,6 +143,7 @@ extern "C" int omnitok_comm_create(const unsigned char *id, int rank, int world,
 
 extern "C" void omnitok_comm_destroy(omnitok_comm *c) {
     if (!c) return;
+    DeviceGuard guard(c->device);
     const Rccl *r = rccl();
     if (r && c->comm) r->comm_destroy(c->comm);
     if (c->stage) (void)hipFree(c->stage);
@@ -144,6 +158,7 @@ extern "C" int omnitok_comm_allgather_i32(omnitok_comm *c, const int32_t *send, 
     OT_CHECK_ARG(c && c->comm, "comm_allgather: no communicator");
     OT_CHECK_ARG(count >= 0 && (count == 0 || (send && recv)), "comm_allgather: bad arguments");
     if (count == 0) return OMNITOK_OK;
+    DeviceGuard guard(c->device);
     const Rccl *r = rccl();
     OT_RCCL(r, r->all_gather(send, recv, (size_t)count, kNcclInt32, c->comm, static_cast<hipStream_t>(stream_)));
     return OMNITOK_OK;
@@ -155,6 +170,7 @@ extern "C" int omnitok_comm_allgather_ids(omnitok_comm *c, const int64_t *ids_lo
     OT_CHECK_ARG(c && c->comm, "comm_allgather_ids: no communicator");
     OT_CHECK_ARG(count >= 0 && (count == 0 || (ids_local && ids_all)), "comm_allgather_ids: bad arguments");
     if (count == 0) return OMNITOK_OK;
+    DeviceGuard guard(c->device);
     if (count > c->stage_count) {
         if (c->stage) OT_HIP(hipFree(c->stage));
         c->stage = nullptr;

@@ -113,6 +113,22 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     return OMNITOK_OK;
 }
 
+// current process default of a data-flow option (what an engine follows unless omnitok_engine_set_option pinned its own)
+extern "C" int omnitok_get_option(const char *name, int *value) {
+    if (!name || !value) return OMNITOK_ERR_INVALID;
+    if (!strcmp(name, "gemm_mode")) *value = omnitok::g_gemm_mode;
+    else if (!strcmp(name, "attn_mode")) *value = omnitok::g_attn_mode;
+    else if (!strcmp(name, "gemm_pl")) *value = omnitok::g_gemm_pl;
+    else if (!strcmp(name, "pl_min_tokens")) *value = omnitok::g_pl_min_tokens;
+    else if (!strcmp(name, "temporal_chunk")) *value = omnitok::g_temporal_chunk;
+    else if (!strcmp(name, "prevq_fuse")) *value = omnitok::g_prevq_fuse;
+    else {
+        omnitok::set_error("get_option: %s is not a readable option", name);
+        return OMNITOK_ERR_INVALID;
+    }
+    return OMNITOK_OK;
+}
+
 extern "C" int omnitok_debug_set_gemm_trace(long long *dev_ptr) {
     omnitok::g_gemm_trace = dev_ptr;
     return OMNITOK_OK;

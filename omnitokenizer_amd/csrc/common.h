@@ -73,6 +73,26 @@ __device__ __forceinline__ float row16_allsum(float v) {
     return v;
 }
 
+// pre_vq arithmetic shared by pre_vq_kernel (vq.hip) and layernorm_prevq_kernel (norm.hip): stated operation by operation
+// (no compiler contraction choices), so that the two kernels produce the same bits whatever surrounds the call
+__device__ __forceinline__ float prevq_dot4(const float x0, const float x1, const float x2, const float x3, const float w0,
+                                            const float w1, const float w2, const float w3) {
+#pragma clang fp contract(off)
+    const float a = __builtin_fmaf(x0, w0, x1 * w1);
+    const float b = __builtin_fmaf(x2, w2, x3 * w3);
+    return a + b;
+}
+// z[0..8) -> z / max(||z||, 1e-12) (F.normalize, reference omnitokenizer.py:252); sequential sum of squares
+__device__ __forceinline__ void prevq_l2norm8(float (&z)[8]) {
+#pragma clang fp contract(off)
+    float ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) ss = __builtin_fmaf(z[c], z[c], ss);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) z[c] = z[c] / den;
+}
+
 __device__ __forceinline__ float row16_allmax(float v) {
     v = fmaxf(v, dpp_f32<0xB1>(v));
     v = fmaxf(v, dpp_f32<0x4E>(v));

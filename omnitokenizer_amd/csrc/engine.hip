@@ -210,7 +210,7 @@ static int encode_tokens(omnitok_engine *e, const float *x, int B, int F, int H,
     if (int rc = run_transformer(e, e->enc_s, B, T, &gh, &gw, true, stream, true)) return rc;
     const int S2 = gh * gw;  // pooling blocks shrink the grid, omnitokenizer.py:898-899
     const int64_t L2 = (int64_t)B * T * S2;
-    const bool fuse = fuse_prevq && g_prevq_fuse && !g.defer_s && !(g.defer_t && T > 1) && D % 64 == 0 && D <= 1024 &&
+    const bool fuse = fuse_prevq && g_prevq_fuse && !g.defer_s && !(g.defer_t && T > 1) && (D == 256 || D == 512 || D == 1024) &&
                       c.codebook_dim == 8;
     const PreVqFuse pvf{fuse ? W(e, k_pre_w(c)) : nullptr, fuse ? W(e, k_pre_b(c)) : nullptr, e->Z.p, c.l2_code};
     if (int rc = run_transformer(e, e->enc_t, B, T, &gh, &gw, false, stream, true, false, fuse ? &pvf : nullptr)) return rc;
@@ -344,7 +344,9 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     // tensor after norm_out, no [L, K] pixel rows, no un-patchify pass.
     bool plain_blocks = true;  // no pooling / Up blocks in the last Transformer: its grid is the token grid
     for (const char *q = c.dec_block; *q; ++q) plain_blocks = plain_blocks && (*q == 't' || *q == 'w');
-    const bool px_pl = plain_blocks && gemm_pl_of(e, (int64_t)B * T2 * gh2 * gw2) && gemm_mode_of(e) == 2 && D == 512 && !c.patch_embed_cnn && S % 256 == 0 && p == 8 && gw2 % 32 == 0 &&
+    const bool px_pl = plain_blocks && gemm_pl_of(e, (int64_t)B * T2 * gh2 * gw2) && gemm_mode_of(e) == 2 && D == 512 && !c.patch_embed_cnn && S % 256 == 0 && p == 8 && gw2 % 32 == 0 && gh2 * p == H &&
+                       aligned16(pixels_out) &&  // the un-patchify epilogue's own preconditions (gemm_pl.hip PL_UNPATCH): a caller
+                                                 // whose output is only 4-byte aligned takes the gemm + unpatchify path instead
                        e->plw.count(e->px_w[0]) && (T2 == 1 || e->plw.count(e->px_w[1])) && e->dec_s.out_bound > 0.0f &&
                        e->dec_s.out_bound < 1e30f;
     if (int rc = run_transformer(e, e->dec_s, B, T2, &ghc, &gwc, true, stream, false, px_pl)) return rc;

@@ -27,6 +27,13 @@ __device__ __forceinline__ void row_stats(const f32x4 *v, int nv, int lane, int 
     rstd = 1.0f / sqrtf(q / (float)dim + eps);
 }
 
+// (v - mean) * rstd * gamma as three separately rounded operations: what layernorm_kernel has always computed (the bias add
+// sits in its own branch), stated explicitly so that every kernel sharing it rounds the same way
+__device__ __forceinline__ float ln_apply(float v, float mean, float rstd, float g) {
+#pragma clang fp contract(off)
+    return (v - mean) * rstd * g;
+}
+
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, float *__restrict__ y,
                                                         int64_t rows, int dim, float eps, int64_t rpg,
@@ -57,7 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             const f32x4 g = g4[lane + 64 * i];
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e];
+            for (int e = 0; e < 4; ++e) o[e] = ln_apply(v[i][e], mean, rstd, g[e]);
             if (beta) {
                 const f32x4 b = b4[lane + 64 * i];
 #pragma unroll
@@ -70,75 +77,87 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 // The encoder's last norm_out LayerNorm with pre_vq (Linear dim -> 8, + bias, F.normalize; reference omnitokenizer.py:143-148,
 // 251-252) applied to the normalised row while it is still on chip: the row goes through a wave-private LDS block instead of
 // a 2 KiB HBM write + read per token.  Arithmetic = layernorm_kernel followed by pre_vq_kernel (vq.hip), operation for
-// operation (same lane -> element maps, same reduction trees), so z is bit-identical to the two-pass flow
-// (tests/test_gpu_ops.py::test_layernorm_prevq_matches_two_pass).  One row per wave; the four 16-lane DPP rows of the wave
-// take two of the eight output channels each.  z row = the (optionally transposed) output row of the LayerNorm.
+// operation (same lane -> element maps, same reduction trees, the shared prevq_* helpers of common.h), so z is bit-identical
+// to the two-pass flow (tests/test_gpu_ops.py::test_layernorm_prevq_matches_two_pass).  A wave walks PV_ROWS consecutive rows
+// with the next row's loads in flight; the four 16-lane DPP rows of the wave take two of the eight output channels each and
+// keep their slice of the weight (2 x dim / 16 floats per lane) in registers for the whole walk.  No workgroup barrier: the
+// LDS block is private to the wave, whose LDS instructions execute in order.  z row = the LayerNorm's output row.
+constexpr int PV_ROWS = 8;
+template <int NV>  // float4 per lane of one row: dim = 256 * NV
 __global__ __launch_bounds__(256) void layernorm_prevq_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                              const float *__restrict__ beta, const float *__restrict__ w,
                                                              const float *__restrict__ b, float *__restrict__ z, int64_t rows,
-                                                             int dim, float eps, int tr_a, int tr_c, int l2) {
-    __shared__ __attribute__((aligned(16))) float rowbuf[4][256 * LN_MAX_V4];
+                                                             float eps, int tr_a, int tr_c, int l2) {
+    constexpr int dim = 256 * NV;
+    __shared__ __attribute__((aligned(16))) float rowbuf[4][dim];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row_raw = (int64_t)blockIdx.x * 4 + wave;
-    const bool live = row_raw < rows;
-    const int64_t row = live ? row_raw : rows - 1;
-    const int nv = (dim / 4 + 63) / 64;
-    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + row * dim);
-    f32x4 v[LN_MAX_V4];
+    const int l16 = lane & 15, grp = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * PV_ROWS;
+    if (row0 >= rows) return;
+    const int64_t nrow = rows - row0 < PV_ROWS ? rows - row0 : PV_ROWS;
+    // this DPP row's two channels of the weight, in pre_vq_kernel's lane -> element map (elements l16 * 4 + 64 j)
+    f32x4 wr[2][4 * NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < dim) v[i] = xr[lane + 64 * i];
-    float mean, rstd;
-    row_stats(v, nv, lane, dim, eps, mean, rstd);
-    int64_t orow = row;
-    if (tr_a > 0) {
-        const int64_t c = row % tr_c, ba = row / tr_c;
-        orow = ((ba / tr_a) * tr_c + c) * tr_a + ba % tr_a;
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int j = 0; j < 4 * NV; ++j) wr[cc][j] = *reinterpret_cast<const f32x4 *>(w + (2 * grp + cc) * dim + l16 * 4 + 64 * j);
+    const float bias0 = b[2 * grp], bias1 = b[2 * grp + 1];
+    f32x4 g4[NV], b4[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        g4[i] = reinterpret_cast<const f32x4 *>(gamma)[lane + 64 * i];
+        b4[i] = beta ? reinterpret_cast<const f32x4 *>(beta)[lane + 64 * i] : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gamma);
-    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(beta);
-    f32x4 *yr = reinterpret_cast<f32x4 *>(rowbuf[wave]);
+    f32x4 v[LN_MAX_V4], vn[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAX_V4; ++i)
-        if (i < nv && (lane + 64 * i) * 4 < dim) {
-            const f32x4 g = g4[lane + 64 * i];
+    for (int i = 0; i < NV; ++i) vn[i] = reinterpret_cast<const f32x4 *>(x + row0 * dim)[lane + 64 * i];
+    for (int64_t r = 0; r < nrow; ++r) {
+        const int64_t row = row0 + r;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = vn[i];
+        {
+            const int64_t nx = r + 1 < nrow ? row + 1 : row;  // clamped: the last prefetch re-reads the row (branch-free)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) vn[i] = reinterpret_cast<const f32x4 *>(x + nx * dim)[lane + 64 * i];
+        }
+        float mean, rstd;
+        row_stats(v, NV, lane, dim, eps, mean, rstd);
+        int64_t orow = row;
+        if (tr_a > 0) {
+            const int64_t c = row % tr_c, ba = row / tr_c;
+            orow = ((ba / tr_a) * tr_c + c) * tr_a + ba % tr_a;
+        }
+        f32x4 *yr = reinterpret_cast<f32x4 *>(rowbuf[wave]);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e];
+            for (int e = 0; e < 4; ++e) o[e] = ln_apply(v[i][e], mean, rstd, g4[i][e]);
             if (beta) {
-                const f32x4 bb = b4[lane + 64 * i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] += bb[e];
+                for (int e = 0; e < 4; ++e) o[e] += b4[i][e];
             }
             yr[lane + 64 * i] = o;
         }
-    __syncthreads();
-    // pre_vq: DPP row g of the wave computes channels 2g, 2g + 1 with pre_vq_kernel's lane -> element map
-    const int l16 = lane & 15, grp = lane >> 4;
-    float acc[2] = {0.0f, 0.0f};
-    for (int i = l16 * 4; i < dim; i += 64) {
-        const f32x4 xv = *reinterpret_cast<const f32x4 *>(rowbuf[wave] + i);
+        __builtin_amdgcn_wave_barrier();
+        float acc[2] = {0.0f, 0.0f};
 #pragma unroll
-        for (int cc = 0; cc < 2; ++cc) {
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + (2 * grp + cc) * dim + i);
-            acc[cc] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+        for (int j = 0; j < 4 * NV; ++j) {
+            const f32x4 xv = *reinterpret_cast<const f32x4 *>(rowbuf[wave] + l16 * 4 + 64 * j);
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                acc[cc] += prevq_dot4(xv[0], xv[1], xv[2], xv[3], wr[cc][j][0], wr[cc][j][1], wr[cc][j][2], wr[cc][j][3]);
         }
+        __builtin_amdgcn_wave_barrier();
+        acc[0] = row16_allsum(acc[0]) + bias0;
+        acc[1] = row16_allsum(acc[1]) + bias1;
+        float zc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) zc[c] = __shfl(acc[c & 1], (c >> 1) * 16);
+        if (l2) prevq_l2norm8(zc);
+        if (lane == 0) *reinterpret_cast<f32x4 *>(z + orow * 8) = f32x4{zc[0], zc[1], zc[2], zc[3]};
+        if (lane == 1) *reinterpret_cast<f32x4 *>(z + orow * 8 + 4) = f32x4{zc[4], zc[5], zc[6], zc[7]};
     }
-#pragma unroll
-    for (int cc = 0; cc < 2; ++cc) acc[cc] = row16_allsum(acc[cc]) + b[2 * grp + cc];
-    float zc[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) zc[c] = __shfl(acc[c & 1], (c >> 1) * 16);
-    float ss = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) ss += zc[c] * zc[c];
-    if (l2) {
-        const float den = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(p=2, eps=1e-12), omnitokenizer.py:252
-#pragma unroll
-        for (int c = 0; c < 8; ++c) zc[c] = zc[c] / den;
-    }
-    if (live && lane == 0) *reinterpret_cast<f32x4 *>(z + orow * 8) = f32x4{zc[0], zc[1], zc[2], zc[3]};
-    if (live && lane == 1) *reinterpret_cast<f32x4 *>(z + orow * 8 + 4) = f32x4{zc[4], zc[5], zc[6], zc[7]};
 }
 
 // statistics only: the normalisation itself is applied by the consuming GEMM while it stages its
@@ -514,13 +533,19 @@ extern "C" int omnitok_layernorm_prevq(const float *x, const float *gamma, const
                                        omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(x && gamma && w && b && z, "layernorm_prevq: null pointer");
-    OT_CHECK_ARG(dim > 0 && dim % 64 == 0 && dim <= 256 * LN_MAX_V4 && a > 0 && c > 0, "layernorm_prevq: bad shape");
+    OT_CHECK_ARG((dim == 256 || dim == 512 || dim == 1024) && a > 0 && c > 0, "layernorm_prevq: dim %d (256, 512 or 1024)", dim);
     OT_CHECK_ARG(aligned16(x) && aligned16(z) && aligned16(gamma) && aligned16(w) && (!beta || aligned16(beta)),
                  "layernorm_prevq: pointers must be 16-byte aligned");
     const int64_t rows = n * a * c;
     if (rows == 0) return OMNITOK_OK;
-    hipLaunchKernelGGL(layernorm_prevq_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, gamma, beta, w, b, z,
-                       rows, dim, eps, transpose ? a : 0, c, l2);
+    const dim3 grid((unsigned)((rows + 4 * PV_ROWS - 1) / (4 * PV_ROWS)));
+    const int tr_a = transpose ? a : 0;
+    if (dim == 256)
+        hipLaunchKernelGGL(layernorm_prevq_kernel<1>, grid, dim3(256), 0, stream, x, gamma, beta, w, b, z, rows, eps, tr_a, c, l2);
+    else if (dim == 512)
+        hipLaunchKernelGGL(layernorm_prevq_kernel<2>, grid, dim3(256), 0, stream, x, gamma, beta, w, b, z, rows, eps, tr_a, c, l2);
+    else
+        hipLaunchKernelGGL(layernorm_prevq_kernel<4>, grid, dim3(256), 0, stream, x, gamma, beta, w, b, z, rows, eps, tr_a, c, l2);
     OT_LAUNCH_CHECK("layernorm_prevq");
     return OMNITOK_OK;
 }

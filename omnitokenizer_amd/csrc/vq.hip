@@ -306,20 +306,12 @@ __global__ __launch_bounds__(256) void pre_vq_kernel(const float *__restrict__ x
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + c * D + i);
-            acc[c] += (xv[0] * wv[0] + xv[1] * wv[1]) + (xv[2] * wv[2] + xv[3] * wv[3]);
+            acc[c] += prevq_dot4(xv[0], xv[1], xv[2], xv[3], wv[0], wv[1], wv[2], wv[3]);
         }
     }
-    float ss = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        acc[c] = row16_allsum(acc[c]) + b[c];
-        ss += acc[c] * acc[c];
-    }
-    if (l2) {
-        const float den = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize(p=2, eps=1e-12), omnitokenizer.py:252
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = acc[c] / den;
-    }
+    for (int c = 0; c < 8; ++c) acc[c] = row16_allsum(acc[c]) + b[c];
+    if (l2) prevq_l2norm8(acc);  // F.normalize(p=2, eps=1e-12), omnitokenizer.py:252
     if (l16 == 0) *reinterpret_cast<f32x4 *>(z + row * 8) = f32x4{acc[0], acc[1], acc[2], acc[3]};
     if (l16 == 1) *reinterpret_cast<f32x4 *>(z + row * 8 + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
 }

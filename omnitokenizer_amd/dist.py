@@ -22,6 +22,26 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def data_flow_for(n_total: int, tokens_per_item: int, world: int, min_tokens: int) -> int:
+    """The per-engine "pl_min_tokens" value that makes EVERY rank of a clip-sharded job take the data flow its largest
+    shard would take on its own: 0 (plane flow everywhere) when ceil(n_total / world) items reach the threshold, else a
+    value no call reaches (small-call flow everywhere).  The two flows round differently (include/omnitok.h
+    "pl_min_tokens"), so without this a ragged shard -- or 2 clips per rank against 4 -- could give the same clip
+    different latent bits on different ranks."""
+    largest = -(-int(n_total) // max(int(world), 1)) * int(tokens_per_item)
+    return 0 if largest >= int(min_tokens) else (1 << 30)
+
+
+def pin_data_flow(model, n_total: int, tokens_per_item: int, group=None) -> int:
+    """Pins `model`'s engine (OmniTokenizer_VQGAN.set_option) to one data flow for a sharded job of n_total items of
+    tokens_per_item tokens each, decided from the GLOBAL batch; returns the value set.  Call once before the step loop."""
+    from . import _lib
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    value = data_flow_for(n_total, tokens_per_item, world, _lib.get_option("pl_min_tokens"))
+    model.set_option("pl_min_tokens", value)
+    return value
+
+
 class IdGather:
     """The one collective of the path (reference launch contract ddp_utils.py:333-364: one process per GPU, a default
     process group): all-gather of the token ids, int32 on the wire, off the critical path.

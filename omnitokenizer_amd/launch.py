@@ -108,6 +108,7 @@ class rank_errors:
         sys.stderr.write(f"rank {rank} of {world}: {et.__name__}: {ev}\n")
         sys.stderr.write("".join(traceback.format_exception(et, ev, tb)))
         sys.stderr.flush()
+        sys.stdout.flush()  # os._exit skips the interpreter's own flush: partial JSON lines would be lost
         if world > 1:
             os._exit(1)   # do not run atexit / destructors that wait for the other ranks
         return False
@@ -268,18 +269,54 @@ def probe_native_gather(info: RankInfo, ids_local: torch.Tensor, res: ShardedRes
     th = threading.Thread(target=body, daemon=True)
     th.start()
     th.join(timeout_s)
-    if th.is_alive():
+    hung = th.is_alive()
+    if hung:
         out["error"] = f"timeout after {timeout_s:.0f} s"
+    # Every rank must leave the same way: a rank whose probe hung cannot take part in the closing barrier /
+    # destroy_process_group, and the others would wait for it until the watchdog fires.  Agreement goes through the
+    # rendezvous store (host side, TCP) -- not through a collective, which may be what is stuck.
+    hung_ranks = _agree_on_hang(info, hung)
+    if hung_ranks:
         info.abandoned_thread = True
+        out["hung_ranks"] = hung_ranks
+        if not hung:
+            out["error"] = f"native gather probe hung on rank(s) {hung_ranks}"
+            out["ok"] = False
     res.extra["native_comm"] = out.pop("_comm", None)
     return out
 
 
-def finish(info: RankInfo, on_gpu: bool = True):
-    if getattr(info, "abandoned_thread", False):   # a helper thread hangs inside a collective: no orderly teardown
+def _agree_on_hang(info: RankInfo, hung: bool, timeout_s: float = 30.0):
+    """-> sorted list of ranks whose probe thread hung (every rank gets the same list; a rank that never reports counts as
+    hung).  world 1: [0] or []."""
+    if info.world <= 1 or not dist.is_initialized():
+        return [info.rank] if hung else []
+    import datetime
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        store.set(f"omnitok/native_probe/{info.rank}", "1" if hung else "0")
+        bad = []
+        for r in range(info.world):
+            key = f"omnitok/native_probe/{r}"
+            try:
+                store.wait([key], datetime.timedelta(seconds=timeout_s))
+                if store.get(key) != b"0":
+                    bad.append(r)
+            except Exception:  # noqa: BLE001  (the rank never reported)
+                bad.append(r)
+        return bad
+    except Exception:  # noqa: BLE001  (no store: fall back to this rank's own view)
+        return [info.rank] if hung else []
+
+
+def finish(info: RankInfo, on_gpu: bool = True, native_timed: bool = False):
+    """Orderly teardown; when a native-gather probe thread hangs inside a collective (on ANY rank, see _agree_on_hang) every
+    rank leaves through os._exit -- status 0 when the timed region used torch.distributed's gather (the line is valid, the
+    probe's `error` field says what happened), status 3 when the timed region itself was the native gather."""
+    if getattr(info, "abandoned_thread", False):
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(3 if native_timed else 0)
     if info.world > 1:
         _barrier(info, on_gpu)
         dist.destroy_process_group()

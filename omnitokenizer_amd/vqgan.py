@@ -117,6 +117,11 @@ class OmniTokenizer_VQGAN(nn.Module):
 
         self.codebook.call_cnt = 0          # reference codebook.py:19 (usage EMA state)
         self.codebook.usage_sigma = 0.99    # reference codebook.py:12
+        # Reference Codebook.forward updates the `codebook_usage` EMA buffer and `call_cnt` on EVERY call, also in eval mode
+        # and therefore on every encode() (codebook.py:122-143): a state_dict() taken after N encodes carries that state.
+        # True (default) reproduces it with one histogram kernel per encode (microseconds); False makes encode() free of
+        # side effects (forward(log_image=True) still updates, as the statistics are part of what it returns).
+        self.update_codebook_usage_on_encode = True
 
         self._engine = None
         self._engine_sig = None
@@ -329,7 +334,7 @@ class OmniTokenizer_VQGAN(nn.Module):
     @torch.no_grad()
     @_on_own_device
     def encode(self, x, is_image, include_embeddings=False, return_latents=False, noise=None,
-               sample_posterior=True, return_moments=False):
+               sample_posterior=True, return_moments=False, _stats_out=None):
         """reference omnitokenizer.py:247-266.  x: [B,C,H,W] (is_image) or [B,C,F,H,W] fp32 in
         [-0.5,0.5] on the GPU.  Returns LongTensor ids [B,T',h,w]; with include_embeddings
         (embeddings [B,cdim,T',h,w], ids).
@@ -373,6 +378,13 @@ class OmniTokenizer_VQGAN(nn.Module):
         # identity, not by address: the caching allocator hands a freed block to the next tensor of the same size, and
         # every fresh tensor has _version 0, so (data_ptr, _version, shape) would also match foreign ids.
         self._own_ids = (weakref.ref(ids), ids._version)
+        # the eval-time state mutation of reference Codebook.forward (codebook.py:122-143); forward(log_image=True) passes
+        # _stats_out to receive the statistics of this one update.  Not recorded into a HIP graph: `call_cnt` is host state.
+        if not self.use_external_codebook and (_stats_out is not None or self.update_codebook_usage_on_encode) \
+                and not torch.cuda.is_current_stream_capturing():
+            stats = self._update_codebook_usage(ids)
+            if _stats_out is not None:
+                _stats_out.update(stats)
         if not include_embeddings:
             emb = None
         elif self.use_external_codebook:
@@ -380,6 +392,16 @@ class OmniTokenizer_VQGAN(nn.Module):
         if return_latents:
             return (emb, ids, z) if include_embeddings else (ids, z)
         return (emb, ids) if include_embeddings else ids
+
+    def _update_codebook_usage(self, ids):
+        """batch_usage / perplexity / avg_usage of reference Codebook.forward (codebook.py:122-143) for `ids`, with its side
+        effects: `codebook_usage` <- usage (first call) or sigma * codebook_usage + (1 - sigma) * usage; call_cnt += 1."""
+        from . import ops
+        cb = self.codebook
+        usage, perplexity, avg_usage = ops.vq_stats(ids, self.cfg.n_codes, cb.codebook_usage.data, cb.call_cnt == 0,
+                                                    cb.usage_sigma)
+        cb.call_cnt += 1
+        return dict(batch_usage=usage, perplexity=perplexity, avg_usage=avg_usage)
 
     def _encode_native(self, x, want_emb, want_z):
         """omnitok::vqgan_encode on CUDA tensors: x [B, C, F, H, W] fp32 contiguous -> (ids, emb, z); emb / z are
@@ -547,7 +569,8 @@ class OmniTokenizer_VQGAN(nn.Module):
             z = self.encode(x, is_image)
             x_recon = self.decode(z if is_image else z.permute(0, 2, 3, 4, 1), is_image)
         else:
-            emb, ids = self.encode(x, is_image, include_embeddings=True)
+            stats = {}
+            emb, ids = self.encode(x, is_image, include_embeddings=True, _stats_out=None if self.use_external_codebook else stats)
             x_recon = self.decode(ids, is_image)
         if is_image:
             frames, frames_recon = x, x_recon
@@ -560,15 +583,13 @@ class OmniTokenizer_VQGAN(nn.Module):
             return frames, frames_recon, x, x_recon, None
         # the statistics Codebook.forward returns next to the ids (reference codebook.py:122-143);
         # vqgan_eval.py:152,195 accumulates batch_usage
-        from . import ops
-        cb = self.codebook
-        usage, perplexity, avg_usage = ops.vq_stats(ids, self.cfg.n_codes, cb.codebook_usage.data,
-                                                    cb.call_cnt == 0, cb.usage_sigma)
-        cb.call_cnt += 1
-        vq_output = dict(embeddings=emb, encodings=ids, batch_usage=usage, perplexity=perplexity, avg_usage=avg_usage)
-        if self.use_external_codebook:  # VectorQuantize also reports its (eval: zero) commitment loss
+        if self.use_external_codebook:  # VectorQuantize keeps no usage state; it reports its (eval: zero) commitment loss
+            stats = self._update_codebook_usage(ids)
+            vq_output = dict(embeddings=emb, encodings=ids, **stats)
             vq_output["commitment_loss"] = torch.zeros(1, device=x.device)
             vq_output["perplexity"] = self._ext_perplexity(ids)
+        else:
+            vq_output = dict(embeddings=emb, encodings=ids, **stats)
         return frames, frames_recon, x, x_recon, vq_output
 
     @staticmethod

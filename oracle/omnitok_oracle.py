@@ -340,6 +340,22 @@ def vq_argmin(z_flat, codebook):
     return torch.argmin(dist, dim=1)
 
 
+def codebook_usage_update(ids, n_codes, usage_prev, call_cnt, sigma=0.99):
+    """The statistics AND the eval-time state mutation of reference Codebook.forward (modules/codebook.py:54-72
+    calculate_batch_codebook_usage_percentage, :122-123 perplexity, :133-140 EMA buffer / call_cnt / avg_usage).
+    Returns (batch_usage [n_codes], perplexity, avg_usage, new codebook_usage buffer, new call_cnt)."""
+    flat = ids.reshape(-1)
+    total = flat.numel()
+    usage = torch.zeros(n_codes, dtype=torch.float32)
+    uniq, counts = torch.unique(flat, return_counts=True)            # :64
+    usage[uniq.long()] = counts.float() / total                      # :66-69
+    avg_probs = torch.bincount(flat, minlength=n_codes).float() / total  # mean of the one-hot rows, :87, :122
+    perplexity = torch.exp(-torch.sum(avg_probs * torch.log(avg_probs + 1e-10)))  # :123
+    new = usage if call_cnt == 0 else sigma * usage_prev + (1 - sigma) * usage   # :133-136
+    avg_usage = (new > (1 / n_codes)).sum() / n_codes                # :140
+    return usage, perplexity, avg_usage, new, call_cnt + 1
+
+
 def ext_pre_vq(sd, tok, cosine=True):
     """--use_external_codebook: VectorQuantize.project_in (512 -> codebook_dim, +bias) then the codebook's
     transform_input: l2norm for the cosine codebook, identity for the Euclidean one

@@ -527,9 +527,35 @@ def run_heavy_batch_case(name="heavy_s2_sdpa_r256_vid17_b8", batch=8, stride=8):
           f"pixel noise {noise_pix_clip.max().item():.2e}, |recon|max {out['rec32'].abs().max().item():.1f}")
 
 
+def make_usage_state_golden(name="usage_state_s2_sdpa_r64"):
+    """The eval-time STATE MUTATION of the reference's quantiser (codebook.py:122-143): every Codebook.forward -- hence
+    every encode() -- rewrites the `codebook_usage` buffer (first call: the batch's usage; later: the 0.99 / 0.01 EMA) and
+    bumps `call_cnt`.  Fixture: the reference's state_dict entry after encode(x_img), encode(x_vid), then
+    forward-style third call on x_img again, plus the ids of each call."""
+    args = make_args(2, resolution=64)
+    cfg = OmniTokConfig.from_args(args, attention_mode="sdpa")
+    sd = synth.synth_state_dict(cfg, seed=0)
+    model = rh.build_reference_model(args)
+    model.load_state_dict(sd, strict=False)
+    xi = synth.synth_image(2, 64, seed=1234)
+    xv = synth.synth_video(2, 5, 64, seed=1234)
+    usage, ids_all = [], []
+    with torch.no_grad(), rh.attention_mode("sdpa"):
+        for x, is_image in ((xi, True), (xv, False), (xi, True)):
+            ids = model.encode(x, is_image)
+            ids_all.append(ids.numpy().astype(np.int16))
+            usage.append(model.state_dict()["codebook.codebook_usage"].clone().numpy())
+    assert model.codebook.call_cnt == 3
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), usage=np.stack(usage), call_cnt=np.int32(model.codebook.call_cnt),
+                        ids0=ids_all[0], ids1=ids_all[1], ids2=ids_all[2], state_crc=np.uint32(synth.state_checksum(sd)))
+    print(f"{name}: usage sums {[float(u.sum()) for u in usage]}, nonzero {[int((u > 0).sum()) for u in usage]}")
+
+
 if __name__ == "__main__":
     assert rh.reference_available(), "run in the build container (needs /root/reference)"
     only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only in (None, "usage"):
+        make_usage_state_golden()
     if only == "up":  # only the Up-block variants
         for c in VARIANT_CASES:
             if c[0].startswith("var_up_"):

@@ -106,6 +106,35 @@ def test_c4_shards_are_32_clips_each():
     assert [shard_range(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
 
 
+def test_sharded_job_pins_one_data_flow_for_all_ranks():
+    """the plane / small-call switch ("pl_min_tokens") used to be decided per call from the LOCAL token count,
+    so a ragged shard could round a clip differently than its neighbours.  dist.data_flow_for decides from the global
+    batch; pin_data_flow applies it through the per-engine option and reads the process default through the C ABI."""
+    from omnitokenizer_amd import _lib
+    from omnitokenizer_amd.dist import data_flow_for, pin_data_flow
+    thr = _lib.get_option("pl_min_tokens")
+    assert thr == 12288
+    # C4: 256 clips of 5120 tokens on 8 ranks -> planes; 9 clips on 8 ranks: largest shard 2 clips = 10240 < 12288 -> the
+    # small-call flow on EVERY rank (also the ranks that hold 1 clip); 17 clips on 8 ranks: largest 3 clips -> planes everywhere
+    assert data_flow_for(256, 5120, 8, thr) == 0
+    assert data_flow_for(9, 5120, 8, thr) == 1 << 30
+    assert data_flow_for(17, 5120, 8, thr) == 0
+    assert data_flow_for(12, 1024, 1, thr) == 0 and data_flow_for(11, 1024, 1, thr) == 1 << 30
+
+    class FakeModel:
+        def set_option(self, name, value):
+            self.got = (name, value)
+    m = FakeModel()
+    assert pin_data_flow(m, 2, 5120) == 1 << 30 and m.got == ("pl_min_tokens", 1 << 30)
+    try:
+        _lib.set_option("pl_min_tokens", 0)
+        assert pin_data_flow(m, 2, 5120) == 0
+    finally:
+        _lib.set_option("pl_min_tokens", 12288)
+    with pytest.raises(ValueError):
+        _lib.get_option("no_such_option")
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 32, 256):
         for w in (1, 2, 3, 8):

@@ -176,3 +176,16 @@ def test_heavy_batch_fixture_is_consistent_and_pins_the_oracle():
     assert torch.equal(ids, c.ids[b:b + 1]) and torch.equal(ids64, c.ids64[b:b + 1])
     assert (taps["z"] - c.z[b:b + 1]).abs().max().item() < 2e-5          # fp32 vs fp32: summation order only
     assert (taps64["z"] - c.z64[b:b + 1]).abs().max().item() < 2e-6      # fp64 vs fp64 (RoPE table precision)
+
+
+def test_codebook_usage_state_matches_reference():
+    """Reference Codebook.forward mutates `codebook_usage` / `call_cnt` on every call, also in eval mode, i.e. on every
+    encode() (codebook.py:122-143): the oracle's restatement reproduces the reference's buffer after three encodes
+    (fixture made by tests/golden/make_golden.py::make_usage_state_golden from the reference itself)."""
+    g = np.load(os.path.join(GOLDEN, "usage_state_s2_sdpa_r64.npz"))
+    usage, cnt = torch.zeros(8192), 0
+    for i in range(3):
+        ids = torch.from_numpy(g[f"ids{i}"].astype(np.int64))
+        _, _, _, usage, cnt = orc.codebook_usage_update(ids, 8192, usage, cnt)
+        assert (usage - torch.from_numpy(g["usage"][i])).abs().max().item() < 1e-8
+    assert cnt == int(g["call_cnt"]) == 3
