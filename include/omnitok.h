@@ -66,7 +66,7 @@ const char *omnitok_version(void);
  * Tuning knobs of the stand-alone kernel entry points for A/B measurements (process-wide; results do not depend on them --
  * tests check bitwise independence of the tile shape): "gemm_variant", "gemm_small", "gemm_gn", "gemm_lds_pad_kb",
  * "x3_tile", "h2_tile" (0 auto | 1 256x256 | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "pl_cfg" (0 auto | 1 256x256 |
- * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
+ * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "vq_screen" (1 default: omnitok_encode uses the screened search omnitok_vq_argmin_screened | 0 the exact sweep), "vq_screen_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
  * staged in LDS; all bit-exact, profiles/r03_vq_variants.txt), "pl_stagger" (start delay step of persistent GEMM workgroups in
  * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant" (1 default: LDS-tiled -- the 64-channel kernel of peg_wide.h for
  * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, its one-plane form (9 taps, four workgroups per CU) for images,
@@ -441,6 +441,15 @@ int omnitok_vq_prepare(const float *codebook, int n_codes, int cdim, float *pack
  * adds of rounded squares. n_codes % 32 == 0, cdim == 8. ids int64. */
 int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int64_t n, int n_codes,
                       int64_t *ids, omnitok_stream_t stream);
+/* The same ids, bit for bit, from a SCREENED search (csrc/vq.hip "vq_screen_kernel"): one fp16 MFMA per 32 codes x 32 rows
+ * evaluates a coarse distance with a rigorous error bound, the codes within that bound of the coarse minimum (almost always
+ * one tile) are re-evaluated with the exact k-ordered fp32 chain of omnitok_vq_argmin, first minimum kept.  Inputs outside
+ * fp16's range, non-finite inputs and codebooks with more than four candidate tiles per row take the exact evaluation for
+ * every tile.  screen[n_codes * 4 + 4] floats from omnitok_vq_screen_prepare(E, ee) (ee from omnitok_vq_prepare). */
+int omnitok_vq_screen_prepare(const float *codebook, const float *ee, int n_codes, int cdim, float *screen,
+                              omnitok_stream_t stream);
+int omnitok_vq_argmin_screened(const float *z, const float *packed, const float *ee, const float *screen, int64_t n,
+                               int n_codes, int64_t *ids, omnitok_stream_t stream);
 
 /* --use_external_codebook (cosine similarity): ids[n] = first argmax_c sum_k z[n,k] E[c,k]  (reference
  * quantizer/vector_quantize_pytorch.py:646-650: einsum + argmax; z and E rows unit-norm).  Same kernel

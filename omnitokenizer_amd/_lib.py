@@ -91,6 +91,8 @@ _PROTOS = {
     "omnitok_pre_vq": [P, P, P, P, I64, c_int, c_int, c_int, P],
     "omnitok_vq_prepare": [P, c_int, c_int, P, P, P],
     "omnitok_vq_argmin": [P, P, P, I64, c_int, P, P],
+    "omnitok_vq_screen_prepare": [P, P, c_int, c_int, P, P],
+    "omnitok_vq_argmin_screened": [P, P, P, P, I64, c_int, P, P],
     "omnitok_vq_argmax_cos": [P, P, I64, c_int, P, P],
     "omnitok_vq_argmin_cdist": [P, P, P, I64, c_int, P, P],
     "omnitok_dequant_post_vq": [P, P, c_int, c_int, P, P, P, I64, c_int, P, P],

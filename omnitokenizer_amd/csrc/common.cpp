@@ -76,6 +76,8 @@ extern int g_attn_window_mode;
 extern int g_pl_cfg;
 extern int g_pl_stagger;
 extern int g_vq_variant;
+extern int g_vq_screen;
+extern int g_vq_screen_split;
 extern int g_lm_wide_u;
 }  // namespace omnitok
 
@@ -87,6 +89,8 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "gemm_small")) omnitok::g_gemm_small = value;
     else if (!strcmp(name, "vq_split")) omnitok::g_vq_split = value;
     else if (!strcmp(name, "vq_variant")) omnitok::g_vq_variant = value;
+    else if (!strcmp(name, "vq_screen")) omnitok::g_vq_screen = value;
+    else if (!strcmp(name, "vq_screen_split")) omnitok::g_vq_screen_split = value;
     else if (!strcmp(name, "x3_tile")) omnitok::g_x3_tile = value;
     else if (!strcmp(name, "gemm_mode")) omnitok::g_gemm_mode = value;
     else if (!strcmp(name, "attn_mode")) omnitok::g_attn_mode = value;

@@ -119,7 +119,7 @@ struct omnitok_engine {
     int pe_k[2] = {0, 0}, pe_ld[2] = {0, 0};
     const float *px_w[2] = {nullptr, nullptr}, *px_b[2] = {nullptr, nullptr};
     // derived
-    float *cb_packed = nullptr, *cb_ee = nullptr, *alibi = nullptr;
+    float *cb_packed = nullptr, *cb_ee = nullptr, *cb_screen = nullptr, *alibi = nullptr;
     float *dq_table = nullptr;  // [n_codes, dim] = E . post_vq^T + b (decode = row gather)
     std::map<int, std::pair<float *, float *>> rope;                    // N -> cos, sin
     std::map<std::string, float *> bias_tables;                          // prefix|gh|gw -> table
@@ -147,7 +147,7 @@ namespace omnitok {
 constexpr int N_BOUND_LAUNCHES = 64;  // row-statistics launches with ranges per encode / decode
 
 // process defaults of the per-engine modes (omnitok_set_option; engine_run.hip)
-extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl, g_pl_min_tokens, g_temporal_chunk, g_prevq_fuse;
+extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl, g_pl_min_tokens, g_temporal_chunk, g_prevq_fuse, g_vq_screen;
 
 Geo geometry(const omnitok_config &c);
 bool walk_enc_grid(const char *block, int *gh, int *gw, int64_t *peak);

@@ -271,8 +271,12 @@ extern "C" int omnitok_encode(omnitok_engine *e, const float *x, int B, int F, i
             OT_RUN("dequant_post_vq", (double)L * D * 4.0,
                    omnitok_gather_rows(ids_out, e->dq_table, c.n_codes, emb_out, L, D, nullptr, stream));
     } else {
-        OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
-               omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
+        if (g_vq_screen && e->cb_screen)  // same ids, bit for bit (csrc/vq.hip vq_screen_kernel)
+            OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+                   omnitok_vq_argmin_screened(e->Z.p, e->cb_packed, e->cb_ee, e->cb_screen, L, c.n_codes, ids_out, stream));
+        else
+            OT_RUN("vq_argmin", 2.0 * (double)L * c.n_codes * 8.0,
+                   omnitok_vq_argmin(e->Z.p, e->cb_packed, e->cb_ee, L, c.n_codes, ids_out, stream));
         if (emb_out)
             OT_RUN("vq_embed_st", (double)L * 8 * 8.0,
                    omnitok_vq_embed_st(ids_out, e->Z.p, W(e, k_embed(c)), 8, B, (int64_t)T * S, emb_out, stream));

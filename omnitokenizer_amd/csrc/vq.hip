@@ -14,6 +14,7 @@
 //     L2-resident: 256 KiB for 8192 codes), ee[] staged in LDS and read as broadcast float4;
 //   * each wave keeps two 32-row B fragments, so one A load feeds 8 MFMAs.
 #include "common.h"
+#include "h2_common.h"
 
 namespace omnitok {
 
@@ -28,6 +29,10 @@ int g_vq_split = 0;  // 0 = automatic
 //   2  like 0 with the split's codebook fragments staged in LDS once per workgroup (1 KiB per 32 codes): 0.32 ms, the
 //      L2-resident fragments (one coalesced 16-byte load per lane and tile, prefetched two tiles ahead) were never the limit
 int g_vq_variant = 1;
+// "vq_screen" 1 (default): omnitok_encode's nearest-code search is the screened form (vq_screen_kernel below: same ids,
+// a fifth of the matrix work) | 0: the exact sweep for every code.  "vq_screen_split": 0 = automatic, else forced.
+int g_vq_screen = 1;
+int g_vq_screen_split = 0;
 
 __global__ void vq_prepare_kernel(const float *__restrict__ E, int n_codes, float *__restrict__ packed,
                                   float *__restrict__ ee) {
@@ -261,6 +266,261 @@ __global__ __launch_bounds__(256, VAR == 2 ? 1 : 2) void vq_argmin_kernel(const 
             if (d < bd) {
                 bd = d;
                 bi = t * 32 + r;
+            }
+        }
+        best[g] = bd;
+        bidx[g] = bi;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const float od = swap32(best[g]);
+        const int oi = __shfl_xor(bidx[g], 32);
+        if (od < best[g] || (od == best[g] && oi < bidx[g])) {
+            best[g] = od;
+            bidx[g] = oi;
+        }
+        const int64_t row = row_base + g * 32 + r32;
+        if (hi == 0 && row < n) {
+            if (SPLIT)
+                atomicMin(reinterpret_cast<unsigned long long *>(ids + row),
+                          ((unsigned long long)order_key(best[g]) << 32) | (unsigned)bidx[g]);
+            else
+                ids[row] = (int64_t)bidx[g];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SCREENED nearest-code search ("vq_variant" 3, VQ_CODEBOOK distance; reference modules/codebook.py:82-86): the same ids as
+// vq_argmin_kernel, bit for bit, at a fraction of its matrix work.
+//
+// The exact search spends five fp32-input MFMAs (320 matrix cycles) per 32 codes x 32 rows because the distance must be
+// the reference's own fp32 value fl(fl(xx - dot) + ee) with dot a k-ordered fmaf chain -- that is the tie-breaking
+// contract.  But almost every code is nowhere near the minimum, and for THOSE any cheap distance with a rigorous error
+// bound is enough to rule them out.  One fp16 MFMA (v_mfma_f32_32x32x16_f16, 32 matrix cycles) evaluates
+//     s'[c] = ee_h[c] + ee_l[c] - sum_k fp16(E[c][k]) * fp16(2 z[k])          (K = 16: 8 products, ee as two halves x 1)
+// for a whole tile: the A fragment of lane (r32, half) is half 0: fp16(E[c][0..7]), half 1: (ee_h, ee_l, 0 ...); the B
+// fragment half 0: fp16(-2 z[0..7]), half 1: (1, 1, 0 ...).  With u = 2^-11 (fp16 unit roundoff), eta = 2^-25 (half the
+// subnormal spacing), |E_c| <= M_E and ee_c <= M_ee for every code (vq_screen_prepare), n_z >= |z|_2:
+//     |s'[c] - (ee_c - 2 z . E_c)| <= eps := 4.002 u M_E n_z                       products of two rounded factors (Cauchy-Schwarz)
+//                                          + 1.001 eta sqrt(8) (M_E + 2 n_z) + 2^-47    subnormal inputs
+//                                          + 2^-22 M_ee + 2^-25                         ee = ee_h + ee_l + rest
+//                                          + 2^-18 (M_ee + 2.01 M_E n_z + 1)            ten exact fp16 x fp16 products summed in fp32
+//                                                                                       (64 units in the last place of the largest
+//                                                                                       partial sum: any adder tree qualifies)
+// and the exact path's own distance differs from the real number xx + (ee_c - 2 z . E_c) by at most
+//     delta := 2^-24 * 1.001 * (21 M_E n_z + 2 xx + M_ee)       (gamma_8 of the fmaf chain + the two roundings of the epilogue).
+// Let c* be the reference's answer (first minimum of the fp32 distance d) and c_m the minimiser of s'.  Then
+//     s'[c*] <= d[c*] - xx + delta + eps <= d[c_m] - xx + delta + eps <= s'[c_m] + 2 (delta + eps),
+// i.e. c* -- and every code tied with it in fp32 -- lies within tau = 2 (eps + delta) of the screen's minimum.
+// Pass 1 sweeps all codes for min s' (per row); pass 2 sweeps again and RECORDS the tiles holding a code within tau of it
+// (almost always exactly one); the recorded tiles are then re-evaluated with the exact fmaf chain of the kernel above, in
+// increasing code order with a strict '<'.  Rows whose inputs leave fp16's range or are not finite, and rows with more than
+// SCR_CAP candidate tiles (a codebook full of duplicates), re-evaluate every tile: slow, never wrong.
+constexpr int SCR_CAP = 4;
+
+__global__ void vq_screen_prepare_kernel(const float *__restrict__ E, const float *__restrict__ ee, int n_codes,
+                                         u32x4 *__restrict__ frag, unsigned *__restrict__ consts) {
+    // consts[0] = max |E_c|_2 (rounded up), [1] = max ee_c, [2] = max |E_ck| as float bits (non-negative: uint order)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_codes * 2) return;
+    const int tile = idx >> 6, lane = idx & 63, r32 = lane & 31, hi = lane >> 5;
+    const int c = tile * 32 + r32;
+    f16x8 h;
+    if (hi == 0) {
+        float nrm2 = 0.0f, amax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float v = E[c * 8 + k];
+            h[k] = (_Float16)v;
+            nrm2 = fmaf(v, v, nrm2);
+            amax = fmaxf(amax, fabsf(v));
+        }
+        float nr = sqrtf(nrm2) * 1.000001f;
+        if (!(nr >= 0.0f)) nr = INFINITY;      // NaN in the codebook: every row takes the exact path
+        if (!(amax >= 0.0f)) amax = INFINITY;
+        atomicMax(consts + 0, __float_as_uint(nr));
+        atomicMax(consts + 2, __float_as_uint(amax));
+    } else {
+        float e = ee[c];
+        if (!(e >= 0.0f)) e = INFINITY;
+        atomicMax(consts + 1, __float_as_uint(e));
+        const _Float16 eh = (_Float16)ee[c];
+        const _Float16 el = (_Float16)(ee[c] - (float)eh);
+        h = f16x8{eh, el, 0, 0, 0, 0, 0, 0};
+    }
+    frag[idx] = __builtin_bit_cast(u32x4, h);
+}
+
+template <bool SPLIT>
+__global__ __launch_bounds__(256, 2) void vq_screen_kernel(const float *__restrict__ z, const float *__restrict__ packed,
+                                                           const float *__restrict__ ee_g, const u32x4 *__restrict__ frag,
+                                                           const float *__restrict__ consts, int64_t n, int n_codes,
+                                                           int64_t *__restrict__ ids) {
+    extern __shared__ __attribute__((aligned(16))) float ee_s[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, hi = lane >> 5;
+    const int ntiles_all = n_codes >> 5;
+    const int tiles_per = (ntiles_all + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t0 = SPLIT ? (int)blockIdx.y * tiles_per : 0;
+    const int t1 = SPLIT ? (t0 + tiles_per < ntiles_all ? t0 + tiles_per : ntiles_all) : ntiles_all;
+    if (t0 >= t1) return;
+    const int c0 = t0 * 32;
+    for (int i = tid * 4; i < (t1 - t0) * 32; i += 256 * 4)
+        *reinterpret_cast<f32x4 *>(ee_s + i) = *reinterpret_cast<const f32x4 *>(ee_g + c0 + i);
+    __syncthreads();
+
+    const float nE = consts[0], nEE = consts[1], nAbs = consts[2];
+    const bool cb_ok = nAbs <= 60000.0f && nEE <= 60000.0f && nE <= 60000.0f;  // false for inf / NaN too
+    const int64_t row_base = (int64_t)blockIdx.x * VQ_ROWS_PER_BLOCK + wave * VQ_ROWS_PER_WAVE;
+    float xx[2], thr[2];
+    f32x4 zlo[2], zhi[2];
+    f16x8 bf[2];
+    bool all_tiles[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        int64_t row = row_base + g * 32 + r32;
+        if (row > n - 1) row = n - 1;
+        const f32x4 lo = *reinterpret_cast<const f32x4 *>(z + row * 8);
+        const f32x4 hi4 = *reinterpret_cast<const f32x4 *>(z + row * 8 + 4);
+        float acc = 0.0f, amax = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(lo[k], lo[k]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc = __fadd_rn(acc, __fmul_rn(hi4[k], hi4[k]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) amax = fmaxf(amax, fmaxf(fabsf(lo[k]), fabsf(hi4[k])));
+        xx[g] = acc;
+        zlo[g] = lo * 2.0f;  // exact
+        zhi[g] = hi4 * 2.0f;
+        // fp16 range of 2 z, finiteness (fmaxf drops NaN, so xx is tested too)
+        all_tiles[g] = !(cb_ok && amax <= 30000.0f && acc <= 1e9f);
+        if (hi == 0)
+            bf[g] = f16x8{(_Float16)(-zlo[g][0]), (_Float16)(-zlo[g][1]), (_Float16)(-zlo[g][2]), (_Float16)(-zlo[g][3]),
+                          (_Float16)(-zhi[g][0]), (_Float16)(-zhi[g][1]), (_Float16)(-zhi[g][2]), (_Float16)(-zhi[g][3])};
+        else
+            bf[g] = f16x8{(_Float16)1.0f, (_Float16)1.0f, 0, 0, 0, 0, 0, 0};
+        // tau = 2 (eps + delta), see the header; every constant rounded up
+        const float nz = sqrtf(acc) * 1.00001f + 1e-30f;
+        const float men = nE * nz;
+        const float eps = 4.002f * 4.8828125e-4f * men + 1.001f * 2.98023224e-8f * 2.8285f * (nE + 2.0f * nz) + 7.2e-15f +
+                          2.38418579e-7f * nEE + 2.98023224e-8f + 3.81469727e-6f * (nEE + 2.01f * men + 1.0f);
+        const float delta = 5.96046448e-8f * 1.001f * (21.0f * men + 2.0f * acc + nEE);
+        thr[g] = 2.0f * (eps + delta) * 1.01f;  // becomes min s' + tau after pass 1
+    }
+    const u32x4 *pf = frag + lane;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto tile_min = [&](const f32x16 &a) {
+        float m = fminf(fminf(a[0], a[1]), a[2]);
+        m = fminf(fminf(m, a[3]), a[4]);
+        m = fminf(fminf(m, a[5]), a[6]);
+        m = fminf(fminf(m, a[7]), a[8]);
+        m = fminf(fminf(m, a[9]), a[10]);
+        m = fminf(fminf(m, a[11]), a[12]);
+        m = fminf(fminf(m, a[13]), a[14]);
+        return fminf(m, a[15]);
+    };
+    auto screen = [&](const u32x4 &a, int g) {
+        return tile_min(__builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), bf[g], zero16, 0, 0, 0));
+    };
+    // ---- pass 1: the screen's minimum per row ----------------------------------------------------------------------
+    // Fragments are requested two tiles ahead into four rotating registers (no copies: a copy would wait for the load it
+    // moves); clamped indices keep every load unconditional (a load inside a branch makes the compiler's waitcnt pass drain
+    // vmcnt(0) at the top of every iteration).
+    auto ld = [&](int t) { return pf[(int64_t)(t < t1 ? t : t1 - 1) * 64]; };
+    float mn[2] = {INFINITY, INFINITY};
+    {
+        auto step = [&](const u32x4 &a) {
+            mn[0] = fminf(mn[0], screen(a, 0));
+            mn[1] = fminf(mn[1], screen(a, 1));
+        };
+        u32x4 A = ld(t0), B = ld(t0 + 1);
+        for (int t = t0; t < t1; t += 4) {
+            const u32x4 C = ld(t + 2), D = ld(t + 3);
+            step(A);
+            if (t + 1 < t1) step(B);
+            A = ld(t + 4);
+            B = ld(t + 5);
+            if (t + 2 < t1) step(C);
+            if (t + 3 < t1) step(D);
+        }
+    }
+    int cnt[2] = {0, 0};
+    int ct[2][SCR_CAP];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        mn[g] = fminf(mn[g], swap32(mn[g]));  // the other half-wave holds the other 16 codes of every tile
+        // |min s'| enters through the rounding of the sum; a NaN / inf minimum (no finite screen value) -> every tile
+        thr[g] = mn[g] + (thr[g] + 1.2e-7f * fabsf(mn[g]));
+        if (!(fabsf(thr[g]) < INFINITY)) all_tiles[g] = true;
+#pragma unroll
+        for (int i = 0; i < SCR_CAP; ++i) ct[g][i] = t0;
+    }
+    // ---- pass 2: record the tiles that hold a code within tau of it ------------------------------------------------
+    {
+        auto step = [&](const u32x4 &a, int t) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const float m = screen(a, g);
+                if (m <= thr[g]) {
+#pragma unroll
+                    for (int i = 0; i < SCR_CAP; ++i)
+                        if (cnt[g] == i) ct[g][i] = t;
+                    ++cnt[g];
+                }
+            }
+        };
+        u32x4 A = ld(t0), B = ld(t0 + 1);
+        for (int t = t0; t < t1; t += 4) {
+            const u32x4 C = ld(t + 2), D = ld(t + 3);
+            step(A, t);
+            if (t + 1 < t1) step(B, t + 1);
+            A = ld(t + 4);
+            B = ld(t + 5);
+            if (t + 2 < t1) step(C, t + 2);
+            if (t + 3 < t1) step(D, t + 3);
+        }
+    }
+    // ---- exact re-evaluation of the recorded tiles (the arithmetic of vq_argmin_kernel's index resolution) ----------
+    float best[2];
+    int bidx[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        // a lane whose own 16 codes were never within tau still takes part in the merge below with (inf, first code)
+        const bool every = all_tiles[g] || cnt[g] > SCR_CAP;
+        // both half-waves must scan the same tiles for the merge to see every candidate: a tile recorded by one half only
+        // is simply absent from the other half's list -- its codes there are above the threshold, hence not the answer
+        const int nt = every ? t1 - t0 : cnt[g];
+        float bd = INFINITY;
+        int bi = t0 * 32 + 4 * hi;
+        const float zz[8] = {zlo[g][0], zlo[g][1], zlo[g][2], zlo[g][3], zhi[g][0], zhi[g][1], zhi[g][2], zhi[g][3]};
+        for (int i = 0; __builtin_amdgcn_ballot_w64(i < nt) != 0; ++i) {
+            if (i < nt) {
+                int t = t0 + i;
+                if (!every) {
+                    t = ct[g][0];
+#pragma unroll
+                    for (int j = 1; j < SCR_CAP; ++j)
+                        if (i == j) t = ct[g][j];
+                }
+                const float *pt = packed + (int64_t)t * 256;
+#pragma unroll 4
+                for (int qe = 0; qe < 16; ++qe) {
+                    const int r = 8 * (qe >> 2) + (qe & 3) + 4 * hi;
+                    const f32x4 ev = *reinterpret_cast<const f32x4 *>(pt + r * 4);
+                    const f32x4 od = *reinterpret_cast<const f32x4 *>(pt + (32 + r) * 4);
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        dot = __fmaf_rn(ev[s], zz[2 * s], dot);
+                        dot = __fmaf_rn(od[s], zz[2 * s + 1], dot);
+                    }
+                    const float d = __fadd_rn(__fsub_rn(xx[g], dot), ee_s[t * 32 + r - c0]);
+                    if (d < bd) {  // tiles and codes in increasing order: strict '<' keeps the first minimum
+                        bd = d;
+                        bi = t * 32 + r;
+                    }
+                }
             }
         }
         best[g] = bd;
@@ -632,6 +892,57 @@ extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const floa
     OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin: n_codes=%d unsupported", n_codes);
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee), "vq_argmin: unaligned");
     return launch_vq<VQ_CODEBOOK>(z, packed, ee, n, n_codes, ids, stream);
+}
+
+// screen[n_codes * 4 + 4] floats: n_codes x 16 bytes of fp16 screening fragments (tile-major, MFMA A-fragment order) followed
+// by {max |E_c|_2, max ee_c, max |E_ck|, 0}
+extern "C" int omnitok_vq_screen_prepare(const float *codebook, const float *ee, int n_codes, int cdim, float *screen,
+                                         omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(codebook && ee && screen, "vq_screen_prepare: null pointer");
+    OT_CHECK_ARG(cdim == 8 && n_codes % 32 == 0 && n_codes > 0 && aligned16(screen), "vq_screen_prepare: need cdim == 8, n_codes %% 32 == 0");
+    unsigned *consts = reinterpret_cast<unsigned *>(screen + (int64_t)n_codes * 4);
+    if (int rc = device_fill_u32(consts, 0u, 4, stream)) return rc;
+    hipLaunchKernelGGL(vq_screen_prepare_kernel, dim3((n_codes * 2 + 255) / 256), dim3(256), 0, stream, codebook, ee, n_codes,
+                       reinterpret_cast<u32x4 *>(screen), consts);
+    OT_LAUNCH_CHECK("vq_screen_prepare");
+    return OMNITOK_OK;
+}
+
+extern "C" int omnitok_vq_argmin_screened(const float *z, const float *packed, const float *ee, const float *screen, int64_t n,
+                                          int n_codes, int64_t *ids, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (n == 0) return OMNITOK_OK;
+    OT_CHECK_ARG(z && packed && ee && screen && ids, "vq_argmin_screened: null pointer");
+    OT_CHECK_ARG(n_codes % 32 == 0 && n_codes > 0 && n_codes <= 32768, "vq_argmin_screened: n_codes=%d unsupported", n_codes);
+    OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee) && aligned16(screen), "vq_argmin_screened: unaligned");
+    const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
+    const int ntiles = n_codes >> 5;
+    // splits of the code range: only to fill the chip (512 workgroup slots) -- every split pays a rescan of its own best tile
+    int nsplit = 1;
+    while (blocks * nsplit < 512 && nsplit < 16 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
+    if (g_vq_screen_split >= 1) nsplit = g_vq_screen_split;
+    if (nsplit > ntiles) nsplit = ntiles;
+    const int tiles_per = (ntiles + nsplit - 1) / nsplit;
+    const int lds = (tiles_per * 32 + 3) / 4 * 4 * 4;
+    if (lds > 65536) {
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_screen_kernel<false>), lds)) return rc;
+        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_screen_kernel<true>), lds)) return rc;
+    }
+    const u32x4 *frag = reinterpret_cast<const u32x4 *>(screen);
+    const float *consts = screen + (int64_t)n_codes * 4;
+    const dim3 grid((unsigned)blocks, nsplit);
+    if (nsplit == 1) {
+        hipLaunchKernelGGL((vq_screen_kernel<false>), grid, dim3(256), lds, stream, z, packed, ee, frag, consts, n, n_codes, ids);
+        OT_LAUNCH_CHECK("vq_screen");
+        return OMNITOK_OK;
+    }
+    if (int rc = device_fill_u32(ids, 0xFFFFFFFFu, n * 2, stream)) return rc;
+    hipLaunchKernelGGL((vq_screen_kernel<true>), grid, dim3(256), lds, stream, z, packed, ee, frag, consts, n, n_codes, ids);
+    OT_LAUNCH_CHECK("vq_screen");
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n);
+    OT_LAUNCH_CHECK("vq_finalize");
+    return OMNITOK_OK;
 }
 
 extern "C" int omnitok_vq_argmax_cos(const float *z, const float *packed, int64_t n, int n_codes, int64_t *ids,

@@ -610,6 +610,29 @@ def vq_prepare(codebook):
     return packed, ee
 
 
+def vq_screen_prepare(codebook, ee):
+    """fp16 screening fragments + norm bounds for vq_argmin_screened (include/omnitok.h omnitok_vq_screen_prepare)."""
+    codebook = _req(codebook, "codebook")
+    n_codes, cdim = codebook.shape
+    screen = torch.empty(n_codes * 4 + 4, device=codebook.device, dtype=torch.float32)
+    check(_lib.load().omnitok_vq_screen_prepare(_p(codebook), _p(_req(ee, "ee")), n_codes, cdim, _p(screen), _stream()),
+          "vq_screen_prepare")
+    return screen
+
+
+def vq_argmin_screened(z, codebook, prepared=None, screen=None):
+    """ids[n] = nearest code of z[n] (int64) through the fp16-screened search: bit-identical to vq_argmin."""
+    z = _req(z, "z")
+    packed, ee = prepared if prepared is not None else vq_prepare(codebook)
+    if screen is None:
+        screen = vq_screen_prepare(codebook, ee)
+    n = z.numel() // 8
+    ids = torch.empty(z.shape[:-1], device=z.device, dtype=torch.int64)
+    check(_lib.load().omnitok_vq_argmin_screened(_p(z), _p(packed), _p(ee), _p(screen), n, codebook.shape[0], _p(ids),
+                                                 _stream()), "vq_argmin_screened")
+    return ids
+
+
 def vq_argmin(z, codebook, prepared=None):
     """ids[n] = nearest code of z[n] (int64), bit-exact with reference modules/codebook.py:82-86."""
     z = _req(z, "z")

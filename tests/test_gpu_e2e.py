@@ -281,8 +281,8 @@ def test_small_calls_take_the_fp32_activation_flow(models):
 
 
 def test_prevq_fusion_and_temporal_chunks_are_bit_identical(models):
-    """Two r05 data-flow changes that must not change a bit: "prevq_fuse" (pre_vq inside the encoder's last LayerNorm pass)
-    and "temporal_chunk" (the temporal q|k|v GEMM + attention run chunk by chunk through an Infinity-Cache-sized buffer;
+    """Three r05 changes that must not change a bit: "prevq_fuse" (pre_vq inside the encoder's last LayerNorm pass),
+    "vq_screen" (the fp16-screened nearest-code search) and "temporal_chunk" (the temporal q|k|v GEMM + attention run chunk by chunk through an Infinity-Cache-sized buffer;
     process option and per-engine option).  8 distinct 17x256^2 clips, ragged last chunk (3 + 3 + 2) included."""
     from omnitokenizer_amd import _lib
     c = GoldenCase(HEAVY_BATCH_CASE)
@@ -298,9 +298,10 @@ def test_prevq_fusion_and_temporal_chunks_are_bit_identical(models):
         finally:
             _lib.set_option("prevq_fuse", 1)
             _lib.set_option("temporal_chunk", 0)
+            _lib.set_option("vq_screen", 1)
 
-    base = run(prevq_fuse=0, temporal_chunk=0)
-    for opts in (dict(prevq_fuse=1), dict(temporal_chunk=4), dict(temporal_chunk=3), dict(temporal_chunk=1),
+    base = run(prevq_fuse=0, temporal_chunk=0, vq_screen=0)
+    for opts in (dict(prevq_fuse=1, vq_screen=0), dict(vq_screen=1, prevq_fuse=0), dict(temporal_chunk=4), dict(temporal_chunk=3), dict(temporal_chunk=1),
                  dict(temporal_chunk=8), dict(temporal_chunk=100)):
         got = run(**opts)
         assert all(torch.equal(a, b) for a, b in zip(base, got)), opts

@@ -576,6 +576,78 @@ def test_vq_argmin_large_random_vs_c_oracle(ops):
     assert (chosen <= dist_other + 1e-6).all()
 
 
+@pytest.mark.parametrize("split", [0, 1, 2, 4, 16, 3])
+def test_vq_screened_search_is_bit_identical(ops, split):
+    """The fp16-screened nearest-code search (omnitok_vq_argmin_screened: one fp16 MFMA per tile with a rigorous error
+    bound, exact re-evaluation of the candidates) returns the ids of the exact sweep and of the reference, bit for bit:
+    the reference's KATs (with duplicated codes: lowest index), every code-range split, ragged / empty sizes, inputs far
+    off the unit sphere, codebooks full of duplicates (more candidate tiles than the list holds), inputs outside fp16's
+    range and non-finite rows (those must match whatever the exact kernel returns)."""
+    from omnitokenizer_amd import _lib
+    _lib.set_option("vq_screen_split", split)
+    try:
+        for n_codes in (8192, 16384):
+            g = np.load(os.path.join(GOLDEN, f"vq_kat_{n_codes}.npz"))
+            z, E, ids_ref = torch.from_numpy(g["z"]), torch.from_numpy(g["codebook"]), g["ids"].astype(np.int64)
+            ids = ops.vq_argmin_screened(dev(z), dev(E)).cpu().numpy()
+            assert np.array_equal(ids, ids_ref), f"{n_codes}: {(ids != ids_ref).sum()} of {ids.size} ids differ"
+            for n in (1, 31, 257, 1000):
+                assert np.array_equal(ops.vq_argmin_screened(dev(z[:n]), dev(E)).cpu().numpy(), ids_ref[:n])
+            assert ops.vq_argmin_screened(dev(z[:0]), dev(E)).numel() == 0
+        rng = np.random.default_rng(11)
+        zz = (rng.standard_normal((3000, 8)) * 3.0).astype(np.float32)
+        EE = rng.standard_normal((2048, 8)).astype(np.float32)
+        got = ops.vq_argmin_screened(dev(torch.from_numpy(zz)), dev(torch.from_numpy(EE))).cpu().numpy()
+        assert np.array_equal(got, c_oracle.vq_argmin(zz, EE))
+        # duplicates: two far apart, and a codebook where ONE vector fills 9 tiles (more candidates than the list holds)
+        g = np.load(os.path.join(GOLDEN, "vq_kat_8192.npz"))
+        E2 = torch.from_numpy(g["codebook"]).clone()
+        E2[8000] = E2[100]
+        q = E2[[100, 8000, 100]].contiguous()
+        assert ops.vq_argmin_screened(dev(q), dev(E2)).cpu().tolist() == [100, 100, 100]
+        E3 = E2.clone()
+        E3[3000:3000 + 9 * 32] = E3[77]
+        q3 = torch.cat([E3[[77, 3100]], torch.from_numpy(g["z"][:500])])
+        want = ops.vq_argmin(dev(q3), dev(E3)).cpu()
+        assert torch.equal(ops.vq_argmin_screened(dev(q3), dev(E3)).cpu(), want) and want[:2].tolist() == [77, 77]
+        # rows outside fp16's range, tiny rows, zeros, inf and NaN rows: whatever the exact kernel answers
+        zb = torch.from_numpy(g["z"][:256]).clone()
+        zb[0] *= 1e6
+        zb[1] *= 4e4
+        zb[2] *= 1e-30
+        zb[3] = 0.0
+        zb[4, 3] = float("inf")
+        zb[5, 0] = float("nan")
+        zb[6] = float("-inf")
+        E1 = torch.from_numpy(g["codebook"])
+        assert torch.equal(ops.vq_argmin_screened(dev(zb), dev(E1)).cpu(), ops.vq_argmin(dev(zb), dev(E1)).cpu())
+        # a codebook outside fp16's range / with a non-finite entry: every row takes the exact evaluation
+        for bad in (7e4, float("inf"), float("nan")):
+            Eb = E1.clone()
+            Eb[5000, 2] = bad
+            zq = torch.from_numpy(g["z"][:300])
+            assert torch.equal(ops.vq_argmin_screened(dev(zq), dev(Eb)).cpu(), ops.vq_argmin(dev(zq), dev(Eb)).cpu())
+    finally:
+        _lib.set_option("vq_screen_split", 0)
+
+
+def test_vq_screened_large_random_vs_exact(ops):
+    """262 144 unit-norm rows (the C3 batch is 163 840) x 8192 and 16 384 codes, and heavy-tailed codebooks: screened ==
+    exact on every row; a slice against the scalar C oracle."""
+    rng = np.random.default_rng(5)
+    for n_codes, scale in ((8192, 1.0), (16384, 1.0), (8192, 0.05), (8192, 30.0)):
+        E = (rng.standard_normal((n_codes, 8)) * scale).astype(np.float32)
+        if scale == 30.0:
+            E *= rng.standard_t(3, size=(n_codes, 1)).astype(np.float32)   # a few codes with very large norms
+        z = rng.standard_normal((262144, 8), dtype=np.float32)
+        z /= np.linalg.norm(z, axis=1, keepdims=True)
+        zd, Ed = dev(torch.from_numpy(z)), dev(torch.from_numpy(E))
+        a = ops.vq_argmin_screened(zd, Ed).cpu().numpy()
+        b = ops.vq_argmin(zd, Ed).cpu().numpy()
+        assert np.array_equal(a, b), f"{n_codes} codes x {scale}: {(a != b).sum()} rows differ"
+        assert np.array_equal(a[:2048], c_oracle.vq_argmin(z[:2048], E))
+
+
 def test_vq_idempotence_full_codebook(ops):
     """Quantising the code vectors themselves returns their own indices (property test at the
     full codebook size)."""
@@ -583,3 +655,4 @@ def test_vq_idempotence_full_codebook(ops):
     E = c.sd["codebook.embeddings"]
     ids = ops.vq_argmin(dev(E), dev(E)).cpu()
     assert torch.equal(ids, torch.arange(E.shape[0]))
+    assert torch.equal(ops.vq_argmin_screened(dev(E), dev(E)).cpu(), ids)
