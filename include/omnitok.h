@@ -445,7 +445,7 @@ int omnitok_vq_argmin(const float *z, const float *packed, const float *ee, int6
  * evaluates a coarse distance with a rigorous error bound, the codes within that bound of the coarse minimum (almost always
  * one tile) are re-evaluated with the exact k-ordered fp32 chain of omnitok_vq_argmin, first minimum kept.  Inputs outside
  * fp16's range, non-finite inputs and codebooks with more than four candidate tiles per row take the exact evaluation for
- * every tile.  screen[n_codes * 4 + 4] floats from omnitok_vq_screen_prepare(E, ee) (ee from omnitok_vq_prepare). */
+ * every tile.  screen[n_codes * 8 + 4] floats from omnitok_vq_screen_prepare(E, ee) (ee from omnitok_vq_prepare). */
 int omnitok_vq_screen_prepare(const float *codebook, const float *ee, int n_codes, int cdim, float *screen,
                               omnitok_stream_t stream);
 int omnitok_vq_argmin_screened(const float *z, const float *packed, const float *ee, const float *screen, int64_t n,

@@ -794,7 +794,7 @@ extern "C" int omnitok_engine_finalize(omnitok_engine *e, omnitok_stream_t strea
         if (int rc = omnitok_vq_prepare(W(e, k_embed(c)), c.n_codes, 8, e->cb_packed, e->cb_ee, stream))
             return rc;
         if (!c.external_codebook) {  // fp16 screening fragments + norm bounds of the screened search (vq.hip)
-            if (int rc = alloc_f(e, &e->cb_screen, (int64_t)c.n_codes * 4 + 4)) return rc;
+            if (int rc = alloc_f(e, &e->cb_screen, (int64_t)c.n_codes * 8 + 4)) return rc;
             if (int rc = omnitok_vq_screen_prepare(W(e, k_embed(c)), e->cb_ee, c.n_codes, 8, e->cb_screen, stream)) return rc;
         }
         // F.embedding + post_vq_conv as one table (reference omnitokenizer.py:270, 156-160)

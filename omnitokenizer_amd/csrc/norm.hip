@@ -8,8 +8,13 @@ namespace omnitok {
 constexpr int LN_MAX_V4 = 4;  // up to 4 float4 per lane -> dim <= 1024
 
 // mean / rstd of a row held as nv float4 per lane (two-pass: mean, then centred sum of squares)
+// Every operation is stated (contraction off, the fused multiply-adds written out): left to the compiler, the two squares
+// of a pair were fused as fma(a, a, b * b) in one kernel and fma(b, b, a * a) in another that inlines this same function
+// with compile-time sizes -- 6 % of rows then differed by one unit in the last place of rstd between layernorm_kernel and
+// layernorm_prevq_kernel (r05, tools/r05/prevq_debug.py).  Now every kernel that shares this function rounds alike.
 __device__ __forceinline__ void row_stats(const f32x4 *v, int nv, int lane, int dim, float eps, float &mean,
                                           float &rstd) {
+#pragma clang fp contract(off)
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < LN_MAX_V4; ++i)
@@ -21,7 +26,7 @@ __device__ __forceinline__ void row_stats(const f32x4 *v, int nv, int lane, int 
     for (int i = 0; i < LN_MAX_V4; ++i)
         if (i < nv && (lane + 64 * i) * 4 < dim) {
             const float a = v[i][0] - mean, b = v[i][1] - mean, c = v[i][2] - mean, d = v[i][3] - mean;
-            q += (a * a + b * b) + (c * c + d * d);
+            q += __builtin_fmaf(a, a, b * b) + __builtin_fmaf(c, c, d * d);
         }
     q = wave_allsum(q);
     rstd = 1.0f / sqrtf(q / (float)dim + eps);

@@ -894,14 +894,15 @@ extern "C" int omnitok_vq_argmin(const float *z, const float *packed, const floa
     return launch_vq<VQ_CODEBOOK>(z, packed, ee, n, n_codes, ids, stream);
 }
 
-// screen[n_codes * 4 + 4] floats: n_codes x 16 bytes of fp16 screening fragments (tile-major, MFMA A-fragment order) followed
-// by {max |E_c|_2, max ee_c, max |E_ck|, 0}
+// screen[n_codes * 8 + 4] floats: 32 bytes per code of fp16 screening fragments (per tile of 32 codes 64 lanes x 16 B in MFMA
+// A-fragment order: lanes 0..31 the code's 8 fp16 coordinates, lanes 32..63 its ee as two fp16 halves) followed by
+// {max |E_c|_2, max ee_c, max |E_ck|, 0}
 extern "C" int omnitok_vq_screen_prepare(const float *codebook, const float *ee, int n_codes, int cdim, float *screen,
                                          omnitok_stream_t stream_) {
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     OT_CHECK_ARG(codebook && ee && screen, "vq_screen_prepare: null pointer");
     OT_CHECK_ARG(cdim == 8 && n_codes % 32 == 0 && n_codes > 0 && aligned16(screen), "vq_screen_prepare: need cdim == 8, n_codes %% 32 == 0");
-    unsigned *consts = reinterpret_cast<unsigned *>(screen + (int64_t)n_codes * 4);
+    unsigned *consts = reinterpret_cast<unsigned *>(screen + (int64_t)n_codes * 8);
     if (int rc = device_fill_u32(consts, 0u, 4, stream)) return rc;
     hipLaunchKernelGGL(vq_screen_prepare_kernel, dim3((n_codes * 2 + 255) / 256), dim3(256), 0, stream, codebook, ee, n_codes,
                        reinterpret_cast<u32x4 *>(screen), consts);
@@ -918,9 +919,12 @@ extern "C" int omnitok_vq_argmin_screened(const float *z, const float *packed, c
     OT_CHECK_ARG(aligned16(z) && aligned16(packed) && aligned16(ee) && aligned16(screen), "vq_argmin_screened: unaligned");
     const int64_t blocks = (n + VQ_ROWS_PER_BLOCK - 1) / VQ_ROWS_PER_BLOCK;
     const int ntiles = n_codes >> 5;
-    // splits of the code range: only to fill the chip (512 workgroup slots) -- every split pays a rescan of its own best tile
+    // splits of the code range, from the sweep in profiles/r05_vq_screen.txt (C3 163 840 x 8192: 378 / 222 / 130 / 168 / 243 us
+    // at 1 / 2 / 4 / 8 / 16 splits; C5 69 632 x 16 384: best at 4-8; one clip / one image: best at 16): about 64 tiles per
+    // workgroup, more splits only while the launch has fewer than 1024 workgroups and a split keeps >= 16 tiles
     int nsplit = 1;
-    while (blocks * nsplit < 512 && nsplit < 16 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
+    while (ntiles / nsplit > 64 && nsplit < 16) nsplit *= 2;
+    while (blocks * nsplit < 1024 && nsplit < 16 && ntiles / (nsplit * 2) >= 16) nsplit *= 2;
     if (g_vq_screen_split >= 1) nsplit = g_vq_screen_split;
     if (nsplit > ntiles) nsplit = ntiles;
     const int tiles_per = (ntiles + nsplit - 1) / nsplit;
@@ -930,7 +934,7 @@ extern "C" int omnitok_vq_argmin_screened(const float *z, const float *packed, c
         if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(vq_screen_kernel<true>), lds)) return rc;
     }
     const u32x4 *frag = reinterpret_cast<const u32x4 *>(screen);
-    const float *consts = screen + (int64_t)n_codes * 4;
+    const float *consts = screen + (int64_t)n_codes * 8;
     const dim3 grid((unsigned)blocks, nsplit);
     if (nsplit == 1) {
         hipLaunchKernelGGL((vq_screen_kernel<false>), grid, dim3(256), lds, stream, z, packed, ee, frag, consts, n, n_codes, ids);

@@ -614,7 +614,7 @@ def vq_screen_prepare(codebook, ee):
     """fp16 screening fragments + norm bounds for vq_argmin_screened (include/omnitok.h omnitok_vq_screen_prepare)."""
     codebook = _req(codebook, "codebook")
     n_codes, cdim = codebook.shape
-    screen = torch.empty(n_codes * 4 + 4, device=codebook.device, dtype=torch.float32)
+    screen = torch.empty(n_codes * 8 + 4, device=codebook.device, dtype=torch.float32)
     check(_lib.load().omnitok_vq_screen_prepare(_p(codebook), _p(_req(ee, "ee")), n_codes, cdim, _p(screen), _stream()),
           "vq_screen_prepare")
     return screen

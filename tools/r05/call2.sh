@@ -2,10 +2,10 @@
 # r05 GPU call 2: fused LayerNorm + pre_vq (rewritten), screened VQ search, encode() state mutation, checkpoint tool -- tests + timing
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-O=gpurun_out/r05c2
+O=gpurun_out/r05c3
 mkdir -p $O
-python -m pytest tests/test_gpu_ops.py -q -x -k "prevq or pre_vq or vq_ or peg or layernorm" 2>&1 | tail -15 > $O/tests_ops.txt
-python -m pytest tests/test_gpu_e2e.py -q -x -k "prevq_fusion or mutates or ckpt_parity or forward_codebook or forward_log or (encode_decode_vs_reference_golden and (r256 or r64))" 2>&1 | tail -15 > $O/tests_e2e.txt
+python tools/r05/prevq_debug.py > $O/prevq_debug.txt 2>&1; python -m pytest tests/test_gpu_ops.py -q -k "prevq or pre_vq or vq_ or peg or layernorm" 2>&1 | tail -15 > $O/tests_ops.txt
+python -m pytest tests/test_gpu_e2e.py -q -k "prevq_fusion or mutates or ckpt_parity or forward_codebook or forward_log or (encode_decode_vs_reference_golden and (r256 or r64))" 2>&1 | tail -15 > $O/tests_e2e.txt
 python - > $O/vq_timing.txt 2>&1 <<'PY'
 import torch, numpy as np, time
 from omnitokenizer_amd import ops, _lib
