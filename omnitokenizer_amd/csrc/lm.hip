@@ -71,13 +71,7 @@ struct LmMerge {
     int n_head, hd, nchunk;
 };
 
-// KS = 2 (balanced grids, "lm_ksplit"): the two waves of a pair share ROWS rows and take one half of K each (partials
-// combined through LDS in a fixed order), so a workgroup covers 2 * ROWS rows and ROWS can be chosen per layer shape so
-// that the launch is a whole number of workgroups per CU: N = 1536 -> 768 x (ROWS 1), 4608 -> 768 x (ROWS 3),
-// 6144 -> 768 x (ROWS 4).  With whole rows per wave the C x C / 4C x C layers launch 384 workgroups = 1.5 per CU (half the
-// chip streams twice as long as the other half: +1.8 us on the FC2 layer) and the 3C x C layer 576 = 2.25 per CU.
-// The whole K row of the activations is staged in LDS at once (BQ * K * 4 bytes).
-template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM, int KS = 1>
+template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
 __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ bias, const float *residual,
                                                       const float *__restrict__ g, const float *__restrict__ beta,
@@ -85,12 +79,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [BQ][kp]
     __shared__ float s_mean[BQ], s_rstd[BQ];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = KS == 2 ? (blockIdx.x * 2 + (wave >> 1)) * ROWS : (blockIdx.x * 4 + wave) * ROWS;
-    const int kp = KS == 2 ? K : (K < LM_KP ? K : LM_KP);
-    const int nch_all = K >> 8;  // 256-float chunks
-    // this wave's chunk range [cb, nch)
-    const int cb = KS == 2 ? (wave & 1) * (nch_all >> 1) : 0;
-    const int nch = KS == 2 ? ((wave & 1) ? nch_all : (nch_all >> 1)) : nch_all;
+    const int row0 = (blockIdx.x * 4 + wave) * ROWS;
+    const int kp = K < LM_KP ? K : LM_KP;
+    const int nch = K >> 8;  // 256-float chunks
     const float *wr[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) wr[r] = w + (int64_t)(row0 + r < N ? row0 + r : N - 1) * K + lane * 4;
@@ -105,7 +96,7 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
         }
     };
     f32x4 wa[ROWS][U], wb[ROWS][U];
-    load_w(wa, cb);  // in flight while the LayerNorm statistics / merge weights are computed
+    load_w(wa, 0);  // in flight while the LayerNorm statistics / merge weights are computed
     // LayerNorm with the whole row in one LDS panel (K <= LM_KP, every GPT block): x, gamma and beta are requested
     // together at kernel start (one memory round trip instead of three dependent ones), the two-pass statistics are
     // block-wide reductions over registers, and the normalised row goes straight to LDS.
@@ -211,10 +202,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     };
 
     constexpr int CPP = LM_KP / 256;  // chunks per panel (a multiple of 2 * U)
-    const int panel_chunks = KS == 2 ? nch_all : CPP;  // KS == 2: one panel = the whole row
-    for (int p0 = 0; p0 < nch_all; p0 += panel_chunks) {
+    for (int p0 = 0; p0 < nch; p0 += CPP) {
         __syncthreads();  // previous panel fully consumed (and s_mean / s_rstd / s_f visible)
-        const int pk = (nch_all - p0 < panel_chunks ? nch_all - p0 : panel_chunks) * 256;  // floats in this panel
+        const int pk = (nch - p0 < CPP ? nch - p0 : CPP) * 256;  // floats in this panel
         for (int i = tid * 4; i < BQ * pk && !ln_fast; i += 1024) {
             const int b = i / pk, k = i - b * pk;
             f32x4 v;
@@ -263,8 +253,8 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
             *reinterpret_cast<f32x4 *>(xs + b * kp + k) = v;
         }
         __syncthreads();
-        const int pend = KS == 2 ? nch : (p0 + CPP < nch ? p0 + CPP : nch);
-        for (int c0 = KS == 2 ? cb : p0; c0 < pend; c0 += 2 * U) {
+        const int pend = p0 + CPP < nch ? p0 + CPP : nch;
+        for (int c0 = p0; c0 < pend; c0 += 2 * U) {
             load_w(wb, c0 + U);  // may belong to the next panel: only the weights are prefetched
             consume(wa, c0, p0);
             if (c0 + U < pend) {
@@ -279,27 +269,11 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
             }
         }
     }
-    if (KS == 1 && row0 >= N) return;
+    if (row0 >= N) return;
 #pragma unroll
     for (int r = 0; r < ROWS; ++r)
 #pragma unroll
         for (int b = 0; b < BQ; ++b) acc[r][b] = wave_allsum(acc[r][b]);
-    if constexpr (KS == 2) {
-        // second half's partial sums -> LDS -> added by the first half's wave: (first half) + (second half), always
-        __shared__ float s_half[2][ROWS * BQ];
-        if ((wave & 1) && lane == 0) {
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-                for (int b = 0; b < BQ; ++b) s_half[wave >> 1][r * BQ + b] = acc[r][b];
-        }
-        __syncthreads();
-        if ((wave & 1) || row0 >= N) return;
-#pragma unroll
-        for (int r = 0; r < ROWS; ++r)
-#pragma unroll
-            for (int b = 0; b < BQ; ++b) acc[r][b] += s_half[wave >> 1][r * BQ + b];
-    }
     // lane (r * BQ + b) finishes and stores output (b, row0 + r)
     float mine = 0.0f;
 #pragma unroll
@@ -583,34 +557,6 @@ static void launch_gemv_cfg(const float *x, const float *w, const float *bias, c
                        lds, stream, x, w, bias, residual, g, beta, y, N, K, mg);
 }
 
-int g_lm_ksplit = 1;  // "lm_ksplit": 1 (default) balanced K-split grids for up to 2 streams | 0 whole rows per wave
-
-template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
-static void launch_gemv_ks(const float *x, const float *w, const float *bias, const float *residual, const float *g,
-                           const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
-    const int lds = BQ * K * 4;
-    if (lds > 65536) (void)set_max_dynamic_lds(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM, 2>), lds);
-    hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM, 2>), dim3((N + 2 * ROWS - 1) / (2 * ROWS)), dim3(256), lds, stream,
-                       x, w, bias, residual, g, beta, y, N, K, mg);
-}
-
-// rows per wave pair of the K-split form: whole workgroups per CU first (cost = rounds over 256 CUs x rows), then the grid
-// closest to 3 workgroups per CU
-static int lm_ksplit_rows(int N) {
-    int best_r = 0;
-    long best_cost = 1l << 60, best_dist = 1l << 60;
-    for (int r = 4; r >= 1; --r) {
-        if (N % (2 * r)) continue;
-        const long wgs = N / (2 * r), cost = ((wgs + 255) / 256) * r, dist = labs(wgs - 768);
-        if (cost < best_cost || (cost == best_cost && dist < best_dist)) {
-            best_cost = cost;
-            best_dist = dist;
-            best_r = r;
-        }
-    }
-    return best_r;
-}
-
 template <int BQ, int ACT, bool LN, bool XM>
 static void launch_gemv_rows(const float *x, const float *w, const float *bias, const float *residual, const float *g,
                              const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
@@ -621,14 +567,6 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
     // fixed cost of each of its 122 dependent launches, after which the kernels stream at 5-7 TB/s.)
     // Wide outputs: 2 rows x 4 chunks x 2 buffers = 16 KiB per wave, i.e. a whole K = 1536 row pair is requested
     // before the LayerNorm prologue finishes (the matrix streams from HBM while x is normalised).
-    if constexpr (BQ <= 2) {
-        // K-split pairs: needs the whole activation row in LDS (K <= 8192 floats per stream) and an even chunk count
-        const int r = (g_lm_ksplit && K % 512 == 0 && BQ * K * 4 <= 64 * 1024) ? lm_ksplit_rows(N) : 0;
-        if (r == 1) return launch_gemv_ks<BQ, 1, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-        if (r == 2) return launch_gemv_ks<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-        if (r == 3) return launch_gemv_ks<BQ, 3, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-        if (r == 4) return launch_gemv_ks<BQ, 4, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-    }
     if (N <= 2048) launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
     else if (g_lm_wide_u == 2) launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
     else launch_gemv_cfg<BQ, 2, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);

@@ -30,23 +30,9 @@ def lib():
     return _lib.load()
 
 
-@pytest.mark.parametrize("ksplit", [1, 0])
 @pytest.mark.parametrize("B", [1, 2, 3, 5, 8, 11])
-@pytest.mark.parametrize("N,K", [(1536, 1536), (4608, 1536), (6144, 1536), (1536, 6144), (8192, 1536), (300, 256), (8193, 768),
-                                 (1538, 512)])
-def test_gemv(lib, B, N, K, ksplit):
-    """ksplit 1 (default): the balanced grids of r05 -- wave pairs split K, rows per pair chosen so that the launch is a whole
-    number of workgroups per CU (1536 -> 1, 4608 -> 3, 6144 / 8192 -> 4 rows per pair; 1538 -> 1 with a ragged last
-    workgroup... no: N % (2 rows) must hold, 1538 = 2 x 769 -> 1); odd N and K % 512 != 0 take the whole-row form."""
-    from omnitokenizer_amd import _lib
-    _lib.set_option("lm_ksplit", ksplit)
-    try:
-        _gemv_case(lib, B, N, K)
-    finally:
-        _lib.set_option("lm_ksplit", 1)
-
-
-def _gemv_case(lib, B, N, K):
+@pytest.mark.parametrize("N,K", [(1536, 1536), (4608, 1536), (6144, 1536), (1536, 6144), (8192, 1536), (300, 256), (8193, 768)])
+def test_gemv(lib, B, N, K):
     x, w, bias, res = rnd(B, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(B, N, seed=4)
     g, beta = rnd(K, seed=5, scale=0.1) + 1.0, rnd(K, seed=6, scale=0.1)
     s = torch.cuda.current_stream().cuda_stream
