@@ -242,8 +242,14 @@ def run(a):
         if "vq_argmin" in kernels and kernels["vq_argmin"]["ms_per_step"] > 0:
             vq_bytes = Ltok * 40 + cfg.n_codes * 32
             kernels["vq_argmin"]["compulsory_gbs"] = round(vq_bytes / (kernels["vq_argmin"]["ms_per_step"] * 1e-3) / 1e9, 2)
-            # the search runs on the fp32-input MFMA: its mode roof IS the fp32 peak (fp16-split kernels carry no such field)
+            # frac_f32_peak = algorithmic distance flops (2 N n_codes 8) / family time / the fp32-MFMA peak: the roof
+            # of the EXACT sweep.  Since r05 the default search screens with one fp16 MFMA per 32 x 32 tile and re-evaluates only
+            # the candidates exactly ("vq_screen" 1, same ids bit for bit): it does a fifth of that matrix work, is VALU-bound
+            # (the min tree), and this fraction can exceed what the fp32 pipe could deliver
             kernels["vq_argmin"]["frac_f32_peak"] = kernels["vq_argmin"].get("frac_of_mode_roof")
+            kernels["vq_argmin"]["search"] = ("screened: fp16-MFMA coarse distance with a rigorous error bound + exact fp32 "
+                                              "re-evaluation of the candidate tiles" if int(opts.get("vq_screen", 1)) and
+                                              not cfg.use_external_codebook else "exact fp32-MFMA sweep")
 
         if is_image:
             wl_name = "C2" if (B, a.resolution) == (64, 256) else "images"
@@ -259,7 +265,7 @@ def run(a):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.gemm_mode == 0 else (f"f32 ({gm_name}, fp32 accumulate; "
                                                            + ("spatial attention likewise; " if a.gemm_mode == 2 else "attention and ")
-                                                           + "VQ on fp32 MFMA)"),
+                                                           + "VQ: fp16-MFMA screen + exact fp32 re-evaluation, ids bit-exact)"),
             "gemm_mode": a.gemm_mode, "data": "synthetic",
             "config": {"workload": wl_name + f": B={B}/GPU " + (f"{a.resolution}x{a.resolution} images" if is_image
                                     else f"{a.frames}x{a.resolution}x{a.resolution} clips")

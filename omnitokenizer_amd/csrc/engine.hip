@@ -348,7 +348,7 @@ static int decode_latent(omnitok_engine *e, LatentKind kind, const void *latent,
     // tensor after norm_out, no [L, K] pixel rows, no un-patchify pass.
     bool plain_blocks = true;  // no pooling / Up blocks in the last Transformer: its grid is the token grid
     for (const char *q = c.dec_block; *q; ++q) plain_blocks = plain_blocks && (*q == 't' || *q == 'w');
-    const bool px_pl = plain_blocks && gemm_pl_of(e, (int64_t)B * T2 * gh2 * gw2) && gemm_mode_of(e) == 2 && D == 512 && !c.patch_embed_cnn && S % 256 == 0 && p == 8 && gw2 % 32 == 0 && gh2 * p == H &&
+    const bool px_pl = plain_blocks && gemm_pl_of(e, (int64_t)B * T2 * gh2 * gw2) && gemm_mode_of(e) == 2 && D == 512 && !c.patch_embed_cnn && S % 256 == 0 && p == 8 && gw2 % 32 == 0 &&
                        aligned16(pixels_out) &&  // the un-patchify epilogue's own preconditions (gemm_pl.hip PL_UNPATCH): a caller
                                                  // whose output is only 4-byte aligned takes the gemm + unpatchify path instead
                        e->plw.count(e->px_w[0]) && (T2 == 1 || e->plw.count(e->px_w[1])) && e->dec_s.out_bound > 0.0f &&
