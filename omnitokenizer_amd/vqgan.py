@@ -381,7 +381,7 @@ class OmniTokenizer_VQGAN(nn.Module):
         # the eval-time state mutation of reference Codebook.forward (codebook.py:122-143); forward(log_image=True) passes
         # _stats_out to receive the statistics of this one update.  Not recorded into a HIP graph: `call_cnt` is host state.
         if not self.use_external_codebook and (_stats_out is not None or self.update_codebook_usage_on_encode) \
-                and not torch.cuda.is_current_stream_capturing():
+                and ids.numel() > 0 and not torch.cuda.is_current_stream_capturing():
             stats = self._update_codebook_usage(ids)
             if _stats_out is not None:
                 _stats_out.update(stats)
