@@ -79,7 +79,6 @@ extern int g_vq_variant;
 extern int g_vq_screen;
 extern int g_vq_screen_split;
 extern int g_lm_wide_u;
-extern int g_lm_prefetch;
 }  // namespace omnitok
 
 extern "C" int omnitok_set_option(const char *name, int value) {
@@ -107,7 +106,6 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;
     else if (!strcmp(name, "attn_window_mode")) omnitok::g_attn_window_mode = value;
     else if (!strcmp(name, "lm_wide_u")) omnitok::g_lm_wide_u = value;
-    else if (!strcmp(name, "lm_prefetch")) omnitok::g_lm_prefetch = value;
     else if (!strcmp(name, "h2_dbg")) omnitok::g_h2_dbg = value;
     else if (!strcmp(name, "h2_tile")) omnitok::g_h2_tile = value;
     else if (!strcmp(name, "x3_dbg")) omnitok::g_x3_dbg = value;

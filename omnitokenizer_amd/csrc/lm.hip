@@ -28,7 +28,6 @@
 namespace omnitok {
 
 constexpr int LM_CHUNK = 256;   // keys per attention workgroup
-typedef unsigned int u32x4_lm __attribute__((ext_vector_type(4)));
 
 // x = token_embedding + position_embedding (reference gpt.py:209-226 / 238-258): the token embedding is
 // tok_emb[idx] or an explicit vector (`embeddings=`, emb [B, C]); the position embedding is pos_emb[pos],
@@ -65,30 +64,6 @@ constexpr int LM_KP = 2048;        // K panel staged in LDS (BQ * LM_KP * 4 B <=
                                    // FC2 input at B = 1 measured the same: 1.114 ms / token)
 constexpr int LM_MAX_CHUNKS = 32;  // attention chunks per sequence: max_len <= 8192
 constexpr int LM_MAX_HEADS = 32;   // (bounds the merge-weight table in LDS: B * heads * chunks floats)
-
-// "lm_prefetch" n > 0: while layer i computes, a side stream reads the weights of layer i + n (plain loads: the lines
-// are allocated in the memory-side Infinity Cache, 256 MiB ~ two layers of 113 MB) so that the dependent GEMV chain of that
-// layer streams from the cache instead of starting cold at HBM after every one of its five launches.  0 = off (default).
-int g_lm_prefetch = 0;
-
-__global__ __launch_bounds__(256) void lm_prefetch_kernel(const u32x4_lm *__restrict__ a, int64_t na, const u32x4_lm *__restrict__ b,
-                                                          int64_t nb, const u32x4_lm *__restrict__ c, int64_t nc,
-                                                          const u32x4_lm *__restrict__ d, int64_t nd, unsigned *sink) {
-    const int64_t stride = (int64_t)gridDim.x * 256, gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    unsigned acc = 0;
-    const u32x4_lm *ptr[4] = {a, b, c, d};
-    const int64_t cnt[4] = {na, nb, nc, nd};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        int64_t i = gid;
-        for (; i + 3 * stride < cnt[k]; i += 4 * stride) {   // four 16-byte loads in flight per lane
-            const u32x4_lm v0 = ptr[k][i], v1 = ptr[k][i + stride], v2 = ptr[k][i + 2 * stride], v3 = ptr[k][i + 3 * stride];
-            acc ^= v0[0] ^ v1[1] ^ v2[2] ^ v3[3];
-        }
-        for (; i < cnt[k]; i += stride) acc ^= ptr[k][i][0];
-    }
-    if (acc == 0x9e3779b9u && sink) *sink = acc;  // keeps the loads alive; practically never stores
-}
 
 struct LmMerge {
     const float *part;         // [B][n_head][nchunk][2 + hd]
@@ -727,11 +702,6 @@ struct omnitok_lm {
     // grow-only prefill workspace (rows = B * T)
     float *pf = nullptr;
     int64_t pf_floats = 0;
-    // "lm_prefetch": a side stream that reads the NEXT layers' weights while a layer computes (fork / join events inside the
-    // step, so the whole thing is capturable into one HIP graph); created by omnitok_lm_alloc_cache
-    hipStream_t pre_stream = nullptr;
-    std::vector<hipEvent_t> pre_fork;
-    hipEvent_t pre_join = nullptr;
 };
 
 static const float *LW(omnitok_lm *lm, const std::string &k) {
@@ -793,9 +763,6 @@ extern "C" void omnitok_lm_destroy(omnitok_lm *lm) {
     for (void *p : lm->owned) (void)hipFree(p);
     lm_free_cache(lm);
     if (lm->err_flag) (void)hipFree(lm->err_flag);
-    for (auto ev : lm->pre_fork) (void)hipEventDestroy(ev);
-    if (lm->pre_join) (void)hipEventDestroy(lm->pre_join);
-    if (lm->pre_stream) (void)hipStreamDestroy(lm->pre_stream);
     delete lm;
 }
 
@@ -905,12 +872,6 @@ extern "C" int omnitok_lm_alloc_cache(omnitok_lm *lm, int max_batch, int max_len
     lm->max_batch = max_batch;
     lm->max_len = max_len;
     lm->cache_bytes = per_layer * 2 * c.n_layer * 4;
-    if (!lm->pre_stream) {
-        OT_HIP(hipStreamCreateWithFlags(&lm->pre_stream, hipStreamNonBlocking));
-        lm->pre_fork.resize(c.n_layer);
-        for (auto &ev : lm->pre_fork) OT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        OT_HIP(hipEventCreateWithFlags(&lm->pre_join, hipEventDisableTiming));
-    }
     if (!lm->err_flag) {
         OT_HIP(hipMalloc(reinterpret_cast<void **>(&lm->err_flag), sizeof(int)));
         OT_HIP(hipMemset(lm->err_flag, 0, sizeof(int)));
@@ -958,21 +919,9 @@ extern "C" int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const floa
     hipLaunchKernelGGL(lm_embed_kernel, dim3(B), dim3(256), 0, stream, idx, pos, LW(lm, "tok_emb.weight"),
                        LW(lm, "pos_emb"), emb, pos_extra, lm->x, C, c.vocab_size, c.block_size);
     OT_LAUNCH_CHECK("lm_embed");
-    const bool prefetch = g_lm_prefetch > 0 && lm->pre_stream && c.n_layer > g_lm_prefetch;
     for (int i = 0; i < c.n_layer; ++i) {
         const LmLayer &L = lm->layers[i];
         float *kc = lm->kv + (int64_t)(2 * i) * per_layer, *vc = kc + per_layer;
-        if (prefetch) {  // fork: the side stream may start reading layer i + n's weights once layer i starts
-            const LmLayer &P = lm->layers[(i + g_lm_prefetch) % c.n_layer];
-            const int64_t cc = (int64_t)C * C / 4;  // 16-byte units
-            OT_HIP(hipEventRecord(lm->pre_fork[i], stream));
-            OT_HIP(hipStreamWaitEvent(lm->pre_stream, lm->pre_fork[i], 0));
-            hipLaunchKernelGGL(lm_prefetch_kernel, dim3(512), dim3(256), 0, lm->pre_stream,
-                               reinterpret_cast<const u32x4_lm *>(P.wqkv), 3 * cc, reinterpret_cast<const u32x4_lm *>(P.wproj), cc,
-                               reinterpret_cast<const u32x4_lm *>(P.w1), 4 * cc, reinterpret_cast<const u32x4_lm *>(P.w2), 4 * cc,
-                               reinterpret_cast<unsigned *>(lm->err_flag));
-            OT_LAUNCH_CHECK("lm_prefetch");
-        }
         // x + proj(attn(ln1(x)))   (reference gpt.py:159-161)
         if (int rc = omnitok_lm_gemv(lm->x, L.wqkv, L.bqkv, nullptr, L.ln1w, L.ln1b, lm->qkv, B, 3 * C, C, 0, stream))
             return rc;
@@ -995,10 +944,6 @@ extern "C" int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const floa
     if (advance) {
         hipLaunchKernelGGL(lm_advance_kernel, dim3(1), dim3(64), 0, stream, pos, cache_len, B);
         OT_LAUNCH_CHECK("lm_advance");
-    }
-    if (prefetch) {  // join: the step (and a graph captured from it) ends when the side stream has drained
-        OT_HIP(hipEventRecord(lm->pre_join, lm->pre_stream));
-        OT_HIP(hipStreamWaitEvent(stream, lm->pre_join, 0));
     }
     return OMNITOK_OK;
 }
