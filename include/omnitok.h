@@ -215,7 +215,7 @@ typedef struct omnitok_pl_gemm {
     float ln_eps;
     int epilogue;               /* 0 fp32 | 1 GEGLU -> planes | 2 fp32 AND LayerNorm -> planes (N == 512) |     */
                                 /* 3 packed V planes of omnitok_attn_spatial_h2 | 4 packed Q | K planes |         */
-                                /* 5 fp32 pixels (un-patchify store, up_* below)                                 */
+                                /* 5 fp32 pixels (un-patchify store, up_* below) | 6 temporal scores | 7 temporal P.V */
     /* LayerNorm folded into the weight (epilogues 0, 3, 4): the operand a holds the CENTRED rows x - mean(x)
      * (omnitok_stats_pack), the weight rows n < fold_cols were multiplied by gamma before packing, and the epilogue finishes
      *   n <  fold_cols:  LayerNorm(x) . W^T = rstd_m ((x - mean_m) . (W o gamma)^T) + b_n     (b = W beta, or NULL)
@@ -256,6 +256,17 @@ typedef struct omnitok_pl_gemm {
     /* 0, or the number of leading k that are not zero padding in BOTH operands (planes and weight are laid out for K): the
      * K loop then stops after ceil(k_valid / 16) steps -- FF-out's K = 1408 holds 1365 hidden channels                */
     int k_valid;
+    /* epilogues 6 / 7: the temporal stage (reference attention.py:402-486, is_spatial = False, T' = 5, causal) without its
+     * q|k|v round trip.  The operand rows are permuted by omnitok_stats_pack_temporal: [tile of 64 sequences][half][time
+     * step][32 sequences], M = ceil(t_nseq / 64) * 320.  6: N = heads * 128 columns [q_h | k_h] per head (weight rows
+     * permuted accordingly, q rows LayerNorm-folded: fold_b / fold_u / w_scale in the same order), q_scale / k_scale [64],
+     * q_mul the SDPA scale, t_alibi [heads] or NULL -> tp[t_nseq][heads][40]: per query step 8 floats (e[0..4], 1 / sum e, 0, 0).
+     * 7: N = heads * 64 columns of V -> out_planes (K = N) at the TOKEN rows seq * 5 + t, scaled per clip by v_bound
+     * (x v_bound_dev[v_bound_stride * (seq / t_seqs_per_clip)]); t_out_scale[token row] = the factor that undoes it. */
+    float *tp;
+    int t_nseq, t_heads, t_seqs_per_clip;
+    const float *t_alibi;
+    float *t_out_scale;
 } omnitok_pl_gemm;
 int64_t omnitok_pl_planes_bytes(int64_t rows, int K, int row_pad);
 /* the factor that undoes the power-of-two scale derived from a static bound (a_scale_const of the consumer) */
@@ -281,6 +292,11 @@ int omnitok_stats_pack(const float *x, int64_t rows, int dim, float eps, int cen
  * of omnitok_attn_window_h2 directly. */
 int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim, float eps, int center, void *planes, int64_t m_pad,
                                float *a_scale, float *stats, int gh, int gw, int ws, omnitok_stream_t stream);
+/* ... and with the OUTPUT rows in the order the fused temporal stage wants (omnitok_pl_gemm epilogues 6 / 7): x [nseq * 5, dim]
+ * in token order (sequence, time step) -> centred planes, a_scale and stats at row ((s / 64) * 2 + (s % 64) / 32) * 160 +
+ * t * 32 + s % 32, ceil(nseq / 64) * 320 rows in all; bounds per clip of seqs_per_clip sequences as omnitok_row_stats. */
+int omnitok_stats_pack_temporal(const float *x, int64_t nseq, int dim, float eps, void *planes, float *a_scale,
+                                float *stats, float *bounds, int64_t seqs_per_clip, omnitok_stream_t stream);
 /* LayerNorm(x) [rows, dim] straight into hi|lo planes scaled by the power of two of `bound` (>= max |LayerNorm(x)|; the
  * consumer's a_scale_const = omnitok_pl_unscale(bound)): a standalone LayerNorm in front of a plane GEMM in one pass. */
 int omnitok_layernorm_planes(const float *x, int64_t rows, int dim, float eps, const float *gamma, const float *beta,

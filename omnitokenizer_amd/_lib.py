@@ -50,6 +50,8 @@ class OmnitokPlGemm(Structure):
         ("a_rpg", c_int64), ("a_gstride", c_int64), ("a_goff", c_int64),
         ("up_C", c_int), ("up_F", c_int), ("up_H", c_int), ("up_W", c_int), ("up_f0", c_int), ("up_t", c_int),
         ("up_pt", c_int), ("up_p", c_int), ("k_valid", c_int),
+        ("tp", c_void_p), ("t_nseq", c_int), ("t_heads", c_int), ("t_seqs_per_clip", c_int), ("t_alibi", c_void_p),
+        ("t_out_scale", c_void_p),
     ]
 
 
@@ -152,6 +154,7 @@ _PROTOS = {
     "omnitok_layernorm_planes": [P, I64, c_int, c_float, P, P, c_float, P, I64, P],
     "omnitok_attn_window_h2": [P, P, P, P, P, I64, P, c_float, c_float, c_float, c_int, c_int, c_int, c_int, P],
     "omnitok_stats_pack_windows": [P, I64, c_int, c_float, c_int, P, I64, P, P, c_int, c_int, c_int, P],
+    "omnitok_stats_pack_temporal": [P, I64, c_int, c_float, P, P, P, P, I64, P],
     "omnitok_attn_temporal_planes": [P, I64, P, P, I64, P, I64, P, P, c_float, P, c_int, I64, I64, c_int, c_int, P, P,
                                      c_float, c_int, P, P],
     # include/omnitok_comm.h

@@ -50,6 +50,9 @@ struct LayerT {  // 't' block (+ FF)
     // temporal attention over ONE token (images): softmax over a single key is exactly 1, the block is x + (x Wv^T) Wo^T.
     // wvo = Wo . Wv (fp64 accumulation, rounded once) lets the plane data flow run it as ONE GEMM from the planes of x
     const float *wvo = nullptr;
+    // fused temporal stage (gemm_pl.h PL_TSCORE): the folded to_q | to_k rows regrouped per head, [q_h (64) | k_h (64)] x heads,
+    // with their fold vectors in the same order (key of the gemm_pl packing: wqk_t)
+    const float *wqk_t = nullptr, *qk_t_fb = nullptr, *qk_t_fu = nullptr;
 };
 struct LayerW {  // 'w' block
     const float *ng, *nb, *wqkv, *wproj, *bproj, *bias_dense;
@@ -147,7 +150,7 @@ namespace omnitok {
 constexpr int N_BOUND_LAUNCHES = 64;  // row-statistics launches with ranges per encode / decode
 
 // process defaults of the per-engine modes (omnitok_set_option; engine_run.hip)
-extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl, g_pl_min_tokens, g_temporal_chunk, g_prevq_fuse, g_vq_screen;
+extern int g_gemm_mode, g_attn_mode, g_attn_vpack, g_gemm_pl, g_pl_min_tokens, g_temporal_chunk, g_prevq_fuse, g_vq_screen, g_temporal_fused;
 
 Geo geometry(const omnitok_config &c);
 bool walk_enc_grid(const char *block, int *gh, int *gw, int64_t *peak);

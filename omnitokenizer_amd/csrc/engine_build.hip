@@ -250,6 +250,21 @@ static int fold_ln_weight(omnitok_engine *e, const float *w, const float *gamma,
     return OMNITOK_OK;
 }
 
+// rows of the folded [to_q o gamma | to_k | to_v] weight regrouped per head for the fused temporal stage: out row
+// h * 128 + j = q row h * 64 + j (j < 64) or k row D + h * 64 + (j - 64); fb / fu likewise (fold_b is 0 on k rows, fold_u on q rows)
+__global__ __launch_bounds__(256) void regroup_qk_kernel(const float *__restrict__ w, const float *__restrict__ fb,
+                                                         const float *__restrict__ fu, int D, int K, float *__restrict__ wout,
+                                                         float *__restrict__ fbo, float *__restrict__ fuo) {
+    const int n = blockIdx.x;  // output row, 0 .. 2D - 1
+    const int h = n >> 7, j = n & 127;
+    const int src = j < 64 ? h * 64 + j : D + h * 64 + (j - 64);
+    for (int k = threadIdx.x; k < K; k += 256) wout[(int64_t)n * K + k] = w[(int64_t)src * K + k];
+    if (threadIdx.x == 0) {
+        fbo[n] = fb[src];
+        fuo[n] = fu[src];
+    }
+}
+
 // wvo[o][i] = sum_m wo[o][m] wv[m][i]  (both [D, D] row-major), fp64 accumulation.  One thread per output element.
 __global__ __launch_bounds__(256) void compose_vo_kernel(const float *__restrict__ wo, const float *__restrict__ wv, int D,
                                                          float *__restrict__ wvo) {
@@ -302,6 +317,19 @@ int build_transformer(omnitok_engine *e, TransformerW &tw, const std::string &pr
                 if (int rc = fold_ln_weight(e, L.t.wqkv, L.t.ng, L.t.nb, c.dim, 3 * c.dim, c.dim, &L.t.wqkv_fold, &L.t.fold_b,
                                             &L.t.fold_u, stream))
                     return rc;
+            if (!spatial && L.t.wqkv_fold && c.dim == c.heads * 64 && c.heads % 2 == 0) {
+                float *wq, *fb, *fu;
+                if (int rc = alloc_f(e, &wq, 2 * (int64_t)c.dim * c.dim)) return rc;
+                if (int rc = alloc_f(e, &fb, 2 * c.dim)) return rc;
+                if (int rc = alloc_f(e, &fu, 2 * c.dim)) return rc;
+                hipLaunchKernelGGL(regroup_qk_kernel, dim3(2 * c.dim), dim3(256), 0, stream, L.t.wqkv_fold, L.t.fold_b, L.t.fold_u,
+                                   c.dim, c.dim, wq, fb, fu);
+                OT_LAUNCH_CHECK("regroup_qk");
+                if (int rc = pack_pl(e, wq, c.dim, 2 * c.dim, c.dim, stream)) return rc;
+                L.t.wqk_t = wq;
+                L.t.qk_t_fb = fb;
+                L.t.qk_t_fu = fu;
+            }
             if (int rc = ln_range(e, L.t.ng, L.t.nb, c.dim, &L.t.ln_bound, nullptr, stream)) return rc;
             if (int rc = weight_range(e, L.t.wkv + (int64_t)c.dim * c.dim, c.dim, c.dim, c.dim, &L.t.vnorm, nullptr, stream))
                 return rc;

@@ -34,6 +34,11 @@ int g_temporal_chunk = 0;
 // "prevq_fuse" 1 (default): omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (omnitok_layernorm_prevq,
 // bit-identical) whenever nothing sits between the two (no deferred pools); 0: LayerNorm store, then omnitok_pre_vq.
 int g_prevq_fuse = 1;
+// "temporal_fused" 1 (default): temporal 't' blocks with T' == 5 (17-frame clips at temporal_patch_size 4), causal, on the plane
+// data flow run WITHOUT the fp32 q|k|v round trip (2 GB per block at C3): omnitok_stats_pack_temporal permutes the rows so that
+// a sequence's five steps sit in one lane pair, a q|k GEMM forms the softmax weights in its epilogue (PL_TSCORE) and a V GEMM
+// applies them in its own (PL_TPV), writing the out-projection's operand planes.  0: q|k|v GEMM + attn_temporal kernel.
+int g_temporal_fused = 1;
 // "qkv_pl" 1 (default, with gemm_pl): the q|k|v projection as a plane GEMM too -- one pass writes the row statistics and
 // the centred rows x - mean as planes (omnitok_stats_pack), the LayerNorm of the Q columns is folded into the weight and finished in the
 // epilogue, which for spatial attention also does RoPE + l2norm + scales and writes Q and K straight into the attention
@@ -261,6 +266,55 @@ int run_transformer(omnitok_engine *e, const TransformerW &tw, int B, int T, int
                 OT_RUN("gemm_out", gemm_f * D,
                        eg_gemm(e, e->AO.p, D, ly.t.wo, D, nullptr, e->X.p, D, e->X.p, D, L, D, D, OMNITOK_GEMM_RESIDUAL,
                                0, 0, 0, stream, ab_ao));
+                goto feed_forward;
+            }
+            if (!spatial && T == 5 && pl && g_qkv_pl && g_temporal_fused && bs && c.causal_temporal && ly.t.wqk_t &&
+                e->plw.count(ly.t.wqk_t) && ly.t.wqkv_fold && e->plw.count(ly.t.wqkv_fold) && S % 64 == 0 && heads * 64 == D &&
+                ly.t.vnorm > 0.0f) {
+                // fused temporal stage (gemm_pl.h PL_TSCORE / PL_TPV; reference attention.py:402-486 with is_spatial = False)
+                const int64_t nseq = (int64_t)B * S;
+                float *P = e->QKV.p, *out_scale = e->QKV.p + nseq * heads * 40;
+                OT_RUN("stats_pack", 2.0 * L * D * 4.0,
+                       omnitok_stats_pack_temporal(e->X.p, nseq, D, 1e-5f, e->X2.p, e->Z.p, e->ST.p, bs, S, stream));
+                const float *alibi = c.legacy_attention ? e->alibi : nullptr;
+                omnitok_pl_gemm g{};
+                g.a = e->X2.p;
+                g.a_scale = e->Z.p;
+                g.fold_stats = e->ST.p;
+                g.M = L;
+                g.K = D;
+                g.tp = P;
+                g.t_nseq = (int)nseq;
+                g.t_heads = heads;
+                g.t_alibi = alibi;
+                omnitok_pl_gemm q = g;
+                const H2W &wqk = e->plw[ly.t.wqk_t];
+                q.w = wqk.pl;
+                q.w_scale = wqk.sc;
+                q.fold_b = ly.t.qk_t_fb;
+                q.fold_u = ly.t.qk_t_fu;
+                q.N = 2 * D;
+                q.epilogue = 6;
+                q.q_scale = ly.t.q_scale;
+                q.k_scale = ly.t.k_scale;
+                q.q_mul = 8.0f;
+                OT_RUN("gemm_qkv", gemm_f * 2 * D, omnitok_gemm_pl(&q, stream));
+                const H2W &wf = e->plw[ly.t.wqkv_fold];
+                omnitok_pl_gemm v = g;
+                v.w = static_cast<const char *>(wf.pl) + (int64_t)(2 * D / 64) * (D / 32) * 8192;
+                v.w_scale = wf.sc + 2 * D;
+                v.fold_u = ly.t.fold_u + 2 * D;
+                v.N = D;
+                v.epilogue = 7;
+                v.out_planes = e->AO.p;
+                v.out_planes_k = D;
+                v.t_out_scale = out_scale;
+                v.v_bound = ab_ao.stat;
+                v.v_bound_dev = ab_ao.dev;
+                v.v_bound_stride = 2;
+                v.t_seqs_per_clip = S;
+                OT_RUN("gemm_qkv", gemm_f * D, omnitok_gemm_pl(&v, stream));
+                if (int rc = gemm_out_pl(ly, e->AO.p, out_scale, 1.0f, ly.t.wo, nullptr)) return rc;
                 goto feed_forward;
             }
             float *Q = e->QKV.p, *KV = e->QKV.p + L * D;

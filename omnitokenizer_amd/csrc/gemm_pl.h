@@ -35,6 +35,11 @@ enum PlEpi {
     PL_VPACK = 3,       // SWAP only: V columns into the attention kernel's packed fp16 planes (attn_h2.hip)
     PL_QKPACK = 4,      // Q | K columns (one head per wave): RoPE + l2norm + scales -> the attention kernel's packed planes
     PL_UNPATCH = 5,     // fp32 (+ bias) scattered as pixels: the un-patchify Rearrange of to_pixels fused into the store
+    // The temporal stage without its q|k|v round trip (T' == 5; reference attention.py:402-486, is_spatial = False): rows ordered
+    // [tile of 64 sequences][32-sequence half][time step][sequence], so that the five time steps of a sequence are the five row
+    // blocks of ONE lane pair of a wave (PlCfg<2, 2, R, D, 0, 4, 5>: wave tile 4 x 5 accumulator blocks, one wave per SIMD)
+    PL_TSCORE = 6,      // columns [q_h | k_h] per wave: LayerNorm fold, l2norm, scales, causal scores, softmax -> P (160 B per sequence-head)
+    PL_TPV = 7,         // columns [v_h | v_h+1] per wave: o_t = sum_s P[t][s] v_s in-lane -> the out-projection's operand planes (token order)
 };
 
 struct PlParams {
@@ -90,6 +95,12 @@ struct PlParams {
     // operand row map (a_rpg == 0: identity): the frame groups of the token tensor
     int64_t a_rpg, a_gstride, a_goff;
     int up_C, up_F, up_H, up_W, up_f0, up_t, up_pt, up_p;  // PL_UNPATCH
+    // PL_TSCORE / PL_TPV: P buffer [sequence][head][40 floats]: per query step t 8 floats = e[t][0..4], 1 / sum_s e[t][s], 0, 0
+    float *tp;
+    int t_nseq, t_heads, t_seqs_per_clip;
+    const float *t_alibi;             // [heads] ALiBi slopes (legacy attention) or null
+    float t_scale;                    // SDPA scale folded into q
+    float *t_out_scale;               // PL_TPV: [token row] factor that undoes the plane scale (a_scale of the out-projection)
     long long *cycles;                // measurement: s_memtime span of workgroup 0 (null = off)
     int stagger;                      // start delay step in ~1 us units ("pl_stagger"); workgroup phase = (id / 8) % 8
 };
@@ -125,7 +136,7 @@ struct PlCfg {
     static constexpr int LDS = R * STAGE;
     static constexpr bool EPI_T = NW == 8;  // fp32 epilogues go through a 4 KiB LDS block per wave (row-major global accesses)
     static_assert(NP % NW == 0, "pieces per wave");
-    static_assert(PPW <= 8 && (D_ - 1) * PPW < 48, "vmcnt bookkeeping");
+    static_assert(PPW <= NI_ * MI_ && (D_ - 1) * PPW < 48, "vmcnt bookkeeping: at most two pieces per MFMA-pair slot, vmcnt < 64");
     static_assert(D_ >= 2 && D_ <= 3 && D_ < R_, "prefetch distance");
 };
 
@@ -826,6 +837,205 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                 *reinterpret_cast<u32x4 *>(dst + 4096) =
                                     __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
                             }
+                        }
+                    }
+                } else if constexpr (EPI == PL_TSCORE) {
+                    // Wave = one head: blocks ni 0, 1 = q_h (64 channels), ni 2, 3 = k_h; block mi = time step mi of the wave's 32
+                    // sequences.  A lane holds 32 of the 64 channels of q_t and k_s of ITS sequence for every step, its partner
+                    // (hi ^ 1) the other 32: a score is a lane-local dot + one exchange.  Arithmetic of attn_temporal_reg (l2norm with
+                    // F.normalize's eps, learned scales, SDPA scale on q, causal mask, ALiBi, exp(s - max)); the un-normalised
+                    // weights e and 1 / sum e go out, 160 bytes per (sequence, head) instead of 2 x 1280 bytes of q and k.
+                    static_assert(EPI != PL_TSCORE || (NI == 4 && MI == 5), "q_h | k_h columns x 5 time steps per wave");
+                    if (n_w0 < p.N) {
+                        const int head = n_w0 >> 7;
+                        const int ln = hi * 32 + r32;
+                        const float swq = p.w_scale[n_w0 + ln], swk = p.w_scale[n_w0 + 64 + ln];
+                        const float fbq = p.fold_b ? p.fold_b[n_w0 + ln] : 0.0f;
+                        const float fuk = p.fold_u ? p.fold_u[n_w0 + 64 + ln] : 0.0f;
+                        const float sql = p.q_scale[ln], skl = p.k_scale[ln];
+                        float ssq[MI], ssk[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) ssq[mi] = ssk[mi] = 0.0f;
+                        // phase A: projected values (operand / weight scales, folded LayerNorm for q, mean add-back for k)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const bool isq = ni < 2;
+                                float sw[2][4], fx[2][4];
+#pragma unroll
+                                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const int src = ((ni & 1) * 32 + c * 16 + hi * 8 + h * 4 + e) * 4;
+                                        sw[h][e] = lane_bcast(isq ? swq : swk, src);
+                                        fx[h][e] = lane_bcast(isq ? fbq : fuk, src);
+                                    }
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi) {
+                                    const float ra = isq ? frs[mi] : 1.0f, rb = isq ? 1.0f : fmu[mi];
+#pragma unroll
+                                    for (int h = 0; h < 2; ++h) {
+                                        f32x4 v;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            v[e] = ra * (acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e])) + rb * fx[h][e];
+                                        const float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                                        if (isq) ssq[mi] += s2; else ssk[mi] += s2;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc[ni][mi][c * 8 + h * 4 + e] = v[e];
+                                    }
+                                }
+                            }
+                        float invq[MI], invk[MI];
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) {
+                            invq[mi] = 1.0f / fmaxf(sqrtf(ssq[mi] + swap32(ssq[mi])), 1e-12f);
+                            invk[mi] = 1.0f / fmaxf(sqrtf(ssk[mi] + swap32(ssk[mi])), 1e-12f);
+                        }
+                        // phase B: l2norm, learned scales, SDPA scale on q
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                const bool isq = ni < 2;
+                                float s8[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e)
+                                    s8[e] = lane_bcast(isq ? sql : skl, ((ni & 1) * 32 + c * 16 + hi * 8 + e) * 4);
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi) {
+                                    const float iv = isq ? invq[mi] : invk[mi], mul = isq ? p.t_scale : 1.0f;
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * iv * s8[e] * mul;
+                                }
+                            }
+                        // scores of query step i against key steps j <= i (causal), softmax weights
+                        const float slope = p.t_alibi ? p.t_alibi[head] : 0.0f;
+                        const int seq = (int)(bm * 64) + wm * 32 + r32;
+                        float *pp = p.tp + ((int64_t)(seq < p.t_nseq ? seq : 0) * p.t_heads + head) * 40;
+                        const bool wr = hi == 0 && seq < p.t_nseq;
+                        float inv_l[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            float sc[5], mx = -INFINITY;
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) {
+                                float d = 0.0f;
+#pragma unroll
+                                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) d = fmaf(acc[ni][i][r], acc[ni + 2][j][r], d);
+                                d += swap32(d);
+                                d -= slope * (float)(i - j);
+                                sc[j] = d;
+                                mx = fmaxf(mx, d);
+                            }
+                            float l = 0.0f, ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                            for (int j = 0; j <= i; ++j) {
+                                ev[j] = expf(sc[j] - mx);
+                                l += ev[j];
+                            }
+                            inv_l[i] = 1.0f / l;
+                            if (wr) {
+                                *reinterpret_cast<f32x4 *>(pp + i * 8) = f32x4{ev[0], ev[1], ev[2], ev[3]};
+                                *reinterpret_cast<f32x4 *>(pp + i * 8 + 4) = f32x4{ev[4], inv_l[i], 0.0f, 0.0f};
+                            }
+                        }
+                    }
+                } else if constexpr (EPI == PL_TPV) {
+                    // Wave = V of two heads: blocks ni 0, 1 = v_hA, ni 2, 3 = v_hA+1; block mi = time step.  o_i = (sum_{j<=i} e_ij v_j)
+                    // (1 / l_i), formed in place from the last step down (o_i needs v_j, j <= i, only), scaled and split into the
+                    // out-projection's operand planes at the TOKEN row seq * 5 + i.
+                    static_assert(EPI != PL_TPV || (NI == 4 && MI == 5), "v_h | v_h+1 columns x 5 time steps per wave");
+                    if (n_w0 < p.N) {
+                        const int hA = n_w0 >> 6;
+                        const int ln = hi * 32 + r32;
+                        const float sw0 = p.w_scale[n_w0 + ln], sw1 = p.w_scale[n_w0 + 64 + ln];
+                        const float fu0 = p.fold_u ? p.fold_u[n_w0 + ln] : 0.0f, fu1 = p.fold_u ? p.fold_u[n_w0 + 64 + ln] : 0.0f;
+                        const int seq = (int)(bm * 64) + wm * 32 + r32;
+                        const bool live = seq < p.t_nseq;
+                        const int seqc = live ? seq : 0;
+                        float vb = p.v_bound;
+                        if (p.v_bound_dev) vb *= p.v_bound_dev[(seqc / p.t_seqs_per_clip) * p.v_bound_stride];
+                        const float so = h2_scale_of_bound(vb);
+                        // phase A: v = xc . Wv^T (scales) + mean u
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                float sw[8], fx[8];
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) {
+                                    const int src = ((ni & 1) * 32 + c * 16 + hi * 8 + e) * 4;
+                                    sw[e] = lane_bcast(ni < 2 ? sw0 : sw1, src);
+                                    fx[e] = lane_bcast(ni < 2 ? fu0 : fu1, src);
+                                }
+#pragma unroll
+                                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * (sa[mi] * sw[e]) + fmu[mi] * fx[e];
+                            }
+                        // phase B: P . V per head, in place
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const float *pp = p.tp + ((int64_t)seqc * p.t_heads + hA + hh) * 40;
+#pragma unroll
+                            for (int i = 4; i >= 0; --i) {
+                                const f32x4 pa = *reinterpret_cast<const f32x4 *>(pp + i * 8);
+                                const f32x4 pb = *reinterpret_cast<const f32x4 *>(pp + i * 8 + 4);
+                                const float e0 = pa[0], e1 = pa[1], e2 = pa[2], e3 = pa[3], e4 = pb[0];
+                                const float fin = pb[1] * so;   // (1 / l_i) and the plane scale (a power of two: exact)
+#pragma unroll
+                                for (int ni = 2 * hh; ni < 2 * hh + 2; ++ni)
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        float o = acc[ni][0][r] * e0;
+                                        if (i >= 1) o = fmaf(acc[ni][1][r], e1, o);
+                                        if (i >= 2) o = fmaf(acc[ni][2][r], e2, o);
+                                        if (i >= 3) o = fmaf(acc[ni][3][r], e3, o);
+                                        if (i >= 4) o = fmaf(acc[ni][4][r], e4, o);
+                                        acc[ni][i][r] = o * fin;
+                                    }
+                            }
+                        }
+                        // planes of the out-projection's operand, token order: row seq * 5 + i
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            const int64_t m = (int64_t)seqc * 5 + i;
+                            unsigned char *rowp = p.cp + (m >> 6) * (int64_t)p.cp_kblocks * 8192 + (m & 63) * 16;
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni) {
+                                const int kb = (n_w0 >> 5) + ni;
+#pragma unroll
+                                for (int c = 0; c < 2; ++c) {
+                                    f32x4 va, vb2;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        va[e] = acc[ni][i][c * 8 + e];
+                                        vb2[e] = acc[ni][i][c * 8 + 4 + e];
+                                    }
+                                    const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb2, f16x4);
+                                    const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
+                                    const f16x4 lb = __builtin_convertvector(vb2 - __builtin_convertvector(hb, f32x4), f16x4);
+                                    unsigned char *dst = rowp + (int64_t)kb * 8192 + (c * 2 + hi) * 1024;
+                                    if (live) {
+                                        *reinterpret_cast<u32x4 *>(dst) =
+                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                        *reinterpret_cast<u32x4 *>(dst + 4096) =
+                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    }
+                                }
+                            }
+                            if (live && n_w0 == 0 && hi == 0) p.t_out_scale[m] = 1.0f / so;
                         }
                     }
                 } else if constexpr (EPI == PL_QKPACK) {

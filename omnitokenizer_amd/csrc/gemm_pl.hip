@@ -125,6 +125,9 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
         return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
     } else if constexpr (EPI == PL_UNPATCH) {
         return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+    } else if constexpr (EPI == PL_TSCORE || EPI == PL_TPV) {
+        // 320 x 256 tiles, 4 waves of (4 x 5 blocks): one wave per SIMD, 320 accumulator registers; ring of 4 x 36 KiB
+        return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 5>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
     } else {
@@ -218,9 +221,10 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
     p.cycles = g->debug_cycles;
     if (g->fold_stats) {
         OT_CHECK_ARG(g->fold_cols >= 0 && g->fold_cols % 64 == 0 && (g->fold_cols >= g->N || g->fold_u) &&
-                         (g->epilogue == PL_F32 || g->epilogue == PL_QKPACK || g->epilogue == PL_VPACK),
+                         (g->epilogue == PL_F32 || g->epilogue == PL_QKPACK || g->epilogue == PL_VPACK || g->epilogue == PL_TSCORE ||
+                          g->epilogue == PL_TPV),
                      "gemm_pl: a centred operand needs fold_cols %% 64 == 0, the row sums fold_u for the columns >= fold_cols, "
-                     "and epilogue 0, 3 or 4");
+                     "and epilogue 0, 3, 4, 6 or 7");
         p.fold_stats = g->fold_stats;
         p.fold_b = g->fold_b;
         p.fold_u = g->fold_u;
@@ -299,6 +303,36 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             p.ln_beta = g->ln_beta;
             p.ln_eps = g->ln_eps;
             return launch_pl<PL_ROWLN>(p, cfg, stream);
+        case PL_TSCORE:
+        case PL_TPV: {
+            // rows: [tile of 64 sequences][32-sequence half][5 time steps][32 sequences] (omnitok_stats_pack_temporal)
+            OT_CHECK_ARG(g->M % 320 == 0 && g->t_nseq > 0 && g->M == (int64_t)(g->t_nseq + 63) / 64 * 320 && g->t_heads > 0 &&
+                             g->tp && aligned16(g->tp) && g->fold_stats && g->a_scale && !g->a2 && g->a_rpg == 0,
+                         "gemm_pl: the temporal epilogues need M = ceil(nseq / 64) * 320 permuted rows, row statistics, per-row "
+                         "scales and the P buffer");
+            p.tp = g->tp;
+            p.t_nseq = g->t_nseq;
+            p.t_heads = g->t_heads;
+            p.t_alibi = g->t_alibi;
+            p.t_scale = g->q_mul > 0.0f ? g->q_mul : 1.0f;
+            if (g->epilogue == PL_TSCORE) {
+                OT_CHECK_ARG(g->N == g->t_heads * 128 && g->q_scale && g->k_scale && g->fold_u,
+                             "gemm_pl: temporal scores need N = heads * 128 ([q_h | k_h] columns), q / k scale vectors and fold_u");
+                p.q_scale = g->q_scale;
+                p.k_scale = g->k_scale;
+                return launch_pl<PL_TSCORE>(p, cfg, stream);
+            }
+            OT_CHECK_ARG(g->N == g->t_heads * 64 && g->t_heads % 2 == 0 && g->out_planes && aligned16(g->out_planes) &&
+                             g->out_planes_k == g->N && g->t_out_scale && g->v_bound > 0.0f &&
+                             (!g->v_bound_dev || g->t_seqs_per_clip > 0),
+                         "gemm_pl: temporal P.V needs N = heads * 64, out_planes (K = N), t_out_scale and a bound of |v|");
+            p.t_out_scale = g->t_out_scale;
+            p.v_bound = g->v_bound;
+            p.v_bound_dev = g->v_bound_dev;
+            p.v_bound_stride = g->v_bound_stride > 0 ? g->v_bound_stride : 1;
+            p.t_seqs_per_clip = g->t_seqs_per_clip > 0 ? g->t_seqs_per_clip : g->t_nseq;
+            return launch_pl<PL_TPV>(p, cfg, stream);
+        }
         default:
             set_error("gemm_pl: unsupported epilogue %d", g->epilogue);
             return OMNITOK_ERR_INVALID;

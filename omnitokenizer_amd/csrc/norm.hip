@@ -369,10 +369,11 @@ struct SpArgs {
     unsigned char *planes;
     float *a_scale, *stats;
     int win_gh, win_gw, win_ws;
+    int t_nseq;  // SP_TEMPORAL: sequences of 5 tokens; output row -> (tile of 64 sequences, half, time step, sequence)
     const float *ln_g, *ln_b;
     float ln_bound;
 };
-enum { SP_PLAIN = 0, SP_WINDOWS = 1, SP_LAYERNORM = 2 };
+enum { SP_PLAIN = 0, SP_WINDOWS = 1, SP_LAYERNORM = 2, SP_TEMPORAL = 3 };
 
 template <int H, int MODE>
 __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
@@ -394,6 +395,16 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
     for (int r = 0; r < 16; ++r) {
         const int64_t row = row0 + r;
         int64_t src = row < rows ? row : rows - 1;
+        bool pad = row >= rows;
+        if constexpr (MODE == SP_TEMPORAL) {
+            // output row = [tile][half][t][32 sequences] (the five time steps of a sequence land in the five row blocks of one
+            // lane pair of the temporal GEMM's wave tile, gemm_pl.h PL_TSCORE / PL_TPV); input row = sequence * 5 + t
+            const int64_t tile = src / 320;
+            const int rem = (int)(src - tile * 320), half = rem / 160, t = (rem % 160) >> 5, j = rem & 31;
+            const int64_t seq = tile * 64 + half * 32 + j;
+            pad = pad || seq >= a.t_nseq;
+            src = (seq < a.t_nseq ? seq : 0) * 5 + t;
+        }
         if constexpr (MODE == SP_WINDOWS) {
             const int S = win_gh * win_gw, w2 = win_ws * win_ws, nwx = win_gw / win_ws;
             const int64_t f = src / S;
@@ -405,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
 #pragma unroll
         for (int h = 0; h < H; ++h) {
             v[r][h] = __builtin_nontemporal_load(xr + lane + 64 * h);
-            if (row >= rows) v[r][h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // pad rows of the plane block are zero
+            if (pad) v[r][h] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};  // pad rows of the plane block are zero
         }
     }
     f32x4 lg[H], lb[H];
@@ -634,6 +645,32 @@ static int stats_pack_impl(const float *x, int64_t rows, int dim, float eps, int
         OT_CHECK_ARG(n_clips <= 65535, "stats_pack: %lld clips (max 65535)", (long long)n_clips);
         hipLaunchKernelGGL(range_from_stats_kernel, dim3(RANGE_SPLIT, (unsigned)n_clips), dim3(256), 0, stream, stats, rows, rpc,
                            dim, bounds);
+        OT_LAUNCH_CHECK("range_from_stats");
+    }
+    return OMNITOK_OK;
+}
+
+// The same pass for the fused temporal stage (gemm_pl.h PL_TSCORE / PL_TPV): x [nseq * 5, dim] in token order (sequence, time
+// step); planes, a_scale and stats in the permuted row order [tile of 64 sequences][half][time step][32 sequences],
+// ceil(nseq / 64) * 320 rows (sequences beyond nseq are zero rows).  bounds per clip of seqs_per_clip sequences (% 64 == 0).
+extern "C" int omnitok_stats_pack_temporal(const float *x, int64_t nseq, int dim, float eps, void *planes, float *a_scale,
+                                           float *stats, float *bounds, int64_t seqs_per_clip, omnitok_stream_t stream_) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    OT_CHECK_ARG(x && planes && a_scale && stats && nseq >= 0 && nseq < (1ll << 31) / 5, "stats_pack_temporal: bad arguments");
+    OT_CHECK_ARG(aligned16(x) && aligned16(planes) && (reinterpret_cast<uintptr_t>(stats) & 7) == 0, "stats_pack_temporal: alignment");
+    OT_CHECK_ARG(!bounds || (seqs_per_clip > 0 && seqs_per_clip % 64 == 0 && nseq % seqs_per_clip == 0),
+                 "stats_pack_temporal: per-clip ranges need whole clips of a multiple of 64 sequences");
+    if (nseq == 0) return OMNITOK_OK;
+    const int64_t rows = (nseq + 63) / 64 * 320;
+    SpArgs a{};
+    a.x = x; a.rows = rows; a.eps = eps; a.center = 1; a.planes = static_cast<unsigned char *>(planes);
+    a.a_scale = a_scale; a.stats = stats; a.t_nseq = (int)nseq;
+    if (int rc = stats_pack_launch<SP_TEMPORAL>(a, dim, rows, stream)) return rc;
+    if (bounds) {
+        const int64_t rpc = seqs_per_clip * 5, n_clips = nseq / seqs_per_clip;
+        OT_CHECK_ARG(n_clips <= 65535, "stats_pack_temporal: %lld clips (max 65535)", (long long)n_clips);
+        hipLaunchKernelGGL(range_from_stats_kernel, dim3(RANGE_SPLIT, (unsigned)n_clips), dim3(256), 0, stream, stats, rows, rpc, dim,
+                           bounds);
         OT_LAUNCH_CHECK("range_from_stats");
     }
     return OMNITOK_OK;

@@ -271,6 +271,55 @@ def stats_pack(x, eps=1e-5, center=False):
     return planes, scales, stats
 
 
+def stats_pack_temporal(x, nseq, eps=1e-5):
+    """stats_pack (centred) of x [nseq * 5, K] with the OUTPUT rows in the fused temporal stage's order: row of (sequence s,
+    step t) = ((s // 64) * 2 + (s % 64) // 32) * 160 + t * 32 + s % 32; ceil(nseq / 64) * 320 rows (planes, scales, stats)."""
+    x = _req(x, "x")
+    M, K = x.shape
+    assert M == nseq * 5
+    rows = (nseq + 63) // 64 * 320
+    planes = torch.empty(rows * K, device=x.device, dtype=torch.int32)
+    scales = torch.empty(rows, device=x.device, dtype=torch.float32)
+    stats = torch.empty(rows, 2, device=x.device, dtype=torch.float32)
+    check(_lib.load().omnitok_stats_pack_temporal(_p(x), nseq, K, eps, _p(planes), _p(scales), _p(stats), None, 0, _stream()),
+          "stats_pack_temporal")
+    return planes, scales, stats
+
+
+def temporal_fused(planes, scales, stats, nseq, heads, wqk_packed, wv_packed, fold_qk, fold_u_v, q_scale, k_scale, scale, v_bound,
+                   alibi=None):
+    """The fused temporal stage on stats_pack_temporal's operand (omnitok_pl_gemm epilogues 6 and 7): wqk_packed = packed
+    [q_h | k_h] x heads rows (q rows LayerNorm-folded), fold_qk = (fold_b, fold_u) in that order, wv_packed the V rows,
+    fold_u_v their row sums.  Returns (P [nseq, heads, 40], attention output planes in token order [nseq * 5, heads * 64],
+    out_scale [nseq * 5])."""
+    dev = planes.device
+    D = heads * 64
+    M = (nseq + 63) // 64 * 320
+    P = torch.zeros(nseq, heads, 40, device=dev, dtype=torch.float32)
+    out_planes = torch.zeros(_pad256(nseq * 5) * D, device=dev, dtype=torch.int32)
+    out_scale = torch.zeros(nseq * 5, device=dev, dtype=torch.float32)
+    for epi in (6, 7):
+        g = _lib.OmnitokPlGemm()
+        g.a, g.a_scale, g.fold_stats = planes.data_ptr(), scales.data_ptr(), stats.data_ptr()
+        g.M, g.K = M, D
+        g.tp, g.t_nseq, g.t_heads = P.data_ptr(), nseq, heads
+        g.t_alibi = alibi.data_ptr() if alibi is not None else None
+        g.epilogue = epi
+        if epi == 6:
+            g.w, g.w_scale = wqk_packed[0].data_ptr(), wqk_packed[1].data_ptr()
+            g.fold_b, g.fold_u = fold_qk[0].data_ptr(), fold_qk[1].data_ptr()
+            g.N = 2 * D
+            g.q_scale, g.k_scale, g.q_mul = q_scale.data_ptr(), k_scale.data_ptr(), float(scale)
+        else:
+            g.w, g.w_scale = wv_packed[0].data_ptr(), wv_packed[1].data_ptr()
+            g.fold_u = fold_u_v.data_ptr()
+            g.N = D
+            g.out_planes, g.out_planes_k = out_planes.data_ptr(), D
+            g.t_out_scale, g.v_bound, g.t_seqs_per_clip = out_scale.data_ptr(), float(v_bound), nseq
+        check(_lib.load().omnitok_gemm_pl(ctypes.byref(g), _stream()), "gemm_pl")
+    return P, out_planes, out_scale
+
+
 def stats_pack_windows(x, gh, gw, ws=8, eps=1e-5, center=True):
     """stats_pack with the OUTPUT rows (planes, scales, stats) in window-major order (frame, window, position): the operand of the
     window-attention q|k|v plane GEMM (reference attention.py:170-188 window_partition).  x [frames * gh * gw, K] in token order."""
