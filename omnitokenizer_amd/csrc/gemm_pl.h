@@ -269,7 +269,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 mfma1(wf[ni], af[mi], acc[ni][mi]);
-                if (mi & 1) {
+                if ((ni * MI + mi) & 1) {  // after every second MFMA in issue order (== mi & 1 for even MI; MI = 5 needs the count)
                     __builtin_amdgcn_sched_barrier(0);
                     hook((ni * MI + mi) >> 1);
                     __builtin_amdgcn_sched_barrier(0);

@@ -114,9 +114,37 @@ def test_fused_temporal_stage_vs_fp64_and_unfused(ops, nseq, heavy, alibi):
     wall = torch.cat([ri["wq_folded"], ri["wk"], ri["wv"]]).float().cuda()
     fb_all = torch.cat([ri["fb"], torch.zeros(2 * D, dtype=torch.float64)]).float().cuda()
     fu_all = torch.cat([torch.zeros(D, dtype=torch.float64), ri["fu_k"], ri["fu_v"]]).float().cuda()
-    (qkv,) = o2.linear_pl(xpl, o2.pl_pack_weight(wall), nseq * 5, 3 * D, D, a_scale=xsc, fold=(xst, fb_all, fu_all, D))
+    qkv = o2.linear_pl(xpl, o2.pl_pack_weight(wall), nseq * 5, 3 * D, D, a_scale=xsc, fold=(xst, fb_all, fu_all, D))
     out = o2.attn_temporal(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], nseq, 5, heads, oi["qs"], oi["ks"], True,
                            alibi=slopes.float().cuda() if alibi else None)
     derr = float((got - out.double()).abs().max())
     print(f"   vs the unfused kernels: {derr:.2e}")
     assert derr < 4e-6 * max(1.0, vmax)
+
+
+@pytest.mark.parametrize("name", ["s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17_b8"])
+def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
+    """Whole encode / decode with "temporal_fused" 1 (opt-in: correct, but slower than the two-kernel form on this part, see
+    profiles/r05_temporal_fused.txt) against the reference's golden outputs: same bars as the default flow."""
+    from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib
+    from tests.helpers import GoldenCase
+    from tests.test_gpu_e2e import PIXEL_TOL, Z_TOL, assert_ids_match_or_near_tie
+    c = GoldenCase(name)
+    m = OmniTokenizer_VQGAN(c.args, attention_mode=c.mode)
+    m.load_state_dict(c.sd, strict=True)
+    m = m.cuda().eval()
+    try:
+        _lib.set_option("temporal_fused", 0)
+        ids0, z0 = m.encode(c.x.cuda(), False, return_latents=True)
+        _lib.set_option("temporal_fused", 1)
+        ids1, z1 = m.encode(c.x.cuda(), False, return_latents=True)
+        rec1 = m.decode(c.ids.cuda(), False)
+    finally:
+        _lib.set_option("temporal_fused", 0)
+    assert not torch.equal(z0, z1)   # the option is live (the two forms round differently)
+    noise = max(c.fp32_noise_z, 0.0)
+    ztol = max(Z_TOL, 8.0 * noise)
+    assert float((z1.cpu() - c.z).abs().max()) < ztol and float((z1 - z0).abs().max()) < 2 * ztol
+    assert_ids_match_or_near_tie(ids1, c.ids, z1, c.sd["codebook.embeddings"], name + " (fused temporal stage)")
+    perr = float((c.strided(rec1.cpu()) - c.recon).abs().max())
+    assert perr < max(PIXEL_TOL, 8.0 * c.fp32_noise_pix)
