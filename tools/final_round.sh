@@ -2,7 +2,7 @@
 # Round-end evidence in one GPU call: full GPU suite, the default bench line, the LM bench line, rocprofv3 kernel stats
 # of the bench command and of the LM decode loop.  bash tools/final_round.sh <tag>   (outputs under gpurun_out/<tag>_*)
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT="${GRAFT_REPO_ROOT:-/root/repo}"
 cd /tmp; export TMPDIR=/tmp; cd "$ROOT"
 OUT=gpurun_out; mkdir -p $OUT

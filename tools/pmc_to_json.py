@@ -30,8 +30,9 @@ FAMILIES = {
     "attn_spatial": ["attn_spatial_h2w_kernel", "attn_spatial_h2p_kernel", "attn_spatial_h2x_kernel"],   # r04 default: h2w
     "attn_temporal": ["attn_temporal_reg"],
     "attn_window": ["attn_window_h2_kernel", "attn_window_kernel"],
-    "vq_argmin": ["vq_argmin_kernel"],
-    "peg3d": ["peg3d_wide_kernel", "peg3d_lds_kernel"],   # r04: the 64-channel kernel at C3 (5 planes)
+    "vq_argmin": ["vq_screen_kernel", "vq_argmin_kernel"],   # r05 default: the screened search
+    "peg3d": ["peg3d_wide_kernel", "peg2d_wide_kernel", "peg3d_lds_kernel"],   # r04: the 64-channel kernel at C3 (5 planes)
+    "pre_vq": ["layernorm_prevq_kernel", "pre_vq_kernel"],
     "stats_pack": ["stats_pack_kernel"],
 }
 
