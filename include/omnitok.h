@@ -57,9 +57,9 @@ const char *omnitok_version(void);
  *   "temporal_chunk" 0 (default; also per engine) > 0: temporal blocks run GEMM(chunk of clips) -> attention(chunk) through
  *                one chunk-sized q|k|v buffer (bit-identical; measured slower at C3, profiles/r05_temporal_chunk.txt)
  *   "prevq_fuse" 1 (default) omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (bit-identical) | 0 two passes
- *   "temporal_fused" 0 (default) | 1 temporal blocks with T' = 5 run as two GEMM launches with the attention in their epilogues
- *                (omnitok_pl_gemm epilogues 6 / 7: no fp32 q|k|v in memory; parity-tested, slower on this part:
- *                profiles/r05_temporal_fused.txt)
+ *   "temporal_fused" 1 (default) temporal blocks with T' = 5 (causal, S % 64 == 0) run as two GEMM launches with the attention
+ *                in their epilogues (omnitok_pl_gemm epilogues 6 / 7: no fp32 q|k|v in memory) | 0 q|k|v GEMM + the
+ *                omnitok_attn_temporal kernel; the two forms agree to rounding (profiles/r05_temporal_fused.txt)
  *   "attn_window_mode" 1 (default, process-wide, with gemm_pl / qkv_pl) window attention on the fp16 matrix cores from packed
  *                operands (omnitok_stats_pack_windows -> packing epilogues -> omnitok_attn_window_h2) | 0 fp32 q|k|v and the
  *                fp32-MFMA kernel omnitok_attn_window_planes

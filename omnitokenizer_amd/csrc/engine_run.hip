@@ -34,14 +34,14 @@ int g_temporal_chunk = 0;
 // "prevq_fuse" 1 (default): omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (omnitok_layernorm_prevq,
 // bit-identical) whenever nothing sits between the two (no deferred pools); 0: LayerNorm store, then omnitok_pre_vq.
 int g_prevq_fuse = 1;
-// "temporal_fused" 1: temporal 't' blocks with T' == 5 (17-frame clips at temporal_patch_size 4), causal, on the plane data flow
-// run WITHOUT the fp32 q|k|v round trip (2 GB per block at C3): omnitok_stats_pack_temporal permutes the rows so that a
-// sequence's five steps sit in one lane pair, a q|k GEMM forms the softmax weights in its epilogue (PL_TSCORE) and a V GEMM
-// applies them in its own (PL_TPV), writing the out-projection's operand planes.  Parity-tested (tests/test_gpu_temporal_fused.py)
-// but 2.6x SLOWER per block than the q|k|v GEMM + attn_temporal pair on this compiler / part (profiles/r05_temporal_fused.txt:
-// 320 accumulator registers exceed the 256-register accumulator file, and nine LDS-DMA pieces per wave and K step exceed what the
-// compiler's waitcnt pass tracks), hence opt-in.  0 (default): q|k|v GEMM + attn_temporal kernel.
-int g_temporal_fused = 0;
+// "temporal_fused" 1 (default): temporal 't' blocks with T' == 5 (17-frame clips at temporal_patch_size 4), causal, on the plane
+// data flow run WITHOUT the fp32 q|k|v round trip (2 GB per block at C3): omnitok_stats_pack_temporal permutes the rows so that
+// a sequence's five steps sit in one lane pair, a q|k GEMM forms the softmax weights in its epilogue (PL_TSCORE: the k wave hands
+// k_s to the q wave through LDS) and a V GEMM applies them in its own (PL_TPV), writing the out-projection's operand planes.
+// C3: 0.616 + 0.339 ms per block against 0.658 + 0.263 for the q|k|v GEMM + attn_temporal pair, but 2 GB less HBM traffic per
+// block on a power-capped step: -0.86 ms per step (profiles/r05_temporal_fused.txt).  0: q|k|v GEMM + attn_temporal kernel
+// (what every other T', non-causal configurations and grids with S % 64 != 0 take anyway).
+int g_temporal_fused = 1;
 // "qkv_pl" 1 (default, with gemm_pl): the q|k|v projection as a plane GEMM too -- one pass writes the row statistics and
 // the centred rows x - mean as planes (omnitok_stats_pack), the LayerNorm of the Q columns is folded into the weight and finished in the
 // epilogue, which for spatial attention also does RoPE + l2norm + scales and writes Q and K straight into the attention

@@ -37,9 +37,10 @@ enum PlEpi {
     PL_UNPATCH = 5,     // fp32 (+ bias) scattered as pixels: the un-patchify Rearrange of to_pixels fused into the store
     // The temporal stage without its q|k|v round trip (T' == 5; reference attention.py:402-486, is_spatial = False): rows ordered
     // [tile of 64 sequences][32-sequence half][time step][sequence], so that the five time steps of a sequence are the five row
-    // blocks of ONE lane pair of a wave (PlCfg<2, 2, R, D, 0, 4, 5>: wave tile 4 x 5 accumulator blocks, one wave per SIMD)
-    PL_TSCORE = 6,      // columns [q_h | k_h] per wave: LayerNorm fold, l2norm, scales, causal scores, softmax -> P (160 B per sequence-head)
-    PL_TPV = 7,         // columns [v_h | v_h+1] per wave: o_t = sum_s P[t][s] v_s in-lane -> the out-projection's operand planes (token order)
+    // blocks of ONE lane pair of a wave (PlCfg<2, 2, R, D, 0, 2, 5>: 320 x 128 tiles, wave tile 2 x 5 accumulator blocks = 160
+    // registers, one wave per SIMD, 7 DMA pieces per wave and K step)
+    PL_TSCORE = 6,      // tile = one head [q_h | k_h]: LayerNorm fold, l2norm, scales; k to the q wave through LDS; causal scores, softmax -> P
+    PL_TPV = 7,         // tile = V of two heads: o_t = sum_s P[t][s] v_s in-lane -> the out-projection's operand planes (token order)
 };
 
 struct PlParams {
@@ -840,38 +841,40 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         }
                     }
                 } else if constexpr (EPI == PL_TSCORE) {
-                    // Wave = one head: blocks ni 0, 1 = q_h (64 channels), ni 2, 3 = k_h; block mi = time step mi of the wave's 32
-                    // sequences.  A lane holds 32 of the 64 channels of q_t and k_s of ITS sequence for every step, its partner
-                    // (hi ^ 1) the other 32: a score is a lane-local dot + one exchange.  Arithmetic of attn_temporal_reg (l2norm with
-                    // F.normalize's eps, learned scales, SDPA scale on q, causal mask, ALiBi, exp(s - max)); the un-normalised
-                    // weights e and 1 / sum e go out, 160 bytes per (sequence, head) instead of 2 x 1280 bytes of q and k.
-                    static_assert(EPI != PL_TSCORE || (NI == 4 && MI == 5), "q_h | k_h columns x 5 time steps per wave");
-                    if (n_w0 < p.N) {
+                    // Tile = ONE head: 128 columns [q_h | k_h]; wave (wn, wm): wn = 0 holds q_h, wn = 1 holds k_h (64 channels = blocks
+                    // ni 0, 1) of the 32 sequences of half wm, block mi = time step mi.  A lane holds 32 of the 64 channels of ITS
+                    // sequence for every step, its partner (hi ^ 1) the other 32.  The k wave hands k_s to the q wave of the same half
+                    // through LDS, one time step per round (8 KiB per wave, double-buffered in the two ring stages the DMA cursor
+                    // does not own during the epilogue, 16-byte chunks XOR-swizzled by the sequence: conflict-free both ways); a score
+                    // is then a lane-local dot over 32 channels + one exchange with the partner.  Arithmetic of attn_temporal_reg
+                    // (l2norm with F.normalize's eps, learned scales, SDPA scale on q, causal mask, ALiBi, exp(s - max)); the
+                    // un-normalised weights e and 1 / sum e go out: 160 bytes per (sequence, head) instead of 2 x 1280 bytes of q and k.
+                    static_assert(EPI != PL_TSCORE || (NI == 2 && MI == 5 && C::WN == 2 && R - D >= 2 && C::STAGE >= 16384),
+                                  "q_h | k_h waves x 5 time steps; exchange buffers in the free ring stages");
+                    {
+                        const bool isq = wn == 0;  // wave-uniform
                         const int head = n_w0 >> 7;
                         const int ln = hi * 32 + r32;
-                        const float swq = p.w_scale[n_w0 + ln], swk = p.w_scale[n_w0 + 64 + ln];
-                        const float fbq = p.fold_b ? p.fold_b[n_w0 + ln] : 0.0f;
-                        const float fuk = p.fold_u ? p.fold_u[n_w0 + 64 + ln] : 0.0f;
-                        const float sql = p.q_scale[ln], skl = p.k_scale[ln];
-                        float ssq[MI], ssk[MI];
+                        const int ncl = n_w0 < p.N ? n_w0 + ln : 0;
+                        const float swl = p.w_scale[ncl];
+                        const float fxl = isq ? (p.fold_b ? p.fold_b[ncl] : 0.0f) : (p.fold_u ? p.fold_u[ncl] : 0.0f);
+                        const float svl = (isq ? p.q_scale : p.k_scale)[ln];
+                        float ss[MI];
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) ssq[mi] = ssk[mi] = 0.0f;
+                        for (int mi = 0; mi < MI; ++mi) ss[mi] = 0.0f;
                         // phase A: projected values (operand / weight scales, folded LayerNorm for q, mean add-back for k)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                const bool isq = ni < 2;
-                                float sw[2][4], fx[2][4];
+                                float sw[8], fx[8];
 #pragma unroll
-                                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const int src = ((ni & 1) * 32 + c * 16 + hi * 8 + h * 4 + e) * 4;
-                                        sw[h][e] = lane_bcast(isq ? swq : swk, src);
-                                        fx[h][e] = lane_bcast(isq ? fbq : fuk, src);
-                                    }
+                                for (int e = 0; e < 8; ++e) {
+                                    const int src = (ni * 32 + c * 16 + hi * 8 + e) * 4;
+                                    sw[e] = lane_bcast(swl, src);
+                                    fx[e] = lane_bcast(fxl, src);
+                                }
 #pragma unroll
                                 for (int mi = 0; mi < MI; ++mi) {
                                     const float ra = isq ? frs[mi] : 1.0f, rb = isq ? 1.0f : fmu[mi];
@@ -880,101 +883,135 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                         f32x4 v;
 #pragma unroll
                                         for (int e = 0; e < 4; ++e)
-                                            v[e] = ra * (acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h][e])) + rb * fx[h][e];
-                                        const float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-                                        if (isq) ssq[mi] += s2; else ssk[mi] += s2;
+                                            v[e] = ra * (acc[ni][mi][c * 8 + h * 4 + e] * (sa[mi] * sw[h * 4 + e])) + rb * fx[h * 4 + e];
+                                        ss[mi] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
                                         for (int e = 0; e < 4; ++e) acc[ni][mi][c * 8 + h * 4 + e] = v[e];
                                     }
                                 }
                             }
-                        float invq[MI], invk[MI];
-#pragma unroll
-                        for (int mi = 0; mi < MI; ++mi) {
-                            invq[mi] = 1.0f / fmaxf(sqrtf(ssq[mi] + swap32(ssq[mi])), 1e-12f);
-                            invk[mi] = 1.0f / fmaxf(sqrtf(ssk[mi] + swap32(ssk[mi])), 1e-12f);
-                        }
                         // phase B: l2norm, learned scales, SDPA scale on q
+                        float inv[MI];
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
+                        for (int mi = 0; mi < MI; ++mi) inv[mi] = 1.0f / fmaxf(sqrtf(ss[mi] + swap32(ss[mi])), 1e-12f);
+                        const float mul = isq ? p.t_scale : 1.0f;
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
-                                const bool isq = ni < 2;
                                 float s8[8];
 #pragma unroll
-                                for (int e = 0; e < 8; ++e)
-                                    s8[e] = lane_bcast(isq ? sql : skl, ((ni & 1) * 32 + c * 16 + hi * 8 + e) * 4);
+                                for (int e = 0; e < 8; ++e) s8[e] = lane_bcast(svl, (ni * 32 + c * 16 + hi * 8 + e) * 4);
 #pragma unroll
-                                for (int mi = 0; mi < MI; ++mi) {
-                                    const float iv = isq ? invq[mi] : invk[mi], mul = isq ? p.t_scale : 1.0f;
+                                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                                    for (int e = 0; e < 8; ++e) acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * iv * s8[e] * mul;
-                                }
+                                    for (int e = 0; e < 8; ++e) acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * inv[mi] * s8[e] * mul;
                             }
-                        // scores of query step i against key steps j <= i (causal), softmax weights
-                        const float slope = p.t_alibi ? p.t_alibi[head] : 0.0f;
-                        const int seq = (int)(bm * 64) + wm * 32 + r32;
-                        float *pp = p.tp + ((int64_t)(seq < p.t_nseq ? seq : 0) * p.t_heads + head) * 40;
-                        const bool wr = hi == 0 && seq < p.t_nseq;
-                        float inv_l[5];
+                        // exchange + scores: round s hands k_s over; the q wave forms d[t][s] for t >= s
+                        unsigned char *xb[2] = {pl_smem + d_stage * C::STAGE, pl_smem + (d_stage + 1 == R ? 0 : d_stage + 1) * C::STAGE};
+                        const int rowb = (wm * 32 + r32) * 256, sw15 = r32 & 15;
+                        float sc[15];  // d[t][s] at t (t + 1) / 2 + s
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            float sc[5], mx = -INFINITY;
-#pragma unroll
-                            for (int j = 0; j <= i; ++j) {
-                                float d = 0.0f;
+                        for (int s = 0; s < 5; ++s) {
+                            unsigned char *buf = xb[s & 1];
+                            if (!isq) {
 #pragma unroll
                                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                                    for (int r = 0; r < 16; ++r) d = fmaf(acc[ni][i][r], acc[ni + 2][j][r], d);
-                                d += swap32(d);
-                                d -= slope * (float)(i - j);
-                                sc[j] = d;
-                                mx = fmaxf(mx, d);
-                            }
-                            float l = 0.0f, ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                                    for (int c = 0; c < 2; ++c)
 #pragma unroll
-                            for (int j = 0; j <= i; ++j) {
-                                ev[j] = expf(sc[j] - mx);
-                                l += ev[j];
+                                        for (int h = 0; h < 2; ++h) {
+                                            const int chunk = ni * 8 + c * 4 + hi * 2 + h;
+                                            *reinterpret_cast<f32x4 *>(buf + rowb + ((chunk ^ sw15) << 4)) =
+                                                f32x4{acc[ni][s][c * 8 + h * 4], acc[ni][s][c * 8 + h * 4 + 1], acc[ni][s][c * 8 + h * 4 + 2],
+                                                      acc[ni][s][c * 8 + h * 4 + 3]};
+                                        }
                             }
-                            inv_l[i] = 1.0f / l;
-                            if (wr) {
-                                *reinterpret_cast<f32x4 *>(pp + i * 8) = f32x4{ev[0], ev[1], ev[2], ev[3]};
-                                *reinterpret_cast<f32x4 *>(pp + i * 8 + 4) = f32x4{ev[4], inv_l[i], 0.0f, 0.0f};
+                            lds_barrier();
+                            if (isq) {
+                                f32x4 kk[8];
+#pragma unroll
+                                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                        for (int h = 0; h < 2; ++h) {
+                                            const int chunk = ni * 8 + c * 4 + hi * 2 + h;
+                                            kk[ni * 4 + c * 2 + h] = *reinterpret_cast<const f32x4 *>(buf + rowb + ((chunk ^ sw15) << 4));
+                                        }
+#pragma unroll
+                                for (int t = s; t < 5; ++t) {
+                                    float d = 0.0f;
+#pragma unroll
+                                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                                for (int e = 0; e < 4; ++e)
+                                                    d = fmaf(acc[ni][t][c * 8 + h * 4 + e], kk[ni * 4 + c * 2 + h][e], d);
+                                    sc[t * (t + 1) / 2 + s] = d + swap32(d);
+                                }
+                            }
+                        }
+                        lds_barrier();  // every q wave is done with the buffers before the ring takes the stages back
+                        if (isq && n_w0 < p.N) {
+                            const float slope = p.t_alibi ? p.t_alibi[head] : 0.0f;
+                            const int seq = (int)(bm * 64) + wm * 32 + r32;
+                            float *pp = p.tp + ((int64_t)(seq < p.t_nseq ? seq : 0) * p.t_heads + head) * 40;
+                            const bool wr = hi == 0 && seq < p.t_nseq;
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) {
+                                float mx = -INFINITY, dd[5];
+#pragma unroll
+                                for (int j = 0; j <= i; ++j) {
+                                    dd[j] = sc[i * (i + 1) / 2 + j] - slope * (float)(i - j);
+                                    mx = fmaxf(mx, dd[j]);
+                                }
+                                float l = 0.0f, ev[5] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                                for (int j = 0; j <= i; ++j) {
+                                    ev[j] = expf(dd[j] - mx);
+                                    l += ev[j];
+                                }
+                                if (wr) {
+                                    *reinterpret_cast<f32x4 *>(pp + i * 8) = f32x4{ev[0], ev[1], ev[2], ev[3]};
+                                    *reinterpret_cast<f32x4 *>(pp + i * 8 + 4) = f32x4{ev[4], 1.0f / l, 0.0f, 0.0f};
+                                }
                             }
                         }
                     }
                 } else if constexpr (EPI == PL_TPV) {
-                    // Wave = V of two heads: blocks ni 0, 1 = v_hA, ni 2, 3 = v_hA+1; block mi = time step.  o_i = (sum_{j<=i} e_ij v_j)
-                    // (1 / l_i), formed in place from the last step down (o_i needs v_j, j <= i, only), scaled and split into the
-                    // out-projection's operand planes at the TOKEN row seq * 5 + i.
-                    static_assert(EPI != PL_TPV || (NI == 4 && MI == 5), "v_h | v_h+1 columns x 5 time steps per wave");
+                    // Tile = V of two heads, wave (wn, wm) = v of head 2 bn + wn for the 32 sequences of half wm; block mi = time step.
+                    // o_i = (sum_{j<=i} e_ij v_j) (1 / l_i), formed in place from the last step down (o_i needs v_j, j <= i, only),
+                    // scaled and split into the out-projection's operand planes at the TOKEN row seq * 5 + i.
+                    static_assert(EPI != PL_TPV || (NI == 2 && MI == 5), "v_h columns x 5 time steps per wave");
                     if (n_w0 < p.N) {
-                        const int hA = n_w0 >> 6;
+                        const int head = n_w0 >> 6;
                         const int ln = hi * 32 + r32;
-                        const float sw0 = p.w_scale[n_w0 + ln], sw1 = p.w_scale[n_w0 + 64 + ln];
-                        const float fu0 = p.fold_u ? p.fold_u[n_w0 + ln] : 0.0f, fu1 = p.fold_u ? p.fold_u[n_w0 + 64 + ln] : 0.0f;
+                        const float swl = p.w_scale[n_w0 + ln];
+                        const float ful = p.fold_u ? p.fold_u[n_w0 + ln] : 0.0f;
                         const int seq = (int)(bm * 64) + wm * 32 + r32;
                         const bool live = seq < p.t_nseq;
                         const int seqc = live ? seq : 0;
                         float vb = p.v_bound;
                         if (p.v_bound_dev) vb *= p.v_bound_dev[(seqc / p.t_seqs_per_clip) * p.v_bound_stride];
                         const float so = h2_scale_of_bound(vb);
+                        const float *pp = p.tp + ((int64_t)seqc * p.t_heads + head) * 40;
                         // phase A: v = xc . Wv^T (scales) + mean u
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                             for (int c = 0; c < 2; ++c) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 float sw[8], fx[8];
 #pragma unroll
                                 for (int e = 0; e < 8; ++e) {
-                                    const int src = ((ni & 1) * 32 + c * 16 + hi * 8 + e) * 4;
-                                    sw[e] = lane_bcast(ni < 2 ? sw0 : sw1, src);
-                                    fx[e] = lane_bcast(ni < 2 ? fu0 : fu1, src);
+                                    const int src = (ni * 32 + c * 16 + hi * 8 + e) * 4;
+                                    sw[e] = lane_bcast(swl, src);
+                                    fx[e] = lane_bcast(ful, src);
                                 }
 #pragma unroll
                                 for (int mi = 0; mi < MI; ++mi)
@@ -982,41 +1019,41 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                     for (int e = 0; e < 8; ++e)
                                         acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * (sa[mi] * sw[e]) + fmu[mi] * fx[e];
                             }
-                        // phase B: P . V per head, in place
+                        // phase B: P . V in place, last step first
 #pragma unroll
-                        for (int hh = 0; hh < 2; ++hh) {
+                        for (int i = 4; i >= 0; --i) {
                             __builtin_amdgcn_sched_barrier(0);
-                            const float *pp = p.tp + ((int64_t)seqc * p.t_heads + hA + hh) * 40;
+                            const f32x4 pa = *reinterpret_cast<const f32x4 *>(pp + i * 8);
+                            const f32x4 pb = *reinterpret_cast<const f32x4 *>(pp + i * 8 + 4);
+                            const float e0 = pa[0], e1 = pa[1], e2 = pa[2], e3 = pa[3], e4 = pb[0];
+                            const float fin = pb[1] * so;   // (1 / l_i) and the plane scale (a power of two: exact)
 #pragma unroll
-                            for (int i = 4; i >= 0; --i) {
-                                const f32x4 pa = *reinterpret_cast<const f32x4 *>(pp + i * 8);
-                                const f32x4 pb = *reinterpret_cast<const f32x4 *>(pp + i * 8 + 4);
-                                const float e0 = pa[0], e1 = pa[1], e2 = pa[2], e3 = pa[3], e4 = pb[0];
-                                const float fin = pb[1] * so;   // (1 / l_i) and the plane scale (a power of two: exact)
+                            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                                for (int ni = 2 * hh; ni < 2 * hh + 2; ++ni)
-#pragma unroll
-                                    for (int r = 0; r < 16; ++r) {
-                                        float o = acc[ni][0][r] * e0;
-                                        if (i >= 1) o = fmaf(acc[ni][1][r], e1, o);
-                                        if (i >= 2) o = fmaf(acc[ni][2][r], e2, o);
-                                        if (i >= 3) o = fmaf(acc[ni][3][r], e3, o);
-                                        if (i >= 4) o = fmaf(acc[ni][4][r], e4, o);
-                                        acc[ni][i][r] = o * fin;
-                                    }
-                            }
+                                for (int r = 0; r < 16; ++r) {
+                                    float o = acc[ni][0][r] * e0;
+                                    if (i >= 1) o = fmaf(acc[ni][1][r], e1, o);
+                                    if (i >= 2) o = fmaf(acc[ni][2][r], e2, o);
+                                    if (i >= 3) o = fmaf(acc[ni][3][r], e3, o);
+                                    if (i >= 4) o = fmaf(acc[ni][4][r], e4, o);
+                                    acc[ni][i][r] = o * fin;
+                                }
                         }
-                        // planes of the out-projection's operand, token order: row seq * 5 + i
+                        // Planes of the out-projection's operand in token order.  The wave's 32 sequences x 5 steps are 160
+                        // CONSECUTIVE token rows, but a lane holds rows 5 apart: stored straight from the accumulators every
+                        // instruction touched 64 partly written lines (measured: 0.51 ms for this launch against 0.25 expected).
+                        // Each (block, run) therefore goes through a wave-private 10 KiB LDS block -- two waves per free ring
+                        // stage -- written by (sequence, step) and read back by token row: 1 KiB per store instruction.
+                        unsigned char *stg = pl_smem + ((wave >> 1) ? (d_stage + 1 == R ? 0 : d_stage + 1) : d_stage) * C::STAGE + (wave & 1) * 10240;
+                        const int64_t row0 = ((int64_t)(bm * 64) + wm * 32) * 5;   // first token row of this wave
+                        const int lane64 = hi * 32 + r32;
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            const int64_t m = (int64_t)seqc * 5 + i;
-                            unsigned char *rowp = p.cp + (m >> 6) * (int64_t)p.cp_kblocks * 8192 + (m & 63) * 16;
+                        for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                            for (int ni = 0; ni < 4; ++ni) {
-                                const int kb = (n_w0 >> 5) + ni;
+                            for (int c = 0; c < 2; ++c) {
+                                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                                for (int c = 0; c < 2; ++c) {
+                                for (int i = 0; i < 5; ++i) {
                                     f32x4 va, vb2;
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
@@ -1026,18 +1063,35 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                                     const f16x4 ha = __builtin_convertvector(va, f16x4), hb = __builtin_convertvector(vb2, f16x4);
                                     const f16x4 la = __builtin_convertvector(va - __builtin_convertvector(ha, f32x4), f16x4);
                                     const f16x4 lb = __builtin_convertvector(vb2 - __builtin_convertvector(hb, f32x4), f16x4);
-                                    unsigned char *dst = rowp + (int64_t)kb * 8192 + (c * 2 + hi) * 1024;
-                                    if (live) {
-                                        *reinterpret_cast<u32x4 *>(dst) =
-                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
-                                        *reinterpret_cast<u32x4 *>(dst + 4096) =
-                                            __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
-                                    }
+                                    unsigned char *d = stg + (hi * 160 + r32 * 5 + i) * 16;   // [plane][hi][160 rows][16 B]
+                                    *reinterpret_cast<u32x4 *>(d) = __builtin_bit_cast(u32x4, __builtin_shufflevector(ha, hb, 0, 1, 2, 3, 4, 5, 6, 7));
+                                    *reinterpret_cast<u32x4 *>(d + 5120) =
+                                        __builtin_bit_cast(u32x4, __builtin_shufflevector(la, lb, 0, 1, 2, 3, 4, 5, 6, 7));
                                 }
+                                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes
+                                __builtin_amdgcn_wave_barrier();
+                                const int kb = (n_w0 >> 5) + ni;
+#pragma unroll
+                                for (int pl2 = 0; pl2 < 2; ++pl2)
+#pragma unroll
+                                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                                        for (int j = 0; j < 3; ++j) {
+                                            const int rr = j * 64 + lane64;           // row inside the wave's 160
+                                            const u32x4 w = *reinterpret_cast<const u32x4 *>(stg + ((pl2 * 2 + hh) * 160 + (rr < 160 ? rr : 0)) * 16);
+                                            const int64_t m = row0 + rr;
+                                            if (rr < 160 && m < (int64_t)p.t_nseq * 5)
+                                                *reinterpret_cast<u32x4 *>(p.cp + ((m >> 6) * (int64_t)p.cp_kblocks + kb) * 8192 + pl2 * 4096 +
+                                                                           (c * 2 + hh) * 1024 + (m & 63) * 16) = w;
+                                        }
+                                __builtin_amdgcn_wave_barrier();
                             }
-                            if (live && n_w0 == 0 && hi == 0) p.t_out_scale[m] = 1.0f / so;
+                        if (live && n_w0 == 0 && hi == 0) {
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) p.t_out_scale[(int64_t)seqc * 5 + i] = 1.0f / so;
                         }
                     }
+                    lds_barrier();  // every wave is done with its staging block before the ring takes the stages back
                 } else if constexpr (EPI == PL_QKPACK) {
                     // One head of Q or K per wave (64 columns = blocks 0 .. 1 of the wave tile; NI == 2): a lane holds 32 of
                     // the 64 channels of token m (block ni, run c: d = 32 ni + 16 c + 8 hi + j), its partner lane (hi ^ 1)

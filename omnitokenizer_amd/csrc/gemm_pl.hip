@@ -126,8 +126,10 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
     } else if constexpr (EPI == PL_UNPATCH) {
         return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
     } else if constexpr (EPI == PL_TSCORE || EPI == PL_TPV) {
-        // 320 x 256 tiles, 4 waves of (4 x 5 blocks): one wave per SIMD, 320 accumulator registers; ring of 4 x 36 KiB
-        return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 5>>(p, stream);
+        // 320 x 128 tiles, 4 waves of (2 x 5 blocks): one wave per SIMD, 160 accumulator registers, 7 DMA pieces per wave and step
+        // (the first form, 320 x 256 tiles with 4 x 5 blocks per wave, needed 320 accumulator registers and 9 pieces: 2.6x slower,
+        // profiles/r05_temporal_fused.txt); ring of 4 x 28 KiB
+        return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 2, 5>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
     } else {

@@ -299,17 +299,20 @@ def test_prevq_fusion_and_temporal_chunks_are_bit_identical(models):
             _lib.set_option("prevq_fuse", 1)
             _lib.set_option("temporal_chunk", 0)
             _lib.set_option("vq_screen", 1)
+            _lib.set_option("temporal_fused", 1)
 
-    base = run(prevq_fuse=0, temporal_chunk=0, vq_screen=0)
+    # the chunk option lives on the two-kernel temporal flow ("temporal_fused" 0): every arm below runs that flow
+    _lib.set_option("temporal_fused", 0)
+    base = run(prevq_fuse=0, temporal_chunk=0, vq_screen=0, temporal_fused=0)
     for opts in (dict(prevq_fuse=1, vq_screen=0), dict(vq_screen=1, prevq_fuse=0), dict(temporal_chunk=4), dict(temporal_chunk=3), dict(temporal_chunk=1),
                  dict(temporal_chunk=8), dict(temporal_chunk=100)):
-        got = run(**opts)
+        got = run(temporal_fused=0, **opts)
         assert all(torch.equal(a, b) for a, b in zip(base, got)), opts
     m._sync_engine()
     lib = _lib.load()
     try:
         assert lib.omnitok_engine_set_option(m._engine, b"temporal_chunk", 2) == 0
-        got = run()
+        got = run(temporal_fused=0)
     finally:
         lib.omnitok_engine_set_option(m._engine, b"temporal_chunk", -1)
     assert all(torch.equal(a, b) for a, b in zip(base, got))

@@ -124,8 +124,8 @@ def test_fused_temporal_stage_vs_fp64_and_unfused(ops, nseq, heavy, alibi):
 
 @pytest.mark.parametrize("name", ["s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17_b8"])
 def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
-    """Whole encode / decode with "temporal_fused" 1 (opt-in: correct, but slower than the two-kernel form on this part, see
-    profiles/r05_temporal_fused.txt) against the reference's golden outputs: same bars as the default flow."""
+    """Whole encode / decode with "temporal_fused" 1 (the default since r05) and 0 (q|k|v GEMM + attn_temporal kernel) against the
+    reference's golden outputs: same bars for both, and the two forms agree to rounding."""
     from omnitokenizer_amd import OmniTokenizer_VQGAN, _lib
     from tests.helpers import GoldenCase
     from tests.test_gpu_e2e import PIXEL_TOL, Z_TOL, assert_ids_match_or_near_tie
@@ -140,7 +140,7 @@ def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
         ids1, z1 = m.encode(c.x.cuda(), False, return_latents=True)
         rec1 = m.decode(c.ids.cuda(), False)
     finally:
-        _lib.set_option("temporal_fused", 0)
+        _lib.set_option("temporal_fused", 1)
     assert not torch.equal(z0, z1)   # the option is live (the two forms round differently)
     noise = max(c.fp32_noise_z, 0.0)
     ztol = max(Z_TOL, 8.0 * noise)

@@ -1,0 +1,16 @@
+#!/bin/bash
+cd /tmp; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r05c11; mkdir -p $O
+timeout 300 python -m pytest tests/test_gpu_temporal_fused.py -q 2>&1 | grep -v amdgpu.ids | tail -5 > $O/tests_unit.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-also --no-clock-probe --steps 3 --warmup 1 --option temporal_fused=1 > $O/stats.log 2>&1
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats_fused.csv; rm -rf $O/stats
+for opt in "temporal_fused=1" "temporal_fused=0" "temporal_fused=1" "temporal_fused=0"; do
+  timeout 200 python bench.py --steps 10 --warmup 3 --no-clock-probe --no-also --no-cpu-baseline --option $opt > $O/c3_${opt}_$RANDOM.json 2>>$O/err.txt
+done
+python - <<'PY' > $O/c3_ab.txt
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r05c11/c3_*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); k=d["kernels"]
+    print(f, d["ms_per_step"], " ".join(f"{n}={k[n]['ms_per_step']:.3f}" for n in ("gemm_qkv","attn_temporal","stats_pack","gemm_out") if n in k))
+PY
+tail -3 $O/tests_unit.txt; grep -E "gemm_pl_kernel<[067]" $O/kernel_stats_fused.csv | cut -c1-170; cat $O/c3_ab.txt
