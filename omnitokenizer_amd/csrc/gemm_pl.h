@@ -315,6 +315,46 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             const int n_w0 = bn * TN + wn * (32 * NI);
             pf_sw = p.w_scale[n_w0 < p.N ? n_w0 + hi * 32 + r32 : 0];
         }
+        // PL_TSCORE / PL_TPV: everything the epilogue reads from memory -- row scales and statistics, column constants, launch 2's
+        // softmax weights -- is requested HERE, a whole K loop ahead (one wave per SIMD: nothing else would hide the round trips;
+        // 60 registers of the 512 this configuration has).  Unconditional loads from clamped addresses, as above.
+        float pt_sa[MI], pt_mu[MI], pt_rs[MI], pt_c0 = 0.0f, pt_c1 = 0.0f, pt_c2 = 0.0f, pt_vb = 1.0f;
+        f32x4 pt_p[10];
+        if constexpr (EPI == PL_TSCORE || EPI == PL_TPV) {
+            const int lid = xcd_remap((int)blockIdx.x + ti * (int)gridDim.x, p.ntiles);
+            int64_t bm;
+            int bn;
+            tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            int r32 = r32_, hi = hi_;
+            asm volatile("" : "+v"(r32), "+v"(hi));
+            const int64_t m_w0 = bm * TM + wm * (32 * MI);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int64_t m = m_w0 + mi * 32 + r32;
+                m = m < p.M ? m : p.M - 1;
+                pt_sa[mi] = p.a_scale[m];
+                pt_mu[mi] = p.fold_stats[2 * m];
+                pt_rs[mi] = p.fold_stats[2 * m + 1];
+            }
+            const int n_w0 = bn * TN + wn * (32 * NI);
+            const int ln = hi * 32 + r32, ncl = n_w0 < p.N ? n_w0 + ln : 0;
+            pt_c0 = p.w_scale[ncl];
+            const bool isq = EPI == PL_TSCORE && wn == 0;
+            const float *fxp = isq ? p.fold_b : p.fold_u;
+            const float *fxb = fxp ? fxp : p.w_scale;
+            pt_c1 = fxb[ncl] * (fxp ? 1.0f : 0.0f);
+            int seq = (int)(bm * 64) + wm * 32 + r32;
+            seq = seq < p.t_nseq ? seq : 0;
+            if constexpr (EPI == PL_TSCORE) {
+                pt_c2 = (isq ? p.q_scale : p.k_scale)[ln];
+            } else {
+                const float *vbp = p.v_bound_dev ? p.v_bound_dev + (seq / p.t_seqs_per_clip) * p.v_bound_stride : p.w_scale;
+                pt_vb = p.v_bound_dev ? *vbp : 1.0f + 0.0f * *vbp;
+                const float *pp = p.tp + ((int64_t)seq * p.t_heads + (n_w0 < p.N ? n_w0 >> 6 : 0)) * 40;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) pt_p[q] = *reinterpret_cast<const f32x4 *>(pp + q * 4);
+            }
+        }
         for (int k = 0; k < nk; ++k) {
             const int s = ti * nk + k;
             const bool more = (DBG & 4) ? false : s + D < total;  // wave-uniform
@@ -420,6 +460,8 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                         float av;
                         if constexpr (EPI == PL_GEGLU && NI == 2)
                             av = pf_sa[mi];  // requested before the K loop
+                        else if constexpr (EPI == PL_TSCORE || EPI == PL_TPV)
+                            av = pt_sa[mi];
                         else
                             av = abase[m < mmax ? m : mmax];
                         sa[mi] = ascl_c * (av * has + (1.0f - has));  // exact: av (has = 1) or 1 (has = 0, av finite)
@@ -433,10 +475,15 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     asm volatile("" : "+v"(sbase), "+v"(mmax));
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) {
-                        const int64_t m = m_w0 + mi * 32 + r32;
-                        const float *sp = sbase + 2 * (m < mmax ? m : mmax);
-                        fmu[mi] = sp[0];
-                        frs[mi] = sp[p.fold_stats ? 1 : 0];
+                        if constexpr (EPI == PL_TSCORE || EPI == PL_TPV) {
+                            fmu[mi] = pt_mu[mi];
+                            frs[mi] = pt_rs[mi];
+                        } else {
+                            const int64_t m = m_w0 + mi * 32 + r32;
+                            const float *sp = sbase + 2 * (m < mmax ? m : mmax);
+                            fmu[mi] = sp[0];
+                            frs[mi] = sp[p.fold_stats ? 1 : 0];
+                        }
                     }
                 }
                 if constexpr (EPI == PL_F32 || EPI == PL_UNPATCH) {
@@ -849,16 +896,13 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     // is then a lane-local dot over 32 channels + one exchange with the partner.  Arithmetic of attn_temporal_reg
                     // (l2norm with F.normalize's eps, learned scales, SDPA scale on q, causal mask, ALiBi, exp(s - max)); the
                     // un-normalised weights e and 1 / sum e go out: 160 bytes per (sequence, head) instead of 2 x 1280 bytes of q and k.
-                    static_assert(EPI != PL_TSCORE || (NI == 2 && MI == 5 && C::WN == 2 && R - D >= 2 && C::STAGE >= 16384),
+                    static_assert(EPI != PL_TSCORE || (NI == 2 && MI == 5 && C::WN == 2 && R - D >= 2 && C::STAGE >= 24576),
                                   "q_h | k_h waves x 5 time steps; exchange buffers in the free ring stages");
                     {
                         const bool isq = wn == 0;  // wave-uniform
                         const int head = n_w0 >> 7;
                         const int ln = hi * 32 + r32;
-                        const int ncl = n_w0 < p.N ? n_w0 + ln : 0;
-                        const float swl = p.w_scale[ncl];
-                        const float fxl = isq ? (p.fold_b ? p.fold_b[ncl] : 0.0f) : (p.fold_u ? p.fold_u[ncl] : 0.0f);
-                        const float svl = (isq ? p.q_scale : p.k_scale)[ln];
+                        const float swl = pt_c0, fxl = pt_c1, svl = pt_c2;   // requested before the K loop
                         float ss[MI];
 #pragma unroll
                         for (int mi = 0; mi < MI; ++mi) ss[mi] = 0.0f;
@@ -908,53 +952,61 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                                     for (int e = 0; e < 8; ++e) acc[ni][mi][c * 8 + e] = acc[ni][mi][c * 8 + e] * inv[mi] * s8[e] * mul;
                             }
-                        // exchange + scores: round s hands k_s over; the q wave forms d[t][s] for t >= s
-                        unsigned char *xb[2] = {pl_smem + d_stage * C::STAGE, pl_smem + (d_stage + 1 == R ? 0 : d_stage + 1) * C::STAGE};
-                        const int rowb = (wm * 32 + r32) * 256, sw15 = r32 & 15;
+                        // exchange + scores: the k wave of a half hands its k to the q wave of the same half in two rounds (steps
+                        // 0..2, then 3..4: 24 / 16 KiB in the half's own free ring stage); the q wave forms d[t][s] for t >= s
+                        unsigned char *xb = pl_smem + (wm ? (d_stage + 1 == R ? 0 : d_stage + 1) : d_stage) * C::STAGE;
+                        const int rowb = r32 * 256, sw15 = r32 & 15;
                         float sc[15];  // d[t][s] at t (t + 1) / 2 + s
 #pragma unroll
-                        for (int s = 0; s < 5; ++s) {
-                            unsigned char *buf = xb[s & 1];
+                        for (int rd = 0; rd < 2; ++rd) {
+                            const int s0 = rd ? 3 : 0, s1 = rd ? 5 : 3;
                             if (!isq) {
 #pragma unroll
-                                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                                        for (int h = 0; h < 2; ++h) {
-                                            const int chunk = ni * 8 + c * 4 + hi * 2 + h;
-                                            *reinterpret_cast<f32x4 *>(buf + rowb + ((chunk ^ sw15) << 4)) =
-                                                f32x4{acc[ni][s][c * 8 + h * 4], acc[ni][s][c * 8 + h * 4 + 1], acc[ni][s][c * 8 + h * 4 + 2],
-                                                      acc[ni][s][c * 8 + h * 4 + 3]};
-                                        }
-                            }
-                            lds_barrier();
-                            if (isq) {
-                                f32x4 kk[8];
-#pragma unroll
-                                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                                    for (int c = 0; c < 2; ++c)
-#pragma unroll
-                                        for (int h = 0; h < 2; ++h) {
-                                            const int chunk = ni * 8 + c * 4 + hi * 2 + h;
-                                            kk[ni * 4 + c * 2 + h] = *reinterpret_cast<const f32x4 *>(buf + rowb + ((chunk ^ sw15) << 4));
-                                        }
-#pragma unroll
-                                for (int t = s; t < 5; ++t) {
-                                    float d = 0.0f;
+                                for (int s = s0; s < s1; ++s)
 #pragma unroll
                                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                                         for (int c = 0; c < 2; ++c)
 #pragma unroll
-                                            for (int h = 0; h < 2; ++h)
+                                            for (int h = 0; h < 2; ++h) {
+                                                const int chunk = ni * 8 + c * 4 + hi * 2 + h;
+                                                *reinterpret_cast<f32x4 *>(xb + (s - s0) * 8192 + rowb + ((chunk ^ sw15) << 4)) =
+                                                    f32x4{acc[ni][s][c * 8 + h * 4], acc[ni][s][c * 8 + h * 4 + 1], acc[ni][s][c * 8 + h * 4 + 2],
+                                                          acc[ni][s][c * 8 + h * 4 + 3]};
+                                            }
+                            }
+                            lds_barrier();
+                            if (isq) {
 #pragma unroll
-                                                for (int e = 0; e < 4; ++e)
-                                                    d = fmaf(acc[ni][t][c * 8 + h * 4 + e], kk[ni * 4 + c * 2 + h][e], d);
-                                    sc[t * (t + 1) / 2 + s] = d + swap32(d);
+                                for (int s = s0; s < s1; ++s) {
+                                    f32x4 kk[8];
+#pragma unroll
+                                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                            for (int h = 0; h < 2; ++h) {
+                                                const int chunk = ni * 8 + c * 4 + hi * 2 + h;
+                                                kk[ni * 4 + c * 2 + h] =
+                                                    *reinterpret_cast<const f32x4 *>(xb + (s - s0) * 8192 + rowb + ((chunk ^ sw15) << 4));
+                                            }
+#pragma unroll
+                                    for (int t = s; t < 5; ++t) {
+                                        float d = 0.0f;
+#pragma unroll
+                                        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                                            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                                                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                                                    for (int e = 0; e < 4; ++e)
+                                                        d = fmaf(acc[ni][t][c * 8 + h * 4 + e], kk[ni * 4 + c * 2 + h][e], d);
+                                        sc[t * (t + 1) / 2 + s] = d + swap32(d);
+                                    }
                                 }
                             }
+                            if (rd == 0) lds_barrier();  // round 0 is read before round 1 overwrites the block
                         }
                         lds_barrier();  // every q wave is done with the buffers before the ring takes the stages back
                         if (isq && n_w0 < p.N) {
@@ -991,15 +1043,11 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     if (n_w0 < p.N) {
                         const int head = n_w0 >> 6;
                         const int ln = hi * 32 + r32;
-                        const float swl = p.w_scale[n_w0 + ln];
-                        const float ful = p.fold_u ? p.fold_u[n_w0 + ln] : 0.0f;
+                        const float swl = pt_c0, ful = pt_c1;   // requested before the K loop, like the softmax weights pt_p
                         const int seq = (int)(bm * 64) + wm * 32 + r32;
                         const bool live = seq < p.t_nseq;
                         const int seqc = live ? seq : 0;
-                        float vb = p.v_bound;
-                        if (p.v_bound_dev) vb *= p.v_bound_dev[(seqc / p.t_seqs_per_clip) * p.v_bound_stride];
-                        const float so = h2_scale_of_bound(vb);
-                        const float *pp = p.tp + ((int64_t)seqc * p.t_heads + head) * 40;
+                        const float so = h2_scale_of_bound(p.v_bound * pt_vb);
                         // phase A: v = xc . Wv^T (scales) + mean u
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
@@ -1023,8 +1071,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 #pragma unroll
                         for (int i = 4; i >= 0; --i) {
                             __builtin_amdgcn_sched_barrier(0);
-                            const f32x4 pa = *reinterpret_cast<const f32x4 *>(pp + i * 8);
-                            const f32x4 pb = *reinterpret_cast<const f32x4 *>(pp + i * 8 + 4);
+                            const f32x4 pa = pt_p[2 * i], pb = pt_p[2 * i + 1];
                             const float e0 = pa[0], e1 = pa[1], e2 = pa[2], e3 = pa[3], e4 = pb[0];
                             const float fin = pb[1] * so;   // (1 / l_i) and the plane scale (a power of two: exact)
 #pragma unroll
