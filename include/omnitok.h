@@ -60,6 +60,10 @@ const char *omnitok_version(void);
  *   "temporal_fused" 1 (default) temporal blocks with T' = 5 (causal, S % 64 == 0) run as two GEMM launches with the attention
  *                in their epilogues (omnitok_pl_gemm epilogues 6 / 7: no fp32 q|k|v in memory) | 0 q|k|v GEMM + the
  *                omnitok_attn_temporal kernel; the two forms agree to rounding (profiles/r05_temporal_fused.txt)
+ *   "temporal_kernel" 1 (default, process-wide) the two launches of "temporal_fused" run on gemm_plt_kernel: two workgroups per CU, so
+ *                one's epilogue overlaps the other's K loop (-0.9 ms per step, profiles/r05_temporal_plt.txt) | 2 the same kernel with
+ *                one workgroup per CU (the reference of the co-residency test) | 0 the first form, gemm_pl_kernel at one wave per SIMD;
+ *                all three agree to rounding
  *   "attn_window_mode" 1 (default, process-wide, with gemm_pl / qkv_pl) window attention on the fp16 matrix cores from packed
  *                operands (omnitok_stats_pack_windows -> packing epilogues -> omnitok_attn_window_h2) | 0 fp32 q|k|v and the
  *                fp32-MFMA kernel omnitok_attn_window_planes

@@ -17,9 +17,9 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libomnitok.so")
-SOURCES = ["common.cpp", "gemm.hip", "gemm_x3.hip", "gemm_h2.hip", "gemm_pl.hip", "norm.hip", "peg.hip", "attn_spatial.hip", "attn_h2.hip", "attn_temporal.hip",
+SOURCES = ["common.cpp", "gemm.hip", "gemm_x3.hip", "gemm_h2.hip", "gemm_pl.hip", "gemm_plt.hip", "norm.hip", "peg.hip", "attn_spatial.hip", "attn_h2.hip", "attn_temporal.hip",
            "vq.hip", "resample.hip", "engine.hip", "engine_build.hip", "engine_run.hip", "lm.hip", "lm_select.hip", "debug.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_x_common.h"), os.path.join(CSRC, "h2_common.h"), os.path.join(CSRC, "gemm_pl.h"), os.path.join(CSRC, "engine.h"), os.path.join(CSRC, "planes.h"), os.path.join(CSRC, "peg_wide.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "gemm_x_common.h"), os.path.join(CSRC, "h2_common.h"), os.path.join(CSRC, "gemm_pl.h"), os.path.join(CSRC, "gemm_plt.h"), os.path.join(CSRC, "engine.h"), os.path.join(CSRC, "planes.h"), os.path.join(CSRC, "peg_wide.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok_lm.h"),
            os.path.join(os.path.dirname(HERE), "include", "omnitok_debug.h"),
@@ -37,12 +37,17 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found")
 
 
-def _digest(paths) -> str:
+# per-file flags.  gemm_plt.hip: no SLP vectorisation -- its epilogues run beside another workgroup's MFMAs on the same SIMD, and the
+# v_pk_*_f32 instructions SLP forms there were the one place a wrong value was ever observed (profiles/r05_temporal_plt.txt)
+FILE_FLAGS = {"gemm_plt.hip": os.environ.get("OMNITOK_PLT_FLAGS", "-fno-slp-vectorize").split()}
+
+
+def _digest(paths, extra=()) -> str:
     h = hashlib.sha256()
     for p in paths:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join([*FLAGS, *extra]).encode())
     return h.hexdigest()
 
 
@@ -50,10 +55,11 @@ def _compile(src: str) -> str:
     path = os.path.join(CSRC, src)
     obj = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
     stamp = obj + ".sha"
-    dig = _digest([path] + HEADERS)
+    extra = FILE_FLAGS.get(src, [])
+    dig = _digest([path] + HEADERS, extra)
     if os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == dig:
         return obj
-    cmd = [_hipcc(), *FLAGS, "-x", "hip", "-c", path, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-x", "hip", "-c", path, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")

@@ -72,6 +72,7 @@ extern int g_pl_min_tokens;
 extern int g_temporal_chunk;
 extern int g_prevq_fuse;
 extern int g_temporal_fused;
+extern int g_temporal_kernel;
 extern int g_qkv_pl;
 extern int g_attn_window_mode;
 extern int g_pl_cfg;
@@ -103,6 +104,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "temporal_chunk")) omnitok::g_temporal_chunk = value;
     else if (!strcmp(name, "prevq_fuse")) omnitok::g_prevq_fuse = value;
     else if (!strcmp(name, "temporal_fused")) omnitok::g_temporal_fused = value;
+    else if (!strcmp(name, "temporal_kernel")) omnitok::g_temporal_kernel = value;
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
     else if (!strcmp(name, "pl_stagger")) omnitok::g_pl_stagger = value;
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;

@@ -5,6 +5,8 @@ namespace omnitok {
 
 extern int g_gemm_gn;
 int g_pl_stagger = 0;  // "pl_stagger": start delay step of persistent workgroups (~1 us units), 0 = off
+// "temporal_kernel": the fused temporal stage's GEMMs (epilogues 6 / 7) on 1 = gemm_plt_kernel (two workgroups per CU), 0 = gemm_pl_kernel
+int g_temporal_kernel = 1;
 int g_pl_cfg = 0;  // "pl_cfg": 0 auto | 1 256x256 (8 waves, 1 workgroup per CU) | 2 128(n)x256(m) (4 waves, 2 per CU)
 
 // ---- weight rows -> scaled fp16 planes, rows permuted inside groups of 32 (pl_perm) ------------------------------
@@ -117,6 +119,9 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     return OMNITOK_OK;
 }
 
+int launch_plt_tscore(PlParams p, hipStream_t stream);  // gemm_plt.hip
+int launch_plt_tpv(PlParams p, hipStream_t stream);
+
 template <int EPI>
 static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
     if constexpr (EPI == PL_VPACK) {
@@ -129,6 +134,7 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
         // 320 x 128 tiles, 4 waves of (2 x 5 blocks): one wave per SIMD, 160 accumulator registers, 7 DMA pieces per wave and step
         // (the first form, 320 x 256 tiles with 4 x 5 blocks per wave, needed 320 accumulator registers and 9 pieces: 2.6x slower,
         // profiles/r05_temporal_fused.txt); ring of 4 x 28 KiB
+        if (g_temporal_kernel >= 1) return EPI == PL_TSCORE ? launch_plt_tscore(p, stream) : launch_plt_tpv(p, stream);
         return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 2, 5>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows

@@ -72,7 +72,7 @@ def test_stats_pack_temporal_is_the_permuted_stats_pack(ops):
 
 
 @pytest.mark.parametrize("nseq,heavy,alibi", [(64, False, False), (1024, False, False), (1024, True, False), (200, False, True),
-                                              (4096, False, False)])
+                                              (4096, False, False), (8192, True, False)])
 def test_fused_temporal_stage_vs_fp64_and_unfused(ops, nseq, heavy, alibi):
     heads, D = 8, 512
     oi, ri = build_operands(ops, nseq, heads, seed=10 + nseq, heavy=heavy)
@@ -122,6 +122,35 @@ def test_fused_temporal_stage_vs_fp64_and_unfused(ops, nseq, heavy, alibi):
     assert derr < 4e-6 * max(1.0, vmax)
 
 
+@pytest.mark.parametrize("nseq", [4096, 8192, 16384, 8200])
+def test_two_workgroups_per_cu_are_bit_identical_to_one(ops, nseq):
+    """gemm_plt_kernel with two workgroups per CU ("temporal_kernel" 1, the default) against the same kernel with one per CU (2),
+    ten launches each size, bit for bit: 1, 2 and 4 tiles per workgroup and a ragged last tile.  Builds whose P . V arithmetic the
+    compiler had packed into v_pk_*_f32 failed exactly this, every launch, and only with two workgroups per CU
+    (profiles/r05_temporal_plt.txt); the first form ("temporal_kernel" 0) bounds both to rounding."""
+    from omnitokenizer_amd import _lib
+    heads = 8
+    oi, ri = build_operands(ops, nseq, heads, seed=3 + nseq, heavy=True)
+    pl, sc, st = ops.stats_pack_temporal(oi["x"], nseq)
+    vb = 1.01 * float(ri["x"].norm(dim=1).max()) * float(ri["wv"].norm(dim=1).max())
+    args = (pl, sc, st, nseq, heads, oi["wqk"], oi["wv"], oi["fold_qk"], oi["fu_v"], oi["qs"], oi["ks"], 8.0, vb)
+    try:
+        _lib.set_option("temporal_kernel", 2)
+        P0, O0, S0 = ops.temporal_fused(*args)
+        _lib.set_option("temporal_kernel", 0)
+        P1, O1, S1 = ops.temporal_fused(*args)
+        _lib.set_option("temporal_kernel", 1)
+        for rep in range(10):
+            P, O, S = ops.temporal_fused(*args)
+            assert torch.equal(P, P0) and torch.equal(O, O0) and torch.equal(S, S0), f"launch {rep}"
+    finally:
+        _lib.set_option("temporal_kernel", 1)
+    assert float((P0 - P1).abs().max()) < 2e-6 and torch.equal(S0, S1)
+    a = ops.pl_unpack_planes(O0, nseq * 5, heads * 64) * S0[:, None]
+    b = ops.pl_unpack_planes(O1, nseq * 5, heads * 64) * S1[:, None]
+    assert float((a - b).abs().max()) < 4e-6 * max(1.0, float(b.abs().max()))
+
+
 @pytest.mark.parametrize("name", ["s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17", "heavy_s2_sdpa_r256_vid17_b8"])
 def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
     """Whole encode / decode with "temporal_fused" 1 (the default since r05) and 0 (q|k|v GEMM + attn_temporal kernel) against the
@@ -139,12 +168,20 @@ def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
         _lib.set_option("temporal_fused", 1)
         ids1, z1 = m.encode(c.x.cuda(), False, return_latents=True)
         rec1 = m.decode(c.ids.cuda(), False)
+        _lib.set_option("temporal_kernel", 2)   # one workgroup per CU: bit-identical to the default (two)
+        ids2, z2 = m.encode(c.x.cuda(), False, return_latents=True)
+        _lib.set_option("temporal_kernel", 0)   # the first fused form: same bars
+        ids3, z3 = m.encode(c.x.cuda(), False, return_latents=True)
     finally:
         _lib.set_option("temporal_fused", 1)
+        _lib.set_option("temporal_kernel", 1)
+    assert torch.equal(z1, z2) and torch.equal(ids1, ids2)
     assert not torch.equal(z0, z1)   # the option is live (the two forms round differently)
     noise = max(c.fp32_noise_z, 0.0)
     ztol = max(Z_TOL, 8.0 * noise)
-    assert float((z1.cpu() - c.z).abs().max()) < ztol and float((z1 - z0).abs().max()) < 2 * ztol
+    zerr, zdiff = float((z1.cpu() - c.z).abs().max()), float((z1 - z0).abs().max())
+    assert zerr < ztol and zdiff < 2 * ztol, (zerr, zdiff, ztol)
+    assert float((z3.cpu() - c.z).abs().max()) < ztol and float((z3 - z1).abs().max()) < 2 * ztol
     assert_ids_match_or_near_tie(ids1, c.ids, z1, c.sd["codebook.embeddings"], name + " (fused temporal stage)")
     perr = float((c.strided(rec1.cpu()) - c.recon).abs().max())
     assert perr < max(PIXEL_TOL, 8.0 * c.fp32_noise_pix)

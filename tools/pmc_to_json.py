@@ -24,8 +24,8 @@ FAMILIES = {
     "gemm_qk_pack": ["gemm_pl_kernel<4,"],        # spatial and window q|k launches (packed Q / K)
     "gemm_v_pack": ["gemm_pl_kernel<3,"],         # spatial and window v launches (packed V)
     "gemm_pixels": ["gemm_pl_kernel<5,"],         # to_pixels with the un-patchify store
-    "gemm_t_scores": ["gemm_pl_kernel<6,"],       # fused temporal stage, launch 1: q|k GEMM -> softmax weights (r05)
-    "gemm_t_pv": ["gemm_pl_kernel<7,"],           # fused temporal stage, launch 2: V GEMM -> attention output planes (r05)
+    "gemm_t_scores": ["gemm_plt_kernel<6>", "gemm_pl_kernel<6,"],       # fused temporal stage, launch 1: q|k GEMM -> softmax weights (r05)
+    "gemm_t_pv": ["gemm_plt_kernel<7>", "gemm_pl_kernel<7,"],           # fused temporal stage, launch 2: V GEMM -> attention output planes (r05)
     # the fp32 epilogue serves FF-out (16 launches, K = 1408) AND the temporal / window q|k|v launches (10, K = 512): one
     # kernel name, so the counters cannot be split per family -- reported under its own key, not as gemm_ff_out
     "gemm_f32_epilogue_mixed": ["gemm_pl_kernel<0,"],

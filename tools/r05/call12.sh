@@ -1,0 +1,17 @@
+#!/bin/bash
+cd /tmp; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r05c12; mkdir -p $O
+timeout 300 python tools/r05/plt_check.py > $O/plt_check.txt 2>&1
+timeout 300 python -m pytest tests/test_gpu_temporal_fused.py -q 2>&1 | grep -v amdgpu.ids | tail -5 > $O/tests_unit.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --no-cpu-baseline --no-also --no-clock-probe --steps 3 --warmup 1 --option temporal_kernel=1 > $O/stats.log 2>&1
+cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/kernel_stats_plt.csv; rm -rf $O/stats
+for opt in "temporal_kernel=1" "temporal_kernel=0" "temporal_kernel=1" "temporal_kernel=0"; do
+  timeout 200 python bench.py --steps 10 --warmup 3 --no-clock-probe --no-also --no-cpu-baseline --option $opt > $O/c3_${opt}_$RANDOM.json 2>>$O/err.txt
+done
+python - <<'PY' > $O/c3_ab.txt
+import json,glob
+for f in sorted(glob.glob("gpurun_out/r05c12/c3_*.json")):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); k=d["kernels"]
+    print(f, d["ms_per_step"], " ".join(f"{n}={k[n]['ms_per_step']:.3f}" for n in ("gemm_qkv","attn_temporal","stats_pack","gemm_out") if n in k))
+PY
+cat $O/plt_check.txt | tail -8; tail -3 $O/tests_unit.txt; grep -E "gemm_plt?_kernel<[67]" $O/kernel_stats_plt.csv | cut -c1-170; cat $O/c3_ab.txt
