@@ -134,7 +134,10 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
         // 320 x 128 tiles, 4 waves of (2 x 5 blocks): one wave per SIMD, 160 accumulator registers, 7 DMA pieces per wave and step
         // (the first form, 320 x 256 tiles with 4 x 5 blocks per wave, needed 320 accumulator registers and 9 pieces: 2.6x slower,
         // profiles/r05_temporal_fused.txt); ring of 4 x 28 KiB
-        if (g_temporal_kernel >= 1) return EPI == PL_TSCORE ? launch_plt_tscore(p, stream) : launch_plt_tpv(p, stream);
+        // gemm_plt_kernel addresses its output planes and the softmax weights with 32-bit offsets: calls beyond 4 GiB of either
+        // (more than ~400 clips of 17 x 256 x 256 in one call) take the first form below
+        const bool fits32 = (int64_t)p.M * (EPI == PL_TPV ? p.cp_kblocks * 32 : 0) * 4 < (1ll << 32) && (int64_t)p.t_nseq * p.t_heads * 160 < (1ll << 32);
+        if (g_temporal_kernel >= 1 && fits32) return EPI == PL_TSCORE ? launch_plt_tscore(p, stream) : launch_plt_tpv(p, stream);
         return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 2, 5>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
         return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
