@@ -78,7 +78,10 @@ const char *omnitok_version(void);
  * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant" (1 default: LDS-tiled -- the 64-channel kernel of peg_wide.h for
  * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, its one-plane form (9 taps, four workgroups per CU) for images,
  * else the 32-channel time ring | 2 the 64-channel walk kernel whenever the grid allows | 3 time ring only (1, 2, 3 bit-identical)
- * | 0 register-blocked), "lm_wide_u"; "x3_dbg" / "h2_dbg" select
+ * | 0 register-blocked), "lm_wide_u"; LM decode A/B switches (include/omnitok_lm.h; profiles/r05_lm_timeline.txt): "lm_ksliced" 1
+ * (default) K-sliced GEMV for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 row GEMV; "lm_balance" 1 (default) 6 waves per workgroup
+ * where that makes the row GEMV's grid a whole number of workgroups per CU | 0 four; "lm_attn_waves" 8 (default) | 4 waves per
+ * 256-key attention chunk; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* Reads the process default of a data-flow option ("gemm_mode", "attn_mode", "gemm_pl", "pl_min_tokens", "temporal_chunk",

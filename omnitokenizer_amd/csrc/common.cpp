@@ -57,6 +57,7 @@ extern int g_gemm_small;
 extern int g_gemm_gn;
 extern int g_vq_split;
 extern long long *g_gemm_trace;
+void lm_trace_reset();
 extern int g_peg_variant;
 extern int g_x3_tile;
 extern int g_x3_dbg;
@@ -81,6 +82,9 @@ extern int g_vq_variant;
 extern int g_vq_screen;
 extern int g_vq_screen_split;
 extern int g_lm_wide_u;
+extern int g_lm_balance;
+extern int g_lm_ksliced;
+extern int g_lm_attn_waves;
 }  // namespace omnitok
 
 extern "C" int omnitok_set_option(const char *name, int value) {
@@ -110,6 +114,9 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;
     else if (!strcmp(name, "attn_window_mode")) omnitok::g_attn_window_mode = value;
     else if (!strcmp(name, "lm_wide_u")) omnitok::g_lm_wide_u = value;
+    else if (!strcmp(name, "lm_balance")) omnitok::g_lm_balance = value;
+    else if (!strcmp(name, "lm_ksliced")) omnitok::g_lm_ksliced = value;
+    else if (!strcmp(name, "lm_attn_waves")) omnitok::g_lm_attn_waves = value;
     else if (!strcmp(name, "h2_dbg")) omnitok::g_h2_dbg = value;
     else if (!strcmp(name, "h2_tile")) omnitok::g_h2_tile = value;
     else if (!strcmp(name, "x3_dbg")) omnitok::g_x3_dbg = value;
@@ -139,6 +146,7 @@ extern "C" int omnitok_get_option(const char *name, int *value) {
 
 extern "C" int omnitok_debug_set_gemm_trace(long long *dev_ptr) {
     omnitok::g_gemm_trace = dev_ptr;
+    omnitok::lm_trace_reset();
     return OMNITOK_OK;
 }
 

@@ -16,7 +16,7 @@
 // Shapes and launch grids do not depend on the position (chunks beyond the cache length exit at
 // once), so a step can be captured once in a HIP graph and replayed for every token.
 #include "common.h"
-#include "gemm_common.h"  // gelu_erf
+#include "gemm_x_common.h"  // gelu_erf, x3_rsrc
 #include "../../include/omnitok_lm.h"
 
 #include <map>
@@ -71,15 +71,17 @@ struct LmMerge {
     int n_head, hd, nchunk;
 };
 
-template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
-__global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ x, const float *__restrict__ w,
+template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM, int NW>
+__global__ __launch_bounds__(NW * 64) void lm_gemv_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                       const float *__restrict__ bias, const float *residual,
                                                       const float *__restrict__ g, const float *__restrict__ beta,
                                                       float *y, int N, int K, LmMerge mg) {
     extern __shared__ __attribute__((aligned(16))) float xs[];  // [BQ][kp]
     __shared__ float s_mean[BQ], s_rstd[BQ];
+    constexpr int NT = NW * 64;  // NW waves per workgroup: the launcher picks NW and ROWS so that the grid is a whole number of
+                                 // workgroups per CU (a CU that gets one workgroup more than its neighbour streams that much longer)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = (blockIdx.x * 4 + wave) * ROWS;
+    const int row0 = (blockIdx.x * NW + wave) * ROWS;
     const int kp = K < LM_KP ? K : LM_KP;
     const int nch = K >> 8;  // 256-float chunks
     const float *wr[ROWS];
@@ -102,35 +104,42 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     // block-wide reductions over registers, and the normalised row goes straight to LDS.
     const bool ln_fast = LN && K <= LM_KP;
     if (ln_fast) {
-        __shared__ float s_part[2][BQ][4];
-        const int k4n = K >> 2;  // float4 per row (<= 512: two per thread)
-        const bool has0 = tid < k4n, has1 = tid + 256 < k4n;
-        f32x4 xv[BQ][2], g4[2], b4[2];
+        __shared__ float s_part[2][BQ][NW];
+        const int k4n = K >> 2;  // float4 per row (<= 512: NJ per thread)
+        constexpr int NJ = (LM_KP / 4 + NT - 1) / NT;
+        f32x4 xv[BQ][NJ], g4[NJ], b4[NJ];
         const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const bool has = j == 0 ? has0 : has1;
-            g4[j] = has ? *reinterpret_cast<const f32x4 *>(g + (tid + 256 * j) * 4) : zero4;
-            b4[j] = has ? *reinterpret_cast<const f32x4 *>(beta + (tid + 256 * j) * 4) : zero4;
+        for (int j = 0; j < NJ; ++j) {
+            const bool has = tid + NT * j < k4n;
+            g4[j] = has ? *reinterpret_cast<const f32x4 *>(g + (tid + NT * j) * 4) : zero4;
+            b4[j] = has ? *reinterpret_cast<const f32x4 *>(beta + (tid + NT * j) * 4) : zero4;
 #pragma unroll
             for (int b = 0; b < BQ; ++b)
-                xv[b][j] = has ? *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + (tid + 256 * j) * 4) : zero4;
+                xv[b][j] = has ? *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + (tid + NT * j) * 4) : zero4;
         }
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
-            const f32x4 t = xv[b][0] + xv[b][1];
+            f32x4 t = xv[b][0];
+#pragma unroll
+            for (int j = 1; j < NJ; ++j) t = t + xv[b][j];
             const float sum = wave_allsum((t[0] + t[1]) + (t[2] + t[3]));
             if (lane == 0) s_part[0][b][wave] = sum;
         }
-        __syncthreads();
+        lds_barrier();  // LDS traffic only: __syncthreads() would also wait for every weight load in flight
         float mean[BQ];
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
-            mean[b] = ((s_part[0][b][0] + s_part[0][b][1]) + (s_part[0][b][2] + s_part[0][b][3])) / (float)K;
+            float tot = 0.0f;
+            if constexpr (NW == 4) tot = (s_part[0][b][0] + s_part[0][b][1]) + (s_part[0][b][2] + s_part[0][b][3]);
+            else
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8) tot += s_part[0][b][w8];
+            mean[b] = tot / (float)K;
             float q = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j == 0 ? has0 : has1) {
+            for (int j = 0; j < NJ; ++j) {
+                if (tid + NT * j < k4n) {
                     const f32x4 a = xv[b][j] - mean[b];
                     q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
                 }
@@ -138,24 +147,29 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
             q = wave_allsum(q);
             if (lane == 0) s_part[1][b][wave] = q;
         }
-        __syncthreads();
+        lds_barrier();  // LDS traffic only: __syncthreads() would also wait for every weight load in flight
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
-            const float var = ((s_part[1][b][0] + s_part[1][b][1]) + (s_part[1][b][2] + s_part[1][b][3])) / (float)K;
+            float tot = 0.0f;
+            if constexpr (NW == 4) tot = (s_part[1][b][0] + s_part[1][b][1]) + (s_part[1][b][2] + s_part[1][b][3]);
+            else
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8) tot += s_part[1][b][w8];
+            const float var = tot / (float)K;
             const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                if (j == 0 ? has0 : has1) {
+            for (int j = 0; j < NJ; ++j) {
+                if (tid + NT * j < k4n) {
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = (xv[b][j][e] - mean[b]) * rstd * g4[j][e] + b4[j][e];
-                    *reinterpret_cast<f32x4 *>(xs + b * kp + (tid + 256 * j) * 4) = v;
+                    *reinterpret_cast<f32x4 *>(xs + b * kp + (tid + NT * j) * 4) = v;
                 }
             }
         }
     } else if (LN) {
         // nn.LayerNorm statistics (two-pass, like ATen): wave w owns activation rows w and w + 4
-        for (int b = wave; b < BQ; b += 4) {
+        for (int b = wave; b < BQ; b += NW) {
             float sum = 0.0f;
             for (int k = lane * 4; k < K; k += 256) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + k);
@@ -203,9 +217,9 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
 
     constexpr int CPP = LM_KP / 256;  // chunks per panel (a multiple of 2 * U)
     for (int p0 = 0; p0 < nch; p0 += CPP) {
-        __syncthreads();  // previous panel fully consumed (and s_mean / s_rstd / s_f visible)
+        lds_barrier();  // LDS traffic only: __syncthreads() would also wait for every weight load in flight  // previous panel fully consumed (and s_mean / s_rstd / s_f visible)
         const int pk = (nch - p0 < CPP ? nch - p0 : CPP) * 256;  // floats in this panel
-        for (int i = tid * 4; i < BQ * pk && !ln_fast; i += 1024) {
+        for (int i = tid * 4; i < BQ * pk && !ln_fast; i += NT * 4) {
             const int b = i / pk, k = i - b * pk;
             f32x4 v;
             if (XM) {
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
             }
             *reinterpret_cast<f32x4 *>(xs + b * kp + k) = v;
         }
-        __syncthreads();
+        lds_barrier();  // LDS traffic only: __syncthreads() would also wait for every weight load in flight
         const int pend = p0 + CPP < nch ? p0 + CPP : nch;
         for (int c0 = p0; c0 < pend; c0 += 2 * U) {
             load_w(wb, c0 + U);  // may belong to the next panel: only the weights are prefetched
@@ -293,14 +307,243 @@ __global__ __launch_bounds__(256) void lm_gemv_kernel(const float *__restrict__ 
     }
 }
 
-// F4 = head_dim / 32 float4 per lane: 8 lanes cover one K/V row of head_dim floats
-template <int F4>
-__global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
-                                                             const int32_t *__restrict__ cache_len, int n_head,
-                                                             int max_len, int prefill_T,
-                                                             float *__restrict__ part, int nchunk,
-                                                             int *__restrict__ err_flag) {
+// K-sliced GEMV (r05; B <= 2, K = NW * CW * 256): wave w of a workgroup owns columns [w * CW * 256, (w + 1) * CW * 256) of EVERY row the
+// workgroup computes, so its slice of the activations lives in registers (no LDS staging, no panel barriers), a row's 6 (or 8) KiB
+// are one contiguous request of the workgroup, and the grid is exactly one workgroup per CU with N / grid rows each.
+// Per row: lane dot over its CW float4 -> wave sum -> one LDS word per (row, wave); one barrier at the end, then the first rows x BQ
+// threads add the NW wave sums in wave order and apply bias / GELU / residual.
+// What the timeline of a decode step (tools/r05/lm_timeline.py, profiles/r05_lm_timeline.txt) taught this kernel:
+//   * loads return in order: what the prologue needs (activations, LayerNorm weights, the attention partials) is requested BEFORE the
+//     weights, or it arrives behind 96 KiB of them;
+//   * no load sits inside a branch -- not a uniform one either: at the join the compiler's counter model only knows "something may
+//     be pending" and waits for vmcnt(0), i.e. for every weight in flight.  Short row groups clamp their row index instead (the
+//     duplicate requests are L2 hits), bias / residual are loaded by every thread from a clamped index;
+//   * the barriers order LDS only (lds_barrier): __syncthreads() drains vmcnt as well.
+#ifndef LM_TRACE
+#define LM_TRACE 0  // 1: s_memrealtime stamps per workgroup (tools/r05/lm_timeline.py; build with OMNITOK_EXTRA_FLAGS=-DLM_TRACE=1)
+#endif
+template <int BQ, int CW, int RG, int ACT, bool LN, bool XM, int NW>
+__global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ bias, const float *residual,
+                                                             const float *__restrict__ g, const float *__restrict__ beta,
+                                                             float *y, int N, int K, LmMerge mg, long long *trace) {
+    extern __shared__ float ks_part[];  // [rows of this workgroup][BQ][NW]
+    auto stamp = [&](int k) {
+        if constexpr (LM_TRACE)
+            if (trace && threadIdx.x == 0) trace[(int64_t)blockIdx.x * 8 + k] = __builtin_amdgcn_s_memrealtime();
+    };
+    stamp(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r_begin = (int)((int64_t)blockIdx.x * N / gridDim.x), r_end = (int)((int64_t)(blockIdx.x + 1) * N / gridDim.x);
+    const int nrows = r_end - r_begin, ngroups = (nrows + RG - 1) / RG;
+    const int col0 = wave * CW * 256 + lane * 4;  // + cw * 256
+    // the workgroup's rows through a buffer descriptor that ends with them: a request past the last row (short last group, the
+    // prefetch of the groups after the last) returns zeros without touching memory -- no branch, no wasted traffic.  aux = 2: nt
+    const auto w_rs = x3_rsrc(w + (int64_t)r_begin * K, nrows * K * 4);
+    const int w_vo = col0 * 4;
+    auto load_w = [&](f32x4 (&dst)[RG][CW], int grp) {
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int cw = 0; cw < CW; ++cw)
+                dst[r][cw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_vo, ((grp * RG + r) * K + cw * 256) * 4, 2));
+    };
+    f32x4 wa[RG][CW], wb[RG][CW];
+    f32x4 xr[BQ][CW];
+    // the finishing thread of output (row r, stream b) is thread r * BQ + b; every thread loads from a clamped index
+    const int fr = tid / BQ < nrows ? tid / BQ : nrows - 1, fb = tid % BQ, fn = r_begin + fr;
+    const float *bias_p = bias ? bias + fn : w, *res_p = residual ? residual + (int64_t)fb * N + fn : w;
+    float e_bias, e_res;
+    // ---- this wave's slice of the activations -> registers, then the weights of the first two row groups ----
+    if constexpr (XM) {
+        // merged attention partials (see lm_gemv_kernel): every lane merges the head its 4 columns belong to.  The partials of the
+        // first XC chunks (1024 keys) are requested before the weights, whether or not they hold keys (selected afterwards: their
+        // addresses exist for every launch); only contexts beyond that take a second round of loads behind the weights.
+        constexpr int XC = 4;
+        const int S = 2 + mg.hd;
+        const float *p0[BQ][CW];  // this head's partials: [M, L, o[hd]] per chunk
+        int dd[CW];
+        float Mc[BQ][CW][XC], Lc[BQ][CW][XC];
+        f32x4 qc[BQ][CW][XC];
+        int used[BQ];
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            used[b] = mg.cache_len[b];
+#pragma unroll
+            for (int cw = 0; cw < CW; ++cw) {
+                const int col = col0 + cw * 256, h = col / mg.hd;
+                dd[cw] = col - h * mg.hd;
+                p0[b][cw] = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * S;
+#pragma unroll
+                for (int c = 0; c < XC; ++c) {
+                    const float *pc = p0[b][cw] + (c < mg.nchunk ? c : mg.nchunk - 1) * S;
+                    Mc[b][cw][c] = pc[0];
+                    Lc[b][cw][c] = pc[1];
+                    qc[b][cw][c] = f32x4{pc[2 + dd[cw]], pc[3 + dd[cw]], pc[4 + dd[cw]], pc[5 + dd[cw]]};
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the requests above go out first (the scheduler otherwise hoists the address-ready weight loads)
+        load_w(wa, 0);
+        load_w(wb, 1);
+        e_bias = *bias_p;
+        e_res = *res_p;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < BQ; ++b) {
+            int nu = (used[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+            if (nu > mg.nchunk) nu = mg.nchunk;
+#pragma unroll
+            for (int cw = 0; cw < CW; ++cw) {
+                const float *pb = p0[b][cw];
+                float M = Mc[b][cw][0];
+#pragma unroll
+                for (int c = 1; c < XC; ++c) M = c < nu ? fmaxf(M, Mc[b][cw][c]) : M;
+                for (int c = XC; c < nu; ++c) M = fmaxf(M, pb[c * S]);
+                float L = 0.0f;
+                L += Lc[b][cw][0] * expf(Mc[b][cw][0] - M);
+#pragma unroll
+                for (int c = 1; c < XC; ++c) L += c < nu ? Lc[b][cw][c] * expf(Mc[b][cw][c] - M) : 0.0f;
+                for (int c = XC; c < nu; ++c) L += pb[c * S + 1] * expf(pb[c * S] - M);
+                const float f0 = expf(Mc[b][cw][0] - M) / L;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                v[0] += qc[b][cw][0][0] * f0;
+                v[1] += qc[b][cw][0][1] * f0;
+                v[2] += qc[b][cw][0][2] * f0;
+                v[3] += qc[b][cw][0][3] * f0;
+#pragma unroll
+                for (int c = 1; c < XC; ++c) {
+                    if (c < nu) {  // (no loads inside: a select of registers)
+                        const float f = expf(Mc[b][cw][c] - M) / L;
+                        v[0] += qc[b][cw][c][0] * f;
+                        v[1] += qc[b][cw][c][1] * f;
+                        v[2] += qc[b][cw][c][2] * f;
+                        v[3] += qc[b][cw][c][3] * f;
+                    }
+                }
+                for (int c = XC; c < nu; ++c) {
+                    const float f = expf(pb[c * S] - M) / L;
+                    const float *q = pb + c * S + 2 + dd[cw];
+                    v[0] += q[0] * f;
+                    v[1] += q[1] * f;
+                    v[2] += q[2] * f;
+                    v[3] += q[3] * f;
+                }
+                xr[b][cw] = v;
+            }
+        }
+    } else {
+        f32x4 g4[CW], b4[CW];
+        f32x4 xf[LN ? BQ : 1][LN ? NW * CW : 1];  // LN: the whole row, for the statistics
+        if constexpr (LN) {
+#pragma unroll
+            for (int b = 0; b < BQ; ++b)
+#pragma unroll
+                for (int c = 0; c < NW * CW; ++c) xf[b][c] = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + c * 256 + lane * 4);
+        }
+#pragma unroll
+        for (int cw = 0; cw < CW; ++cw) {
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) xr[b][cw] = *reinterpret_cast<const f32x4 *>(x + (int64_t)b * K + col0 + cw * 256);
+            if constexpr (LN) {
+                g4[cw] = *reinterpret_cast<const f32x4 *>(g + col0 + cw * 256);
+                b4[cw] = *reinterpret_cast<const f32x4 *>(beta + col0 + cw * 256);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // the requests above go out first (the scheduler otherwise hoists the address-ready weight loads)
+        load_w(wa, 0);
+        load_w(wb, 1);
+        e_bias = *bias_p;
+        e_res = *res_p;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LN) {
+            // nn.LayerNorm, two-pass like ATen.  Every wave reduces the WHOLE row itself (xf: NW * CW float4 per lane, L2 hits for all but
+            // the first wave to ask) instead of exchanging wave partials through LDS: two workgroup barriers, each waiting for the
+            // wave whose slice arrived last, cost 2 us of an 8 us launch (profiles/r05_lm_timeline.txt)
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                f32x4 t = xf[b][0];
+#pragma unroll
+                for (int c = 1; c < NW * CW; ++c) t = t + xf[b][c];
+                const float mean = wave_allsum((t[0] + t[1]) + (t[2] + t[3])) / (float)K;
+                float q = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NW * CW; ++c) {
+                    const f32x4 a = xf[b][c] - mean;
+                    q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+                }
+                const float rstd = 1.0f / sqrtf(wave_allsum(q) / (float)K + 1e-5f);
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[b][cw][e] = (xr[b][cw][e] - mean) * rstd * g4[cw][e] + b4[cw][e];
+            }
+        }
+    }
+    stamp(1);
+    // ---- rows, RG at a time, two groups of weights in flight ----
+    auto consume = [&](const f32x4 (&wv)[RG][CW], int grp) {
+        float acc[RG][BQ];
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                float a = 0.0f;
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) {
+                    a = fmaf(wv[r][cw][0], xr[b][cw][0], a);
+                    a = fmaf(wv[r][cw][1], xr[b][cw][1], a);
+                    a = fmaf(wv[r][cw][2], xr[b][cw][2], a);
+                    a = fmaf(wv[r][cw][3], xr[b][cw][3], a);
+                }
+                acc[r][b] = wave_allsum(a);
+            }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+                if (grp * RG + r < nrows)
+#pragma unroll
+                    for (int b = 0; b < BQ; ++b) ks_part[((grp * RG + r) * BQ + b) * NW + wave] = acc[r][b];
+        }
+    };
+    for (int grp = 0; grp < ngroups; grp += 2) {
+        consume(wa, grp);
+        if (grp == 0) stamp(2);
+        load_w(wa, grp + 2);
+        consume(wb, grp + 1);  // past the last group: nothing is written
+        load_w(wb, grp + 3);
+    }
+    stamp(3);
+    lds_barrier();
+    if (tid < nrows * BQ) {
+        float v = 0.0f;
+#pragma unroll
+        for (int w8 = 0; w8 < NW; ++w8) v += ks_part[(fr * BQ + fb) * NW + w8];
+        if (bias) v += e_bias;
+        if (ACT == 1) v = gelu_erf(v);
+        if (residual) v += e_res;
+        y[(int64_t)fb * N + fn] = v;
+    }
+    if constexpr (LM_TRACE) {
+        __builtin_amdgcn_s_waitcnt(0);
+        stamp(4);
+    }
+}
+
+// F4 = head_dim / 32 float4 per lane: 8 lanes cover one K/V row of head_dim floats.  NWV waves per workgroup share the chunk's
+// LM_CHUNK keys: with 8 waves a wave owns 32 keys = ONE batch of loads, and nothing in a load address depends on cache_len (rows are
+// clamped to the slab, the new token's row comes from qkv and is selected afterwards): q, cache_len and every K / V row of the chunk
+// are one memory round trip where the 4-wave form took three (q + length, then two batches of 32 keys) -- the kernel is a latency
+// chain at decode sizes, not a stream (profiles/r05_lm_balance.txt).
+template <int F4, int NWV>
+__global__ __launch_bounds__(NWV * 64) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
+                                                                  const int32_t *__restrict__ cache_len, int n_head,
+                                                                  int max_len, int prefill_T,
+                                                                  float *__restrict__ part, int nchunk,
+                                                                  int *__restrict__ err_flag) {
     constexpr int HD = F4 * 32;
+    constexpr int KPW = LM_CHUNK / NWV;  // keys per wave
+    static_assert(KPW % 32 == 0, "a wave takes its keys in batches of 32");
     // decode: one query row per stream (row == b), len = cache_len[b].  prefill (prefill_T > 0): row =
     // b * T + t is query position t of stream b; its keys 0..t-1 are already in the cache (scattered by
     // lm_kv_scatter_kernel), key t is the row's own K/V
@@ -310,9 +553,32 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slot = lane >> 3, ds = lane & 7;  // key slot 0..7, dim slot 0..7
     const float *qn = qkv + (int64_t)row * 3 * C + h * HD;
-    f32x4 q[F4];  // requested before cache_len is known (one round trip for both)
+    const float *kn = qn + C, *vn = qn + 2 * C;
+    float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
+    float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
+    const int kbase = c * LM_CHUNK + wave * KPW;
+    // everything this lane will read, requested at once
+    f32x4 q[F4], knv[F4], vnv[F4];
 #pragma unroll
-    for (int i = 0; i < F4; ++i) q[i] = *reinterpret_cast<const f32x4 *>(qn + (ds + 8 * i) * 4);
+    for (int i = 0; i < F4; ++i) {
+        q[i] = *reinterpret_cast<const f32x4 *>(qn + (ds + 8 * i) * 4);
+        knv[i] = *reinterpret_cast<const f32x4 *>(kn + (ds + 8 * i) * 4);
+        vnv[i] = *reinterpret_cast<const f32x4 *>(vn + (ds + 8 * i) * 4);
+    }
+    f32x4 kk[4][F4], vv[4][F4];
+    auto request = [&](int it0) {  // rows past the slab are read from row 0 (a safe address); rows past the sequence hold whatever
+#pragma unroll                     // the cache holds (never used: masked below)
+        for (int j = 0; j < 4; ++j) {
+            const int key = kbase + (it0 + j) * 8 + slot;
+            const int64_t off = (int64_t)(key < max_len ? key : 0) * HD;
+#pragma unroll
+            for (int i = 0; i < F4; ++i) {
+                kk[j][i] = *reinterpret_cast<const f32x4 *>(krow + off + (ds + 8 * i) * 4);
+                vv[j][i] = *reinterpret_cast<const f32x4 *>(vrow + off + (ds + 8 * i) * 4);
+            }
+        }
+    };
+    request(0);
     int len = prefill_T > 0 ? row - b * prefill_T : cache_len[row];
     if (len >= max_len) {
         // a caller stepped past the cache it allocated: flag it (omnitok_lm_overflowed) and stay inside
@@ -322,12 +588,9 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     }
     const int total = len + 1;
     if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
-    const float *kn = qn + C, *vn = qn + 2 * C;
-    float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
-    float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
     // append the new token's K/V (only the workgroup whose chunk holds index len)
     if (prefill_T == 0 && len >= c * LM_CHUNK && len < (c + 1) * LM_CHUNK && len < max_len) {
-        for (int d = tid; d < HD; d += 256) {
+        for (int d = tid; d < HD; d += NWV * 64) {
             krow[(int64_t)len * HD + d] = kn[d];
             vrow[(int64_t)len * HD + d] = vn[d];
         }
@@ -337,46 +600,35 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     f32x4 o[F4];
 #pragma unroll
     for (int i = 0; i < F4; ++i) o[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    const int kbase = c * LM_CHUNK + wave * 64;
-    // 8 keys per iteration; four iterations' K and V rows are requested together (two memory round trips per 64 keys
-    // instead of one per pair).  Rows past the sequence are read from row 0 (a safe address) and masked.
-    for (int it0 = 0; it0 < 8; it0 += 4) {
+    // 8 keys per iteration, four iterations (32 keys) per batch of loads
+    for (int it0 = 0; it0 < KPW / 8; it0 += 4) {
         if (kbase + it0 * 8 >= total) break;  // wave-uniform: no keys left in this chunk
-        f32x4 kk[4][F4], vv[4][F4];
-        bool valid[4];
+        if (it0 > 0) request(it0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int key = kbase + (it0 + j) * 8 + slot;
-            valid[j] = key < total;
-            // the new token's row is read from qkv (its cache copy is being written by this kernel)
-            const float *kp = key == len ? kn : krow + (int64_t)(valid[j] ? key : 0) * HD;
-            const float *vp = key == len ? vn : vrow + (int64_t)(valid[j] ? key : 0) * HD;
-#pragma unroll
-            for (int i = 0; i < F4; ++i) {
-                kk[j][i] = *reinterpret_cast<const f32x4 *>(kp + (ds + 8 * i) * 4);
-                vv[j][i] = *reinterpret_cast<const f32x4 *>(vp + (ds + 8 * i) * 4);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            const bool valid = key < total;
+            // the new token's row comes from qkv (its cache copy is being written by this kernel)
+            const bool fresh = key == len;
             float s = 0.0f;
 #pragma unroll
             for (int i = 0; i < F4; ++i) {
-                s = fmaf(q[i][0], kk[j][i][0], s);
-                s = fmaf(q[i][1], kk[j][i][1], s);
-                s = fmaf(q[i][2], kk[j][i][2], s);
-                s = fmaf(q[i][3], kk[j][i][3], s);
+                const f32x4 kv = fresh ? knv[i] : kk[j][i];
+                s = fmaf(q[i][0], kv[0], s);
+                s = fmaf(q[i][1], kv[1], s);
+                s = fmaf(q[i][2], kv[2], s);
+                s = fmaf(q[i][3], kv[3], s);
             }
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
-            s = valid[j] ? s * scale : -INFINITY;
+            s = valid ? s * scale : -INFINITY;
             const float mn = fmaxf(m, s);
-            if (valid[j] && mn > -INFINITY) {   // a masked key changes nothing (and its V row may be uninitialised)
+            if (valid && mn > -INFINITY) {   // a masked key changes nothing (and its V row may be uninitialised)
                 const float corr = expf(m - mn), p = expf(s - mn);
                 l = l * corr + p;
 #pragma unroll
-                for (int i = 0; i < F4; ++i) o[i] = o[i] * corr + vv[j][i] * p;
+                for (int i = 0; i < F4; ++i) o[i] = o[i] * corr + (fresh ? vnv[i] : vv[j][i]) * p;
                 m = mn;
             }
         }
@@ -398,9 +650,9 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[i][e] += __shfl_xor(o[i][e], sh);
     }
-    // merge the 4 waves through LDS
-    __shared__ float s_m[4], s_l[4];
-    __shared__ __attribute__((aligned(16))) float s_o[4][HD];
+    // merge the waves through LDS
+    __shared__ float s_m[NWV], s_l[NWV];
+    __shared__ __attribute__((aligned(16))) float s_o[NWV][HD];
     if (lane < 8) {
 #pragma unroll
         for (int i = 0; i < F4; ++i) *reinterpret_cast<f32x4 *>(&s_o[wave][(lane + 8 * i) * 4]) = o[i];
@@ -411,10 +663,12 @@ __global__ __launch_bounds__(256) void lm_attn_decode_kernel(const float *__rest
     }
     __syncthreads();
     if (tid < HD) {
-        float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        float M = s_m[0];
+#pragma unroll
+        for (int wv = 1; wv < NWV; ++wv) M = fmaxf(M, s_m[wv]);
         float L = 0.0f, O = 0.0f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
+        for (int wv = 0; wv < NWV; ++wv) {
             const float f = s_m[wv] > -INFINITY ? expf(s_m[wv] - M) : 0.0f;
             L += s_l[wv] * f;
             O += s_o[wv][tid] * f;
@@ -546,15 +800,28 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
     out[i] = i < n ? a[i] : (i < 2 * n ? b[i - n] : c[i - 2 * n]);
 }
 
-template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM>
+int g_lm_attn_waves = 8;  // "lm_attn_waves": 8 = a wave owns 32 keys of the 256-key chunk (one batch of loads) | 4 = 64 keys, two batches
+int g_lm_ksliced = 1;  // "lm_ksliced": 1 = lm_gemv_ks_kernel for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 = lm_gemv_kernel
+int g_lm_balance = 1;  // "lm_balance": 1 = waves per workgroup and rows per wave chosen so that every CU gets the same number of
+                       // workgroups | 0 = 4 waves, 1 row (N <= 2048) or 2 rows per wave
+
+template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM, int NW>
 static void launch_gemv_cfg(const float *x, const float *w, const float *bias, const float *residual, const float *g,
                             const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
     const int kp = K < LM_KP ? K : LM_KP;
     const int lds = BQ * kp * 4;
-    const int rows_per_wg = 4 * ROWS;
-    if (lds > 65536) (void)set_max_dynamic_lds(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), lds);
-    hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(256),
+    const int rows_per_wg = NW * ROWS;
+    if (lds > 65536) (void)set_max_dynamic_lds(reinterpret_cast<const void *>(lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM, NW>), lds);
+    hipLaunchKernelGGL((lm_gemv_kernel<BQ, ROWS, U, ACT, LN, XM, NW>), dim3((N + rows_per_wg - 1) / rows_per_wg), dim3(NW * 64),
                        lds, stream, x, w, bias, residual, g, beta, y, N, K, mg);
+}
+
+extern long long *g_gemm_trace;
+static int g_lm_trace_launch = 0;  // launches since the trace buffer was set (omnitok_debug_set_gemm_trace resets it through lm_trace_reset)
+void lm_trace_reset() { g_lm_trace_launch = 0; }
+static long long *lm_trace_slot(int grid) {  // 8 stamps per workgroup, 1024 workgroups per launch slot, 256 slots
+    if (!g_gemm_trace || g_lm_trace_launch >= 256 || grid > 1024) return nullptr;
+    return g_gemm_trace + (int64_t)(g_lm_trace_launch++) * 1024 * 8;
 }
 
 template <int BQ, int ACT, bool LN, bool XM>
@@ -562,14 +829,60 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
                              const float *beta, float *y, int N, int K, const LmMerge &mg, hipStream_t stream) {
     // ROWS weight rows x U chunks (x2 register buffers) per wave = 8 KiB of weights in flight per wave.
     // Narrow outputs (N <= 2048: the C x C and C x 4C projections) take one row per wave so that the
-    // launch still covers every CU.  (Measured at C = 1536: 4 rows per wave for 4-8 batch rows, or a
-    // side-stream weight prefetch into the Infinity Cache, did not help: the step is bound by the ~4.5 us
-    // fixed cost of each of its 122 dependent launches, after which the kernels stream at 5-7 TB/s.)
-    // Wide outputs: 2 rows x 4 chunks x 2 buffers = 16 KiB per wave, i.e. a whole K = 1536 row pair is requested
-    // before the LayerNorm prologue finishes (the matrix streams from HBM while x is normalised).
-    if (N <= 2048) launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-    else if (g_lm_wide_u == 2) launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
-    else launch_gemv_cfg<BQ, 2, 4, ACT, LN, XM>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    // launch still covers every CU.  Wide outputs: 2 rows x 2 chunks x 2 buffers per wave, i.e. a whole K = 1536 row pair is
+    // requested before the LayerNorm prologue finishes (the matrix streams from HBM while x is normalised).
+    // Balance (r05): a decode GEMV lasts 5-10 us and every CU streams at its own ~25-30 GB/s, so the launch takes as long as the
+    // CU with the most workgroups: 384 workgroups on 256 CUs (N = 1536 at 4 rows per workgroup) run like 512.  With 6 waves per
+    // workgroup N = 1536 is exactly one workgroup per CU and N = 4608 exactly three (profiles/r05_lm_balance.txt).
+    int n_cu = 256;
+    (void)current_device_cus(&n_cu);
+    if constexpr (BQ <= 2) {
+        // K-sliced kernel: one workgroup per CU (more only when a workgroup would own more than 64 rows)
+        int mult = 1;  // workgroups per CU: 2 and 3 measured 7 % and 15 % slower per token (every workgroup repeats the prologue)
+        while (N / (n_cu * mult) > 64) ++mult;
+        while (mult > 1 && N < n_cu * mult) --mult;
+        const int grid = n_cu * mult;
+        const int max_rows = (N + grid - 1) / grid + 1;
+        if (g_lm_ksliced && N >= grid && max_rows * BQ <= 6 * 64) {
+            const int lds = max_rows * BQ * 8 * 4;
+            if (K == 6 * 256) {
+                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 1, 8 / BQ, ACT, LN, XM, 6>), dim3(grid), dim3(384), lds, stream, x, w, bias, residual, g, beta,
+                                   y, N, K, mg, lm_trace_slot(grid));
+                return;
+            }
+            if (K == 6 * 4 * 256) {
+                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 4, 2 / BQ, ACT, LN, XM, 6>), dim3(grid), dim3(384), lds, stream, x, w, bias, residual, g, beta,
+                                   y, N, K, mg, lm_trace_slot(grid));
+                return;
+            }
+            if (K == 8 * 256) {
+                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 1, 8 / BQ, ACT, LN, XM, 8>), dim3(grid), dim3(512), lds, stream, x, w, bias, residual, g, beta,
+                                   y, N, K, mg, lm_trace_slot(grid));
+                return;
+            }
+            if (K == 8 * 4 * 256) {
+                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 4, 2 / BQ, ACT, LN, XM, 8>), dim3(grid), dim3(512), lds, stream, x, w, bias, residual, g, beta,
+                                   y, N, K, mg, lm_trace_slot(grid));
+                return;
+            }
+        }
+    }
+    auto waste = [&](int rows_per_wg) {  // workgroup slots of the last round that stay empty, as a fraction of the launch
+        const int wgs = (N + rows_per_wg - 1) / rows_per_wg;
+        const int rounds = (wgs + n_cu - 1) / n_cu;
+        return (double)(rounds * n_cu - wgs) / (double)(rounds * n_cu);
+    };
+    const bool six = g_lm_balance && BQ <= 2 && K % 256 == 0;
+    if (N <= 2048) {
+        if (six && waste(6) + 0.05 < waste(4)) launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM, 6>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+        else launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM, 4>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    } else if (six && waste(6) + 0.05 < waste(8)) {
+        launch_gemv_cfg<BQ, 1, 4, ACT, LN, XM, 6>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    } else if (g_lm_wide_u == 2) {
+        launch_gemv_cfg<BQ, 2, 2, ACT, LN, XM, 4>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    } else {
+        launch_gemv_cfg<BQ, 2, 4, ACT, LN, XM, 4>(x, w, bias, residual, g, beta, y, N, K, mg, stream);
+    }
 }
 
 template <int BQ>
@@ -645,20 +958,20 @@ static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_
     const int rows = prefill_T > 0 ? B * prefill_T : B;
     OT_CHECK_ARG(rows <= 65535, "lm_attn_decode: %d query rows (max 65535)", rows);
     const dim3 grid(nchunk, n_head, rows);
+    const bool wide = g_lm_attn_waves == 8;
+#define OT_LM_ATTN(F4_)                                                                                                               \
+    if (wide)                                                                                                                        \
+        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 8>), grid, dim3(512), 0, stream, qkv, kc, vc, cache_len, n_head, max_len,    \
+                           prefill_T, scratch, nchunk, err_flag);                                                                   \
+    else                                                                                                                            \
+        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 4>), grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head, max_len,    \
+                           prefill_T, scratch, nchunk, err_flag)
     switch (head_dim) {
-        case 64:
-            hipLaunchKernelGGL(lm_attn_decode_kernel<2>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk, err_flag);
-            break;
-        case 96:
-            hipLaunchKernelGGL(lm_attn_decode_kernel<3>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk, err_flag);
-            break;
-        default:
-            hipLaunchKernelGGL(lm_attn_decode_kernel<4>, grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,
-                               max_len, prefill_T, scratch, nchunk, err_flag);
-            break;
+        case 64: OT_LM_ATTN(2); break;
+        case 96: OT_LM_ATTN(3); break;
+        default: OT_LM_ATTN(4); break;
     }
+#undef OT_LM_ATTN
     OT_LAUNCH_CHECK("lm_attn_decode");
     return OMNITOK_OK;
 }
