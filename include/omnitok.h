@@ -81,7 +81,8 @@ const char *omnitok_version(void);
  * | 0 register-blocked), "lm_wide_u"; LM decode A/B switches (include/omnitok_lm.h; profiles/r05_lm_timeline.txt): "lm_ksliced" 1
  * (default) K-sliced GEMV for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 row GEMV; "lm_balance" 1 (default) 6 waves per workgroup
  * where that makes the row GEMV's grid a whole number of workgroups per CU | 0 four; "lm_attn_waves" 8 (default) | 4 waves per
- * 256-key attention chunk; "x3_dbg" / "h2_dbg" select
+ * 256-key attention chunk; "lm_attn_short" 1 (default, read by omnitok_lm_alloc_cache) 128-key chunks for caches of up to 4096
+ * tokens | 0 always 256; "lm_ks_deep" 0 (default) 8 KiB | 1 16 KiB of weights in flight per wave of the K-sliced GEMV; "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* Reads the process default of a data-flow option ("gemm_mode", "attn_mode", "gemm_pl", "pl_min_tokens", "temporal_chunk",

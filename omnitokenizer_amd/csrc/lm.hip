@@ -28,6 +28,10 @@
 namespace omnitok {
 
 constexpr int LM_CHUNK = 256;   // keys per attention workgroup
+constexpr int LM_CHUNK_SHORT = 128;  // ... of the decode step when the cache holds at most 32 such chunks: twice the workgroups (a
+                                     // 256-key chunk is 196 KB through ONE CU: the kernel is bound by that CU's share of the bandwidth);
+                                     // 64 measured better per token on average and worse at 512 keys, where the merge in the
+                                     // projection's prologue outgrows its first round of loads
 
 // x = token_embedding + position_embedding (reference gpt.py:209-226 / 238-258): the token embedding is
 // tok_emb[idx] or an explicit vector (`embeddings=`, emb [B, C]); the position embedding is pos_emb[pos],
@@ -69,6 +73,7 @@ struct LmMerge {
     const float *part;         // [B][n_head][nchunk][2 + hd]
     const int32_t *cache_len;  // [B]
     int n_head, hd, nchunk;
+    int chunk;                 // keys per attention chunk (LM_CHUNK, or LM_CHUNK_SHORT for caches of up to 4096 tokens)
 };
 
 template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM, int NW>
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_kernel(const float *__restric
                 const float *pp = mg.part + ((int64_t)b * mg.n_head + h) * mg.nchunk * S;
                 const float M0 = pp[0], L0 = pp[1];
                 const float q00 = pp[2 + d], q01 = pp[3 + d], q02 = pp[4 + d], q03 = pp[5 + d];
-                int used = (mg.cache_len[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+                int used = (mg.cache_len[b] + 1 + mg.chunk - 1) / mg.chunk;
                 if (used > mg.nchunk) used = mg.nchunk;  // a stream stepped past max_len (flagged by the attention kernel,
                                                          // which clamps the same way): never read past this head's partials
                 float M = M0;
@@ -357,9 +362,9 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
     // ---- this wave's slice of the activations -> registers, then the weights of the first two row groups ----
     if constexpr (XM) {
         // merged attention partials (see lm_gemv_kernel): every lane merges the head its 4 columns belong to.  The partials of the
-        // first XC chunks (1024 keys) are requested before the weights, whether or not they hold keys (selected afterwards: their
+        // first XC chunks (1024 or 2048 keys) are requested before the weights, whether or not they hold keys (selected afterwards: their
         // addresses exist for every launch); only contexts beyond that take a second round of loads behind the weights.
-        constexpr int XC = 4;
+        constexpr int XC = 8;
         const int S = 2 + mg.hd;
         const float *p0[BQ][CW];  // this head's partials: [M, L, o[hd]] per chunk
         int dd[CW];
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
-            int nu = (used[b] + 1 + LM_CHUNK - 1) / LM_CHUNK;
+            int nu = (used[b] + 1 + mg.chunk - 1) / mg.chunk;
             if (nu > mg.nchunk) nu = mg.nchunk;
 #pragma unroll
             for (int cw = 0; cw < CW; ++cw) {
@@ -535,14 +540,14 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
 // clamped to the slab, the new token's row comes from qkv and is selected afterwards): q, cache_len and every K / V row of the chunk
 // are one memory round trip where the 4-wave form took three (q + length, then two batches of 32 keys) -- the kernel is a latency
 // chain at decode sizes, not a stream (profiles/r05_lm_balance.txt).
-template <int F4, int NWV>
+template <int F4, int NWV, int CHUNK>
 __global__ __launch_bounds__(NWV * 64) void lm_attn_decode_kernel(const float *__restrict__ qkv, float *kc, float *vc,
                                                                   const int32_t *__restrict__ cache_len, int n_head,
                                                                   int max_len, int prefill_T,
                                                                   float *__restrict__ part, int nchunk,
                                                                   int *__restrict__ err_flag) {
     constexpr int HD = F4 * 32;
-    constexpr int KPW = LM_CHUNK / NWV;  // keys per wave
+    constexpr int KPW = CHUNK / NWV;  // keys per wave
     static_assert(KPW % 32 == 0, "a wave takes its keys in batches of 32");
     // decode: one query row per stream (row == b), len = cache_len[b].  prefill (prefill_T > 0): row =
     // b * T + t is query position t of stream b; its keys 0..t-1 are already in the cache (scattered by
@@ -556,7 +561,7 @@ __global__ __launch_bounds__(NWV * 64) void lm_attn_decode_kernel(const float *_
     const float *kn = qn + C, *vn = qn + 2 * C;
     float *krow = kc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
     float *vrow = vc + ((int64_t)b * n_head + h) * (int64_t)max_len * HD;
-    const int kbase = c * LM_CHUNK + wave * KPW;
+    const int kbase = c * CHUNK + wave * KPW;
     // everything this lane will read, requested at once
     f32x4 q[F4], knv[F4], vnv[F4];
 #pragma unroll
@@ -587,9 +592,9 @@ __global__ __launch_bounds__(NWV * 64) void lm_attn_decode_kernel(const float *_
         len = max_len - 1;
     }
     const int total = len + 1;
-    if (c * LM_CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
+    if (c * CHUNK >= total) return;   // chunk beyond the sequence (static launch grid)
     // append the new token's K/V (only the workgroup whose chunk holds index len)
-    if (prefill_T == 0 && len >= c * LM_CHUNK && len < (c + 1) * LM_CHUNK && len < max_len) {
+    if (prefill_T == 0 && len >= c * CHUNK && len < (c + 1) * CHUNK && len < max_len) {
         for (int d = tid; d < HD; d += NWV * 64) {
             krow[(int64_t)len * HD + d] = kn[d];
             vrow[(int64_t)len * HD + d] = vn[d];
@@ -683,11 +688,11 @@ __global__ __launch_bounds__(NWV * 64) void lm_attn_decode_kernel(const float *_
 }
 
 __global__ void lm_attn_merge_kernel(const float *__restrict__ part, const int32_t *__restrict__ cache_len, int n_head,
-                                     int HD, int nchunk, int prefill_T, float *__restrict__ out) {
+                                     int HD, int nchunk, int prefill_T, float *__restrict__ out, int chunk) {
     const int h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;  // b: query row
     if (d >= HD) return;
     const int total = (prefill_T > 0 ? b % prefill_T : cache_len[b]) + 1;
-    const int used = (total + LM_CHUNK - 1) / LM_CHUNK;
+    const int used = (total + chunk - 1) / chunk;
     const float *pp = part + ((int64_t)b * n_head + h) * nchunk * (2 + HD);
     float M = -INFINITY;
     for (int c = 0; c < used; ++c) M = fmaxf(M, pp[c * (2 + HD)]);
@@ -801,6 +806,8 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
 }
 
 int g_lm_attn_waves = 8;  // "lm_attn_waves": 8 = a wave owns 32 keys of the 256-key chunk (one batch of loads) | 4 = 64 keys, two batches
+int g_lm_attn_short = 1;  // "lm_attn_short": 1 = 128-key attention chunks for caches of up to 4096 tokens (read at omnitok_lm_alloc_cache) | 0 = 256
+int g_lm_ks_deep = 0;   // "lm_ks_deep": weights in flight per wave of the K-sliced GEMV: 1 = 16 KiB | 0 = 8 KiB
 int g_lm_ksliced = 1;  // "lm_ksliced": 1 = lm_gemv_ks_kernel for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 = lm_gemv_kernel
 int g_lm_balance = 1;  // "lm_balance": 1 = waves per workgroup and rows per wave chosen so that every CU gets the same number of
                        // workgroups | 0 = 4 waves, 1 row (N <= 2048) or 2 rows per wave
@@ -845,26 +852,32 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
         const int max_rows = (N + grid - 1) / grid + 1;
         if (g_lm_ksliced && N >= grid && max_rows * BQ <= 6 * 64) {
             const int lds = max_rows * BQ * 8 * 4;
+#define OT_KS(CW_, RG_, NW_)                                                                                                         \
+    hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, CW_, RG_, ACT, LN, XM, NW_>), dim3(grid), dim3(NW_ * 64), lds, stream, x, w, bias, residual, g, \
+                       beta, y, N, K, mg, lm_trace_slot(grid))
+            const bool deep = g_lm_ks_deep != 0;  // rows per group: 2 groups in flight per wave = 16 KiB (deep) or 8 KiB
             if (K == 6 * 256) {
-                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 1, 8 / BQ, ACT, LN, XM, 6>), dim3(grid), dim3(384), lds, stream, x, w, bias, residual, g, beta,
-                                   y, N, K, mg, lm_trace_slot(grid));
+                if (g_lm_ks_deep == 2) OT_KS(1, 2, 6);
+                else if (deep) OT_KS(1, 8 / BQ, 6);
+                else OT_KS(1, 4 / BQ, 6);
                 return;
             }
             if (K == 6 * 4 * 256) {
-                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 4, 2 / BQ, ACT, LN, XM, 6>), dim3(grid), dim3(384), lds, stream, x, w, bias, residual, g, beta,
-                                   y, N, K, mg, lm_trace_slot(grid));
+                if (deep) OT_KS(4, 2 / BQ, 6);
+                else OT_KS(4, 1, 6);
                 return;
             }
             if (K == 8 * 256) {
-                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 1, 8 / BQ, ACT, LN, XM, 8>), dim3(grid), dim3(512), lds, stream, x, w, bias, residual, g, beta,
-                                   y, N, K, mg, lm_trace_slot(grid));
+                if (deep) OT_KS(1, 8 / BQ, 8);
+                else OT_KS(1, 4 / BQ, 8);
                 return;
             }
             if (K == 8 * 4 * 256) {
-                hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, 4, 2 / BQ, ACT, LN, XM, 8>), dim3(grid), dim3(512), lds, stream, x, w, bias, residual, g, beta,
-                                   y, N, K, mg, lm_trace_slot(grid));
+                if (deep) OT_KS(4, 2 / BQ, 8);
+                else OT_KS(4, 1, 8);
                 return;
             }
+#undef OT_KS
         }
     }
     auto waste = [&](int rows_per_wg) {  // workgroup slots of the last round that stay empty, as a fraction of the launch
@@ -888,7 +901,7 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
 template <int BQ>
 static void launch_gemv_bq(const float *x, const float *w, const float *bias, const float *residual, const float *g,
                            const float *beta, float *y, int N, int K, int act, const LmMerge *mg, hipStream_t stream) {
-    const LmMerge none{nullptr, nullptr, 0, 0, 0};
+    const LmMerge none{nullptr, nullptr, 0, 0, 0, LM_CHUNK};
     if (mg) {
         launch_gemv_rows<BQ, 0, false, true>(x, w, bias, residual, g, beta, y, N, K, *mg, stream);
     } else if (g) {
@@ -909,7 +922,7 @@ static int lm_gemv_any(const float *x, const float *w, const float *bias, const 
         const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
         const float *xb = x ? x + (int64_t)b0 * K : nullptr, *rb = residual ? residual + (int64_t)b0 * N : nullptr;
         float *yb = y + (int64_t)b0 * N;
-        LmMerge m2{nullptr, nullptr, 0, 0, 0};
+        LmMerge m2{nullptr, nullptr, 0, 0, 0, LM_CHUNK};
         if (mg) {
             m2 = *mg;
             m2.part += (int64_t)b0 * mg->n_head * mg->nchunk * (2 + mg->hd);
@@ -949,22 +962,25 @@ extern "C" int omnitok_lm_gemv(const float *x, const float *w, const float *bias
 // prefill_T > 0: B * prefill_T query rows (row = b * T + t, keys 0..t), chunks sized for T keys
 static int lm_attn_partials(const float *qkv, float *kc, float *vc, const int32_t *cache_len, int B, int n_head,
                             int head_dim, int max_len, float *scratch, hipStream_t stream, int prefill_T = 0,
-                            int *err_flag = nullptr) {
+                            int *err_flag = nullptr, int chunk = LM_CHUNK) {
     OT_CHECK_ARG(qkv && kc && vc && (cache_len || prefill_T > 0) && scratch, "lm_attn_decode: null pointer");
     OT_CHECK_ARG(head_dim == 64 || head_dim == 96 || head_dim == 128, "lm_attn_decode: head_dim %d (64 | 96 | 128)",
                  head_dim);
     OT_CHECK_ARG(max_len > 0 && n_head > 0, "lm_attn_decode: bad sizes");
-    const int nchunk = ((prefill_T > 0 ? prefill_T : max_len) + LM_CHUNK - 1) / LM_CHUNK;
+    const int nchunk = ((prefill_T > 0 ? prefill_T : max_len) + chunk - 1) / chunk;
     const int rows = prefill_T > 0 ? B * prefill_T : B;
     OT_CHECK_ARG(rows <= 65535, "lm_attn_decode: %d query rows (max 65535)", rows);
     const dim3 grid(nchunk, n_head, rows);
     const bool wide = g_lm_attn_waves == 8;
-#define OT_LM_ATTN(F4_)                                                                                                               \
-    if (wide)                                                                                                                        \
-        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 8>), grid, dim3(512), 0, stream, qkv, kc, vc, cache_len, n_head, max_len,    \
-                           prefill_T, scratch, nchunk, err_flag);                                                                   \
-    else                                                                                                                            \
-        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 4>), grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head, max_len,    \
+#define OT_LM_ATTN(F4_)                                                                                                                    \
+    if (chunk == LM_CHUNK_SHORT)                                                                                                          \
+        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 4, LM_CHUNK_SHORT>), grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head,  \
+                           max_len, prefill_T, scratch, nchunk, err_flag);                                                               \
+    else if (wide)                                                                                                                        \
+        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 8, LM_CHUNK>), grid, dim3(512), 0, stream, qkv, kc, vc, cache_len, n_head, max_len, \
+                           prefill_T, scratch, nchunk, err_flag);                                                                        \
+    else                                                                                                                                  \
+        hipLaunchKernelGGL((lm_attn_decode_kernel<F4_, 4, LM_CHUNK>), grid, dim3(256), 0, stream, qkv, kc, vc, cache_len, n_head, max_len, \
                            prefill_T, scratch, nchunk, err_flag)
     switch (head_dim) {
         case 64: OT_LM_ATTN(2); break;
@@ -985,7 +1001,7 @@ extern "C" int omnitok_lm_attn_decode(const float *qkv, float *kc, float *vc, co
     if (int rc = lm_attn_partials(qkv, kc, vc, cache_len, B, n_head, head_dim, max_len, scratch, stream)) return rc;
     const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
     hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(n_head, B), dim3(128), 0, stream, scratch, cache_len, n_head, head_dim,
-                       nchunk, 0, out);
+                       nchunk, 0, out, LM_CHUNK);
     OT_LAUNCH_CHECK("lm_attn_merge");
     return OMNITOK_OK;
 }
@@ -1009,6 +1025,7 @@ struct omnitok_lm {
     // cache + workspaces
     float *kv = nullptr;
     int max_batch = 0, max_len = 0;
+    int chunk = LM_CHUNK;  // keys per attention chunk of the decode step (omnitok_lm_alloc_cache)
     int *err_flag = nullptr;  // set by the attention kernel when a stream steps past max_len
     float *x = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr, *part = nullptr;
     int64_t cache_bytes = 0;
@@ -1174,7 +1191,8 @@ extern "C" int omnitok_lm_alloc_cache(omnitok_lm *lm, int max_batch, int max_len
     const int64_t C = c.n_embd;
     const int hd = c.n_embd / c.n_head;
     const int64_t per_layer = (int64_t)max_batch * c.n_head * max_len * hd;  // floats per K (or V)
-    const int nchunk = (max_len + LM_CHUNK - 1) / LM_CHUNK;
+    lm->chunk = g_lm_attn_short && max_len <= LM_CHUNK_SHORT * LM_MAX_CHUNKS ? LM_CHUNK_SHORT : LM_CHUNK;
+    const int nchunk = (max_len + lm->chunk - 1) / lm->chunk;
     auto alloc = [](float **p, int64_t n) { return hipMalloc(reinterpret_cast<void **>(p), (size_t)n * 4); };
     OT_HIP(alloc(&lm->kv, per_layer * 2 * c.n_layer));
     OT_HIP(alloc(&lm->x, max_batch * C));
@@ -1239,9 +1257,9 @@ extern "C" int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const floa
         if (int rc = omnitok_lm_gemv(lm->x, L.wqkv, L.bqkv, nullptr, L.ln1w, L.ln1b, lm->qkv, B, 3 * C, C, 0, stream))
             return rc;
         if (int rc = lm_attn_partials(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, stream, 0,
-                                      lm->err_flag))
+                                      lm->err_flag, lm->chunk))
             return rc;
-        const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + LM_CHUNK - 1) / LM_CHUNK};
+        const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + lm->chunk - 1) / lm->chunk, lm->chunk};
         if (int rc = lm_gemv_any(nullptr, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, &mg, stream))
             return rc;
         // x + mlp(ln2(x))          (reference gpt.py:162, 150-155)
@@ -1319,7 +1337,7 @@ extern "C" int omnitok_lm_prefill_ex(omnitok_lm *lm, const int64_t *idx, int T_t
         OT_LAUNCH_CHECK("lm_kv_scatter");
         if (int rc = lm_attn_partials(qkv, kc, vc, nullptr, B, c.n_head, hd, lm->max_len, part, stream, T)) return rc;
         hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(c.n_head, (unsigned)M), dim3(128), 0, stream, part, nullptr,
-                           c.n_head, hd, nchunk, T, att);
+                           c.n_head, hd, nchunk, T, att, LM_CHUNK);
         OT_LAUNCH_CHECK("lm_attn_merge");
         if (int rc = omnitok_gemm(att, C, L.wproj, C, L.bproj, x, C, x, C, M, C, C, BR, 0, 0, 0, stream)) return rc;
         hipLaunchKernelGGL(lm_layernorm_rows_kernel, ln_grid, dim3(256), 0, stream, x, L.ln2w, L.ln2b, xn, M, C);
