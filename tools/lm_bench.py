@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT", help="omnitok_set_option switch (A/B)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the 8-stream line (B = 1 runs only)")
     a = ap.parse_args()
     V, BS, L, H, C = a.vocab, a.block, a.layers, a.heads, a.embd
     for kv in a.option:
@@ -100,6 +101,18 @@ def main():
             out_json["roofline"]["traffic_source"] = pmc["source"]
     except Exception:
         pass
+    if B == 1 and not a.no_also:
+        # the same model with 8 streams sampled together (one pass over the weights per step serves all of them)
+        B8, n8 = 8, min(a.steps, 128)
+        cond8 = torch.randint(0, V, (B8, 1 + a.ctx), generator=g).cuda()
+        og.sample_with_past(cond8, m, 8, top_k=2048, top_p=0.9, use_graph=not a.no_graph)
+        torch.cuda.synchronize()
+        t8 = time.perf_counter()
+        og.sample_with_past(cond8, m, n8, top_k=2048, top_p=0.9, use_graph=not a.no_graph)
+        torch.cuda.synchronize()
+        dt8 = time.perf_counter() - t8
+        out_json["also"] = {"b8": {"batch_streams": B8, "steps": n8, "tokens_s": round(B8 * n8 / dt8, 1),
+                                   "ms_per_token_step": round(dt8 / n8 * 1e3, 4)}}
     if not a.no_cpu_baseline:
         from oracle import gpt_oracle as go  # the CPU oracle is only the baseline / checker here
         torch.set_num_threads(min(32, os.cpu_count() or 1))
