@@ -324,6 +324,49 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_kernel(const float *__restric
 //     be pending" and waits for vmcnt(0), i.e. for every weight in flight.  Short row groups clamp their row index instead (the
 //     duplicate requests are L2 hits), bias / residual are loaded by every thread from a clamped index;
 //   * the barriers order LDS only (lds_barrier): __syncthreads() drains vmcnt as well.
+// Sums N = 2^k values over the 64 lanes of a wave in N - 1 + (6 - k) exchanges instead of 6 N: every halving step keeps half of the
+// values (which half: one bit of the lane index, from bit 5 down) and adds the partner lane's copy of the kept half.  On return a[0] of
+// lane l is the wave total of value (l >> (6 - k)); lanes with equal (l >> (6 - k)) hold the same total.
+// partner lane's value for exchange distance S: DPP inside a row of 16 (S <= 8; S = 4 pairs lane j with j ^ 7, which differs in bit 2 --
+// all a halving step needs), the LDS crossbar across rows
+template <int S>
+__device__ __forceinline__ float wave_xchg(float v) {
+    if constexpr (S == 1) return dpp_f32<0xB1>(v);        // quad_perm [1, 0, 3, 2]
+    else if constexpr (S == 2) return dpp_f32<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    else if constexpr (S == 4) return dpp_f32<0x141>(v);  // row_half_mirror
+    else if constexpr (S == 8) return dpp_f32<0x128>(v);  // row_ror:8
+    else return __shfl_xor(v, S);
+}
+template <int N, int S>
+__device__ __forceinline__ void wave_transpose_step(float (&a)[N], int lane, int n) {  // n live values -> n / 2
+    const bool up = (lane & S) != 0;
+    const int half = n >> 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        if (i < half) {
+            const float keep = up ? a[i + half] : a[i], send = up ? a[i] : a[i + half];
+            a[i] = keep + wave_xchg<S>(send);
+        }
+    }
+}
+template <int N>
+__device__ __forceinline__ void wave_transpose_sum(float (&a)[N], int lane) {
+    static_assert(N >= 1 && N <= 64 && (N & (N - 1)) == 0, "power of two");
+    if constexpr (N >= 2) wave_transpose_step<N, 32>(a, lane, N);
+    if constexpr (N >= 4) wave_transpose_step<N, 16>(a, lane, N / 2);
+    if constexpr (N >= 8) wave_transpose_step<N, 8>(a, lane, N / 4);
+    if constexpr (N >= 16) wave_transpose_step<N, 4>(a, lane, N / 8);
+    if constexpr (N >= 32) wave_transpose_step<N, 2>(a, lane, N / 16);
+    if constexpr (N >= 64) wave_transpose_step<N, 1>(a, lane, N / 32);
+    // the 64 / N lanes that now hold partial sums of the same value: plain all-reduce (any pairing)
+    if constexpr (N <= 32) a[0] += wave_xchg<1>(a[0]);
+    if constexpr (N <= 16) a[0] += wave_xchg<2>(a[0]);
+    if constexpr (N <= 8) a[0] += wave_xchg<4>(a[0]);
+    if constexpr (N <= 4) a[0] += wave_xchg<8>(a[0]);
+    if constexpr (N <= 2) a[0] += wave_xchg<16>(a[0]);
+    if constexpr (N <= 1) a[0] += wave_xchg<32>(a[0]);
+}
+
 #ifndef LM_TRACE
 #define LM_TRACE 0  // 1: s_memrealtime stamps per workgroup (tools/r05/lm_timeline.py; build with OMNITOK_EXTRA_FLAGS=-DLM_TRACE=1)
 #endif
@@ -364,7 +407,7 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
         // merged attention partials (see lm_gemv_kernel): every lane merges the head its 4 columns belong to.  The partials of the
         // first XC chunks (1024 or 2048 keys) are requested before the weights, whether or not they hold keys (selected afterwards: their
         // addresses exist for every launch); only contexts beyond that take a second round of loads behind the weights.
-        constexpr int XC = 8;
+        constexpr int XC = BQ <= 2 ? 8 : 2;  // (registers: 6 per chunk, stream and column group)
         const int S = 2 + mg.hd;
         const float *p0[BQ][CW];  // this head's partials: [M, L, o[hd]] per chunk
         int dd[CW];
@@ -439,8 +482,9 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
         }
     } else {
         f32x4 g4[CW], b4[CW];
-        f32x4 xf[LN ? BQ : 1][LN ? NW * CW : 1];  // LN: the whole row, for the statistics
-        if constexpr (LN) {
+        constexpr bool WAVE_LN = LN && BQ * NW * CW <= 16;  // statistics per wave over the whole row (while it fits registers) | LDS partials
+        f32x4 xf[WAVE_LN ? BQ : 1][WAVE_LN ? NW * CW : 1];
+        if constexpr (WAVE_LN) {
 #pragma unroll
             for (int b = 0; b < BQ; ++b)
 #pragma unroll
@@ -461,10 +505,9 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
         e_bias = *bias_p;
         e_res = *res_p;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (LN) {
+        if constexpr (WAVE_LN) {
             // nn.LayerNorm, two-pass like ATen.  Every wave reduces the WHOLE row itself (xf: NW * CW float4 per lane, L2 hits for all but
-            // the first wave to ask) instead of exchanging wave partials through LDS: two workgroup barriers, each waiting for the
-            // wave whose slice arrived last, cost 2 us of an 8 us launch (profiles/r05_lm_timeline.txt)
+            // the first wave to ask) instead of exchanging wave partials through LDS (no workgroup barrier in the prologue)
 #pragma unroll
             for (int b = 0; b < BQ; ++b) {
                 f32x4 t = xf[b][0];
@@ -483,12 +526,55 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
 #pragma unroll
                     for (int e = 0; e < 4; ++e) xr[b][cw][e] = (xr[b][cw][e] - mean) * rstd * g4[cw][e] + b4[cw][e];
             }
+        } else if constexpr (LN) {
+            // more streams than whole rows fit the registers of: wave sums of the slices -> LDS -> every thread adds the NW partials
+            __shared__ float s_red[2][BQ][NW];
+            float part[BQ];
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                f32x4 t = xr[b][0];
+#pragma unroll
+                for (int cw = 1; cw < CW; ++cw) t = t + xr[b][cw];
+                part[b] = (t[0] + t[1]) + (t[2] + t[3]);
+            }
+            wave_transpose_sum<BQ>(part, lane);
+            if ((lane & (64 / BQ - 1)) == 0) s_red[0][lane / (64 / BQ)][wave] = part[0];
+            lds_barrier();
+            float mean[BQ];
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8) tot += s_red[0][b][w8];
+                mean[b] = tot / (float)K;
+                float q = 0.0f;
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw) {
+                    const f32x4 a = xr[b][cw] - mean[b];
+                    q += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+                }
+                part[b] = q;
+            }
+            wave_transpose_sum<BQ>(part, lane);
+            if ((lane & (64 / BQ - 1)) == 0) s_red[1][lane / (64 / BQ)][wave] = part[0];
+            lds_barrier();
+#pragma unroll
+            for (int b = 0; b < BQ; ++b) {
+                float tot = 0.0f;
+#pragma unroll
+                for (int w8 = 0; w8 < NW; ++w8) tot += s_red[1][b][w8];
+                const float rstd = 1.0f / sqrtf(tot / (float)K + 1e-5f);
+#pragma unroll
+                for (int cw = 0; cw < CW; ++cw)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) xr[b][cw][e] = (xr[b][cw][e] - mean[b]) * rstd * g4[cw][e] + b4[cw][e];
+            }
         }
     }
     stamp(1);
     // ---- rows, RG at a time, two groups of weights in flight ----
     auto consume = [&](const f32x4 (&wv)[RG][CW], int grp) {
-        float acc[RG][BQ];
+        float acc[RG * BQ];
 #pragma unroll
         for (int r = 0; r < RG; ++r)
 #pragma unroll
@@ -501,15 +587,12 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
                     a = fmaf(wv[r][cw][2], xr[b][cw][2], a);
                     a = fmaf(wv[r][cw][3], xr[b][cw][3], a);
                 }
-                acc[r][b] = wave_allsum(a);
+                acc[r * BQ + b] = a;
             }
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < RG; ++r)
-                if (grp * RG + r < nrows)
-#pragma unroll
-                    for (int b = 0; b < BQ; ++b) ks_part[((grp * RG + r) * BQ + b) * NW + wave] = acc[r][b];
-        }
+        wave_transpose_sum<RG * BQ>(acc, lane);  // lane l: the wave's sum for (row, stream) number l / (64 / (RG BQ))
+        constexpr int LPV = 64 / (RG * BQ);      // lanes per value
+        const int id = lane / LPV, r = id / BQ;
+        if ((lane & (LPV - 1)) == 0 && grp * RG + r < nrows) ks_part[((grp * RG) * BQ + id) * NW + wave] = acc[0];
     };
     for (int grp = 0; grp < ngroups; grp += 2) {
         consume(wa, grp);
@@ -808,7 +891,7 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
 int g_lm_attn_waves = 8;  // "lm_attn_waves": 8 = a wave owns 32 keys of the 256-key chunk (one batch of loads) | 4 = 64 keys, two batches
 int g_lm_attn_short = 1;  // "lm_attn_short": 1 = 128-key attention chunks for caches of up to 4096 tokens (read at omnitok_lm_alloc_cache) | 0 = 256
 int g_lm_ks_deep = 0;   // "lm_ks_deep": weights in flight per wave of the K-sliced GEMV: 1 = 16 KiB | 0 = 8 KiB
-int g_lm_ksliced = 1;  // "lm_ksliced": 1 = lm_gemv_ks_kernel for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 = lm_gemv_kernel
+int g_lm_ksliced = 2;  // "lm_ksliced": 2 = lm_gemv_ks_kernel for K in {1536, 2048, 6144, 8192} | 1 = only for B <= 2 | 0 = lm_gemv_kernel
 int g_lm_balance = 1;  // "lm_balance": 1 = waves per workgroup and rows per wave chosen so that every CU gets the same number of
                        // workgroups | 0 = 4 waves, 1 row (N <= 2048) or 2 rows per wave
 
@@ -843,38 +926,41 @@ static void launch_gemv_rows(const float *x, const float *w, const float *bias, 
     // workgroup N = 1536 is exactly one workgroup per CU and N = 4608 exactly three (profiles/r05_lm_balance.txt).
     int n_cu = 256;
     (void)current_device_cus(&n_cu);
-    if constexpr (BQ <= 2) {
-        // K-sliced kernel: one workgroup per CU (more only when a workgroup would own more than 64 rows)
+    if (BQ <= 2 ? g_lm_ksliced >= 1 : g_lm_ksliced >= 2) {
+        // K-sliced kernel: one workgroup per CU (more only when a workgroup would own more than 64 rows or 384 outputs)
         int mult = 1;  // workgroups per CU: 2 and 3 measured 7 % and 15 % slower per token (every workgroup repeats the prologue)
-        while (N / (n_cu * mult) > 64) ++mult;
+        while (N / (n_cu * mult) > 64 / (BQ > 4 ? 2 : 1)) ++mult;
         while (mult > 1 && N < n_cu * mult) --mult;
         const int grid = n_cu * mult;
         const int max_rows = (N + grid - 1) / grid + 1;
-        if (g_lm_ksliced && N >= grid && max_rows * BQ <= 6 * 64) {
+        if (N >= grid && max_rows * BQ <= 6 * 64) {
             const int lds = max_rows * BQ * 8 * 4;
 #define OT_KS(CW_, RG_, NW_)                                                                                                         \
     hipLaunchKernelGGL((lm_gemv_ks_kernel<BQ, CW_, RG_, ACT, LN, XM, NW_>), dim3(grid), dim3(NW_ * 64), lds, stream, x, w, bias, residual, g, \
                        beta, y, N, K, mg, lm_trace_slot(grid))
-            const bool deep = g_lm_ks_deep != 0;  // rows per group: 2 groups in flight per wave = 16 KiB (deep) or 8 KiB
+            // rows per group: 2 groups in flight per wave = 8 KiB ("lm_ks_deep" 1: 16 KiB, measured slower: profiles/r05_lm_timeline.txt)
+            constexpr int DEEP = BQ <= 2 ? 2 : 1;  // (the deep variants exist for B <= 2 only)
+            const bool deep = g_lm_ks_deep == 1 && BQ <= 2;
             if (K == 6 * 256) {
-                if (g_lm_ks_deep == 2) OT_KS(1, 2, 6);
-                else if (deep) OT_KS(1, 8 / BQ, 6);
-                else OT_KS(1, 4 / BQ, 6);
+                if (deep) OT_KS(1, 4 * DEEP, 6);
+                else OT_KS(1, 4, 6);
                 return;
             }
-            if (K == 6 * 4 * 256) {
-                if (deep) OT_KS(4, 2 / BQ, 6);
-                else OT_KS(4, 1, 6);
-                return;
+            if constexpr (!XM) {  // (the attention merge only feeds the C x C projection)
+                if (K == 6 * 4 * 256) {
+                    if (deep) OT_KS(4, DEEP, 6);
+                    else OT_KS(4, 1, 6);
+                    return;
+                }
+                if (K == 8 * 4 * 256) {
+                    if (deep) OT_KS(4, DEEP, 8);
+                    else OT_KS(4, 1, 8);
+                    return;
+                }
             }
             if (K == 8 * 256) {
-                if (deep) OT_KS(1, 8 / BQ, 8);
-                else OT_KS(1, 4 / BQ, 8);
-                return;
-            }
-            if (K == 8 * 4 * 256) {
-                if (deep) OT_KS(4, 2 / BQ, 8);
-                else OT_KS(4, 1, 8);
+                if (deep) OT_KS(1, 4 * DEEP, 8);
+                else OT_KS(1, 4, 8);
                 return;
             }
 #undef OT_KS

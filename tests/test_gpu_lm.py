@@ -34,8 +34,9 @@ def lib():
 @pytest.mark.parametrize("N,K", [(1536, 1536), (4608, 1536), (6144, 1536), (1536, 6144), (8192, 1536), (300, 256), (8193, 768),
                                  (2048, 2048), (1000, 8192), (20000, 1536)])
 def test_gemv(lib, B, N, K):
-    """Every GEMV form against torch: B <= 2 with K in {1536, 2048, 6144, 8192} runs the K-sliced kernel (6 or 8 waves, one workgroup
-    per CU, ragged row split for N = 1000, more than one workgroup per CU for N = 20000), everything else the 4- or 6-wave row kernel."""
+    """Every GEMV form against torch: K in {1536, 2048, 6144, 8192} runs the K-sliced kernel for every group of 8 / 4 / 2 / 1 streams
+    (6 or 8 waves, one workgroup per CU, ragged row split for N = 1000, more than one workgroup per CU for N = 20000), everything
+    else the 4- or 6-wave row kernel."""
     x, w, bias, res = rnd(B, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(N, seed=3), rnd(B, N, seed=4)
     g, beta = rnd(K, seed=5, scale=0.1) + 1.0, rnd(K, seed=6, scale=0.1)
     s = torch.cuda.current_stream().cuda_stream
@@ -83,9 +84,9 @@ def test_attn_decode(lib, hd):
             assert torch.equal(kc[b, :, :ln], kc0[b, :, :ln]) and torch.equal(kc[b, :, ln + 1:], kc0[b, :, ln + 1:])
 
 
-@pytest.mark.parametrize("B,N,K", [(1, 4608, 1536), (2, 1536, 6144), (1, 8192, 1536)])
+@pytest.mark.parametrize("B,N,K", [(1, 4608, 1536), (2, 1536, 6144), (1, 8192, 1536), (8, 6144, 1536), (4, 1536, 6144), (8, 1536, 1536)])
 def test_gemv_forms_agree(lib, B, N, K):
-    """The K-sliced kernel ("lm_ksliced" 1, the default for B <= 2) against the row kernel it replaces there: same LayerNorm + GELU +
+    """The K-sliced kernel ("lm_ksliced" 2, the default) against the row kernel it replaces: same LayerNorm + GELU +
     residual outputs to rounding (the dot products are summed in a different order)."""
     from omnitokenizer_amd import _lib
     x, w, bias, res = rnd(B, K, seed=1).cuda(), rnd(N, K, seed=2, scale=0.05).cuda(), rnd(N, seed=3).cuda(), rnd(B, N, seed=4).cuda()
@@ -93,15 +94,15 @@ def test_gemv_forms_agree(lib, B, N, K):
     s = torch.cuda.current_stream().cuda_stream
     out = {}
     try:
-        for form in (1, 0):
+        for form in (2, 0):
             _lib.set_option("lm_ksliced", form)
             y = torch.empty(B, N, device="cuda")
             assert lib.omnitok_lm_gemv(_p(x), _p(w), _p(bias), _p(res), _p(g), _p(beta), _p(y), B, N, K, 1, s) == 0
             out[form] = y
     finally:
-        _lib.set_option("lm_ksliced", 1)
-    assert not torch.equal(out[0], out[1])  # the option is live
-    assert float((out[0] - out[1]).abs().max()) < 1e-5 * math.sqrt(K / 1536)
+        _lib.set_option("lm_ksliced", 2)
+    assert not torch.equal(out[0], out[2])  # the option is live
+    assert float((out[0] - out[2]).abs().max()) < 1e-5 * math.sqrt(K / 1536)
 
 
 @pytest.fixture(scope="module")
