@@ -398,16 +398,38 @@ def run(a):
                                              + ("the unmodified reference (oracle/ref_harness.py)" if ref_model is not None
                                                 else "torch CPU fp32 oracle port")
                                              + f" (ATen/MKL, {ncpu_used} threads = best of a 8..128 probe)"}
-            g_ids, g_z = model.encode(x[:1].contiguous(), is_image, return_latents=True)
-            g_rec = model.decode(ids_ref.cuda(), is_image).cpu()
-            out["parity"] = {"id_flips_vs_oracle": int((g_ids.cpu() != ids_ref).sum()), "ids": int(ids_ref.numel()),
-                             "z_max_abs_err": float((g_z.cpu() - taps["z"]).abs().max()),
+            # Parity of the TIMED work: the ids are the timed batch's own (last timed step, all B clips in one call = the data
+            # flow and tile schedule that was timed), the latents / pixels of clip 0 come out of a full-batch encode / decode.
+            # The oracle encodes every clip of the batch (a few clips per call to bound host memory): flips_all_clips.
+            with torch.no_grad():
+                ids_ref_all = [ids_ref]
+                t_or = time.perf_counter()
+                for c0 in range(1, B, 4):
+                    ids_ref_all.append(orc.encode(sd, x[c0:c0 + 4].cpu(), is_image, cfg))
+                ids_ref_all = torch.cat(ids_ref_all, 0)
+                t_or = time.perf_counter() - t_or
+            g_ids_all, g_z = model.encode(x, is_image, return_latents=True)
+            assert torch.equal(g_ids_all, ids), "encode() of the timed batch is not deterministic"
+            g_rec = model.decode(ids_ref_all.cuda(), is_image)[:1].cpu()
+            flips_by_clip = (g_ids_all.cpu() != ids_ref_all).flatten(1).sum(1)
+            L_call = int(ids.numel())
+            pl_min = _lib.get_option("pl_min_tokens")
+            out["parity"] = {"flow": "planes" if (_lib.get_option("gemm_pl") and L_call >= pl_min and a.gemm_mode == 2) else
+                                     ("fp32 activations" if a.gemm_mode == 2 else GEMM_MODES[a.gemm_mode][0]),
+                             "tokens_per_call": L_call,
+                             "source": "ids of the timed batch (last timed step); z / pixels of clip 0 from full-batch encode / decode",
+                             "flips_all_clips": int(flips_by_clip.sum()), "ids_all_clips": int(ids_ref_all.numel()),
+                             "clips_with_flips": int((flips_by_clip > 0).sum()),
+                             "id_flips_vs_oracle": int(flips_by_clip[0]), "ids": int(ids_ref.numel()),
+                             "z_max_abs_err": float((g_z[:1].cpu().reshape(taps["z"].shape) - taps["z"]).abs().max()),
                              "pixel_max_abs_err": float((g_rec - rec_ref).abs().max()),
                              "psnr_vs_ref_db": round(orc.psnr(g_rec, rec_ref), 2),
-                             "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2)}
+                             "psnr_vs_input_db": round(orc.psnr(g_rec, xs), 2),
+                             "oracle_encode_all_clips_s": round(t_or, 1)}
+            parity_ref_ids = ids_ref_all
         # ---- driver-observed extras of the default C3 line ------------------------------
         if world == 1 and wl_name == "C3" and B == 32 and a.gemm_mode == 2 and not a.option and not a.no_also:
-            out["also"] = also_extras(model, x, sd, a)
+            out["also"] = also_extras(model, x, sd, a, locals().get("parity_ref_ids"))
         print(json.dumps(out), flush=True)
     launch.finish(info, native_timed=bool(a.native_gather))
 
@@ -425,7 +447,7 @@ def _time_steps(model, x, is_image, steps, warmup=1):
     return (time.perf_counter() - t) / steps * 1e3, ids
 
 
-def also_extras(model, x, sd, a):
+def also_extras(model, x, sd, a, ids_ref_all=None):
     """Short extra measurements put on the default line so that they are driver-observed, each a few steps and none inside
     the timed region: the other two single-GPU BASELINE configurations (C2 images, C5-shape long clip), the same C3 step
     in strict fp32 arithmetic (fp32-input MFMA GEMMs and attention: `gemm_mode` 0 / `attn_mode` 0), and the default
@@ -438,11 +460,13 @@ def also_extras(model, x, sd, a):
         # C3 in strict fp32: per-engine options, restored afterwards
         model.set_option("gemm_mode", 0)
         model.set_option("attn_mode", 0)
-        ms, _ = _time_steps(model, x, False, steps=2, warmup=1)
+        ms, ids_strict = _time_steps(model, x, False, steps=2, warmup=1)
         model.set_option("gemm_mode", -1)
         model.set_option("attn_mode", -1)
         also["strict_fp32"] = {"gemm_mode": 0, "attn_mode": 0, "ms_per_step": round(ms, 3),
                                "patches_s": round(x.shape[0] * 5120 / ms * 1e3, 1),
+                               "flips_all_clips": (int((ids_strict.cpu() != ids_ref_all).sum()) if ids_ref_all is not None else None),
+                               "ids_all_clips": int(ids_strict.numel()),
                                "note": "same C3 batch, fp32-input MFMA GEMMs and attention (the reference's arithmetic class); 2 steps"}
     except Exception as e:  # noqa: BLE001
         also["strict_fp32"] = {"error": repr(e)}

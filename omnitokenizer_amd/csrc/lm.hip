@@ -394,7 +394,9 @@ __global__ __launch_bounds__(NW * 64) void lm_gemv_ks_kernel(const float *__rest
         for (int r = 0; r < RG; ++r)
 #pragma unroll
             for (int cw = 0; cw < CW; ++cw)
-                dst[r][cw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_vo, ((grp * RG + r) * K + cw * 256) * 4, 2));
+                // the row offset rides in the VECTOR offset: that operand (+ the instruction offset) is what the descriptor's range
+                // check covers on every generation; an soffset is documented as outside it on some
+                dst[r][cw] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, w_vo + ((grp * RG + r) * K + cw * 256) * 4, 0, 2));
     };
     f32x4 wa[RG][CW], wb[RG][CW];
     f32x4 xr[BQ][CW];

@@ -294,10 +294,14 @@ def _agree_on_hang(info: RankInfo, hung: bool, timeout_s: float = 30.0):
     import datetime
     try:
         store = dist.distributed_c10d._get_default_store()
-        store.set(f"omnitok/native_probe/{info.rank}", "1" if hung else "0")
+        # one key set per call: every rank calls this the same number of times, so the sequence number agrees across ranks and a
+        # second probe in the same process group never reads the previous call's values
+        seq = getattr(info, "_probe_seq", 0)
+        info._probe_seq = seq + 1
+        store.set(f"omnitok/native_probe/{seq}/{info.rank}", "1" if hung else "0")
         bad = []
         for r in range(info.world):
-            key = f"omnitok/native_probe/{r}"
+            key = f"omnitok/native_probe/{seq}/{r}"
             try:
                 store.wait([key], datetime.timedelta(seconds=timeout_s))
                 if store.get(key) != b"0":

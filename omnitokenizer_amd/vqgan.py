@@ -76,6 +76,24 @@ def _model(handle: int) -> "OmniTokenizer_VQGAN":
     return m
 
 
+def load_checkpoint_file(path, map_location="cpu", trust=False):
+    """torch.load of a PL-format checkpoint WITHOUT executing pickled code: weights_only=True with argparse.Namespace (the
+    `hyper_parameters.args` object of the released checkpoints, reference omnitokenizer.py:208) allow-listed.  A file that needs
+    anything else is refused unless the caller vouches for it (trust=True / --trust-checkpoint / OMNITOK_TRUST_CHECKPOINT=1): the
+    reference's own loader (pytorch_lightning) unpickles arbitrary objects, a downloaded .ckpt should not get that by default."""
+    import argparse
+    import os
+    import pickle
+    try:
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location=map_location, weights_only=True)
+    except pickle.UnpicklingError as e:
+        if not (trust or os.environ.get("OMNITOK_TRUST_CHECKPOINT") == "1"):
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({e}); pass trust_checkpoint=True (tools/ckpt_parity.py "
+                               "--trust-checkpoint) only for a file whose origin you trust -- unpickling runs its code") from e
+        return torch.load(path, map_location=map_location, weights_only=False)
+
+
 class OmniTokenizer_VQGAN(nn.Module):
     def __init__(self, args, attention_mode: Optional[str] = None):
         """args: the same Namespace the reference takes.  attention_mode: "sdpa" (what the
@@ -166,7 +184,7 @@ class OmniTokenizer_VQGAN(nn.Module):
     def load_from_checkpoint(cls, path, map_location="cpu", strict=False, **kw):
         """PL-style checkpoint: {"state_dict":…, "hyper_parameters": {"args": Namespace}}
         (reference omnitokenizer.py:208, download.py:49)."""
-        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        ckpt = load_checkpoint_file(path, map_location=map_location, trust=kw.pop("trust_checkpoint", False))
         model = cls(ckpt["hyper_parameters"]["args"], **kw)
         model.load_state_dict(ckpt["state_dict"], strict=strict)
         return model
@@ -379,7 +397,8 @@ class OmniTokenizer_VQGAN(nn.Module):
         # every fresh tensor has _version 0, so (data_ptr, _version, shape) would also match foreign ids.
         self._own_ids = (weakref.ref(ids), ids._version)
         # the eval-time state mutation of reference Codebook.forward (codebook.py:122-143); forward(log_image=True) passes
-        # _stats_out to receive the statistics of this one update.  Not recorded into a HIP graph: `call_cnt` is host state.
+        # _stats_out to receive the statistics of this one update.  Not recorded into a HIP graph: `call_cnt` is host state, so
+        # a captured encode() leaves codebook_usage / call_cnt untouched, at capture and at every replay (forward() refuses capture).
         if not self.use_external_codebook and (_stats_out is not None or self.update_codebook_usage_on_encode) \
                 and ids.numel() > 0 and not torch.cuda.is_current_stream_capturing():
             stats = self._update_codebook_usage(ids)
@@ -570,8 +589,17 @@ class OmniTokenizer_VQGAN(nn.Module):
             x_recon = self.decode(z if is_image else z.permute(0, 2, 3, 4, 1), is_image)
         else:
             stats = {}
+            if torch.cuda.is_current_stream_capturing():
+                # the statistics are part of this call's return value and advance host-side state (call_cnt): a captured graph
+                # would return nothing for them and its replays would not advance it.  encode() / decode() alone
+                # can be captured -- a replay then leaves codebook_usage where the capture found it.
+                raise RuntimeError("forward(log_image=True) returns codebook statistics and updates call_cnt on the host: it cannot "
+                                   "be recorded into a HIP graph (capture encode() / decode() instead)")
             emb, ids = self.encode(x, is_image, include_embeddings=True, _stats_out=None if self.use_external_codebook else stats)
             x_recon = self.decode(ids, is_image)
+            if not self.use_external_codebook and not stats:   # empty batch: no update happened, the statistics are those of no ids
+                z0 = torch.zeros(self.cfg.n_codes, device=x.device)
+                stats = dict(batch_usage=z0, perplexity=torch.ones((), device=x.device), avg_usage=self.codebook.codebook_usage.data.clone())
         if is_image:
             frames, frames_recon = x, x_recon
         else:

@@ -138,16 +138,19 @@ def main(argv=None):
     ap.add_argument("--modes", default="default,strict_fp32")
     ap.add_argument("--pixel-tol", type=float, default=1e-4)
     ap.add_argument("--oracle", action="store_true", help="use the CPU oracle as the checker even when the reference is mounted")
+    ap.add_argument("--trust-checkpoint", action="store_true",
+                    help="fall back to a full unpickle when the file does not load with weights_only=True (runs the file's code)")
     ap.add_argument("--cpu-only", action="store_true", help="load + checker legs only (cross-checks reference vs oracle when both exist)")
     a = ap.parse_args(argv)
     if not a.images and not a.synthetic:
         ap.error("--images DIR or --synthetic N")
 
-    ckpt = torch.load(a.ckpt, map_location="cpu", weights_only=False)
+    from omnitokenizer_amd.vqgan import load_checkpoint_file
+    ckpt = load_checkpoint_file(a.ckpt, trust=a.trust_checkpoint)
     hp = ckpt["hyper_parameters"]["args"]
     mode = a.attention_mode or getattr(hp, "attention_mode", "sdpa")
     from omnitokenizer_amd import OmniTokenizer_VQGAN
-    model = OmniTokenizer_VQGAN.load_from_checkpoint(a.ckpt, strict=False, attention_mode=mode)
+    model = OmniTokenizer_VQGAN.load_from_checkpoint(a.ckpt, strict=False, attention_mode=mode, trust_checkpoint=a.trust_checkpoint)
     cfg = model.cfg
     pt = cfg.enc_temporal_patch_size
     if a.frames > 1 and (a.frames - 1) % pt:
