@@ -517,10 +517,9 @@ def also_extras(model, x, sd, a, ids_ref_all=None):
         mh.load_state_dict(c.sd, strict=True)
         mh = mh.cuda().eval()
         r = {}
-        # the fixture is ONE clip = 5120 tokens, below "pl_min_tokens": on the process default it runs the small-call flow
-        # (fp32 activations), NOT the plane flow the timed C3 batch runs -- so the plane flow gets its own arm
-        # (per-engine pl_min_tokens = 0) and every arm says which flow it ran
-        for tag, gm, am, mt in (("default_plane_flow", -1, -1, 0), ("default_small_call_flow", -1, -1, 1 << 30),
+        # the fixture is ONE clip = 5120 tokens: since r06 it runs the plane flow the timed C3 batch runs (one data flow at every
+        # size); the fp32-activation flow the "pl_min_tokens" option still selects keeps its own arm
+        for tag, gm, am, mt in (("default_plane_flow", -1, -1, -1), ("fp32_activation_flow_option", -1, -1, 1 << 30),
                                 ("strict_fp32", 0, 0, -1)):
             mh.set_option("gemm_mode", gm)
             mh.set_option("attn_mode", am)
@@ -529,8 +528,8 @@ def also_extras(model, x, sd, a, ids_ref_all=None):
             rec = mh.decode(c.ids.cuda(), False)
             zerr = float((z.cpu() - c.z).abs().max())
             perr = float((c.strided(rec.cpu()) - c.recon).abs().max())
-            r[tag] = {"flow": {0: "planes (what the timed C3 step runs)", 1 << 30: "fp32 activations (calls below pl_min_tokens)"}.get(
-                          mt, "fp32-input MFMA kernels"),
+            r[tag] = {"flow": "fp32-input MFMA kernels" if gm == 0 else
+                              ("fp32 activations (pl_min_tokens option)" if mt > 0 else "planes (what the timed C3 step runs; the default at every size)"),
                       "id_flips_vs_reference": int((ids.cpu() != c.ids).sum()), "ids": int(c.ids.numel()),
                       "z_max_abs_err": zerr, "z_err_over_reference_fp32_noise": round(zerr / c.fp32_noise_z, 2),
                       "pixel_max_abs_err": perr, "pixel_err_over_reference_fp32_noise": round(perr / c.fp32_noise_pix, 2)}

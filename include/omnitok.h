@@ -50,10 +50,12 @@ const char *omnitok_version(void);
  *   "attn_vpack" 1 (default) the merged to_q|to_kv launch stores V as packed fp16 planes | 0 attn_pack packs V too
  *   "gemm_pl"    1 (default) plane data flow: attention kernels, the to_out / proj epilogue and the GEGLU epilogue write
  *                the next GEMM's operand as fp16 hi|lo planes (gemm_pl.h) | 0 fp32 activations, split in the K loop
- *   "pl_min_tokens" 12288 (default) calls with fewer tokens (B * T' * h * w) take the gemm_pl 0 data flow: below
- *                ~48 row tiles the 256 x 256 plane GEMM leaves most CUs idle (one image 4.1 ms vs 2.0 ms) | 0 always planes.
- *                Also a per-engine option (omnitok_engine_set_option): the two flows round differently (both inside the
- *                parity bars), so a clip's latent bits depend on the size of the call it is in unless the engine pins it
+ *   "pl_min_tokens" 0 (default since r06: one data flow at every call size -- a clip gets the same bits alone and in any
+ *                batch; the plane GEMM picks thin tiles for small calls, "pl_cfg") | n > 0: calls with fewer tokens
+ *                (B * T' * h * w) take the gemm_pl 0 data flow (rounds 4-5 shipped 12288).  Also a per-engine option
+ *                (omnitok_engine_set_option); the two flows round differently, both inside the parity bars
+ *   "pl_cfg"     0 (default) the plane GEMM's tile configuration by call size (256 x 256 | 128 x 128 | 128 x 64; LayerNorm
+ *                epilogue 128 | 64 | 32 rows) | 1, 2, 5, 6 (7) force one.  Results do not depend on it, bit for bit
  *   "temporal_chunk" 0 (default; also per engine) > 0: temporal blocks run GEMM(chunk of clips) -> attention(chunk) through
  *                one chunk-sized q|k|v buffer (bit-identical; measured slower at C3, profiles/r05_temporal_chunk.txt)
  *   "prevq_fuse" 1 (default) omnitok_encode runs pre_vq inside the encoder's last LayerNorm pass (bit-identical) | 0 two passes

@@ -77,6 +77,7 @@ extern int g_temporal_kernel;
 extern int g_qkv_pl;
 extern int g_attn_window_mode;
 extern int g_pl_cfg;
+extern int g_pl_tail;
 extern int g_pl_stagger;
 extern int g_vq_variant;
 extern int g_vq_screen;
@@ -112,6 +113,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "temporal_fused")) omnitok::g_temporal_fused = value;
     else if (!strcmp(name, "temporal_kernel")) omnitok::g_temporal_kernel = value;
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
+    else if (!strcmp(name, "pl_tail")) omnitok::g_pl_tail = value;
     else if (!strcmp(name, "pl_stagger")) omnitok::g_pl_stagger = value;
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;
     else if (!strcmp(name, "attn_window_mode")) omnitok::g_attn_window_mode = value;
@@ -141,6 +143,8 @@ extern "C" int omnitok_get_option(const char *name, int *value) {
     else if (!strcmp(name, "pl_min_tokens")) *value = omnitok::g_pl_min_tokens;
     else if (!strcmp(name, "temporal_chunk")) *value = omnitok::g_temporal_chunk;
     else if (!strcmp(name, "prevq_fuse")) *value = omnitok::g_prevq_fuse;
+    else if (!strcmp(name, "pl_cfg")) *value = omnitok::g_pl_cfg;
+    else if (!strcmp(name, "pl_tail")) *value = omnitok::g_pl_tail;
     else {
         omnitok::set_error("get_option: %s is not a readable option", name);
         return OMNITOK_ERR_INVALID;

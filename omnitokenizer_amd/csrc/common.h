@@ -112,6 +112,16 @@ __device__ __forceinline__ float wave_allsum(float v) {
 // value held by the partner lane (lane ^ 32)
 __device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32); }
 
+// A product that must be ROUNDED before it is added to something (the reference's own sequence of fp32 roundings, or results that
+// may not depend on which instantiation the compiler fused an fma in): passing it through an empty asm hides the multiply from the
+// fma combiner.  `#pragma clang fp contract(off)` is not enough -- HIP compiles with -ffp-contract=fast-honor-pragmas, and the
+// backend's combiner (fusion mode "fast") contracts a * b - c * d whatever the instruction flags say once packed fp32 is off
+// (found in r06: lm_select's CFG blend came out as one fma).
+__device__ __forceinline__ float no_fuse(float x) {
+    asm("" : "+v"(x));
+    return x;
+}
+
 // all-reduce over the two 32-lane halves of a wave (lane l with lane l ^ 32) through v_permlane32_swap (gfx950):
 // no LDS crossbar round trip.  r[0] = value of lanes 0-31 in both halves, r[1] = value of lanes 32-63.
 __device__ __forceinline__ float halves_max(float v) {

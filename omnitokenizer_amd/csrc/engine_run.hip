@@ -18,14 +18,16 @@ int g_attn_vpack = 1;
 // are written as fp16 hi|lo planes by their producers (attention kernels, the LayerNorm epilogue of to_out, the GEGLU
 // epilogue of FF-in): no row-statistics pass and no in-loop LayerNorm / split in front of the FeedForward.  0: the
 // r02 data flow (fp32 activations everywhere, gemm_h2.hip splits its A operand in the K loop).
-// "pl_min_tokens" (default 12288): calls with fewer tokens (B * T' * h * w) than this take the gemm_pl 0 data flow even
-// when gemm_pl is 1 -- the plane GEMM works in 256 x 256 tiles with a deep LDS-DMA ring, and below ~48 row tiles its
-// launches leave most of the 256 CUs idle: one 256^2 image 4.09 ms vs 2.00 ms, 8 images 5.31 vs 4.59 ms, 16 images
-// 7.00 vs 7.59 ms (profiles/r04_small_batch_latency.txt).  0 = always planes (what the parity tests of that path set).
-// The threshold is also a per-engine option (omnitok_engine_set_option "pl_min_tokens", -1 = this process default): a
-// clip-sharded job pins it from the GLOBAL batch so that every rank takes the same data flow whatever its shard size.
+// "pl_min_tokens" (default 0 since r06: ONE data flow at every call size): calls with fewer tokens (B * T' * h * w) than this
+// take the gemm_pl 0 data flow even when gemm_pl is 1.  Rounds 4-5 shipped 12288 here because the plane GEMM only had 256 x 256
+// tiles (one 256^2 image 4.09 ms vs 2.00 ms, profiles/r04_small_batch_latency.txt) -- and a clip's low bits then depended on
+// the size of the call it was in.  With the thin-tile family of gemm_pl.hip (128 x 128 / 128 x 64 / 32- and 64-row LayerNorm
+// tiles, same bits as the big tiles) the plane flow is as fast or faster at every size (one image 2.40 vs 2.39 ms of kernel
+// time, one clip 4.23 vs 4.44, two clips 5.86 vs 6.39: profiles/r06_small_calls.txt), so a clip is now encoded and decoded to
+// the same bits alone and inside any batch.  The option stays as an A/B switch (also per engine:
+// omnitok_engine_set_option "pl_min_tokens", -1 = this process default).
 int g_gemm_pl = 1;
-int g_pl_min_tokens = 12288;
+int g_pl_min_tokens = 0;
 // "temporal_chunk" (clips per chunk, 0 = off): a temporal 't' block runs its q|k|v plane GEMM and the temporal attention
 // kernel chunk by chunk -- GEMM(chunk) -> attention(chunk) back to back through ONE chunk-sized fp32 q|k|v buffer (31.5 MB
 // per 17x256^2 clip), so that the attention kernel's reads hit the 256 MiB Infinity Cache instead of HBM

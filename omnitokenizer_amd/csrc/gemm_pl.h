@@ -93,6 +93,11 @@ struct PlParams {
     int N, K;
     int nk;                           // K steps of 16 actually run: ceil(k_valid / 16) <= K / 16 (the rest of K is zero padding)
     int nbm, nbn, ntiles, gn;
+    // A launch may cover only the row tiles [bm0, bm0 + nbm) of the problem (r06 tail schedule: full rounds of tall tiles, then the
+    // remaining rows on thin ones); every address is formed from the ABSOLUTE row tile, so the pointers stay those of the whole problem.
+    // row_begin / row_end are host-side (launch_pl_cfg turns them into bm0 / nbm in units of the configuration's tile height).
+    int bm0;
+    int64_t row_begin, row_end;
     // operand row map (a_rpg == 0: identity): the frame groups of the token tensor
     int64_t a_rpg, a_gstride, a_goff;
     int up_C, up_F, up_H, up_W, up_f0, up_t, up_pt, up_p;  // PL_UNPATCH
@@ -119,6 +124,18 @@ __host__ __device__ __forceinline__ int64_t pl_offset(int64_t row, int k, int pl
 
 // s_waitcnt vmcnt(n) only: gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
 #define PL_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+// wait until at most min(ahead, N) K steps of PPWv pieces each are still in flight (ahead is wave-uniform; vmcnt takes an immediate)
+template <int PPWv, int N>
+__device__ __forceinline__ void pl_wait_steps(int ahead) {
+    if constexpr (N == 0) {
+        PL_WAIT_VM(0);
+    } else {
+        if (ahead >= N)
+            PL_WAIT_VM(N * PPWv);
+        else
+            pl_wait_steps<PPWv, N - 1>(ahead);
+    }
+}
 
 // D = how many K steps the DMA cursor runs ahead (D < R).  DBG (measurement builds, wrong results): 1 no vmcnt wait in
 // front of the barrier, 2 no barrier, 4 no DMA in the K loop, 8 no epilogue, 16 no fp32 stores, 32 no store drain at the tile end
@@ -132,13 +149,21 @@ struct PlCfg {
     static constexpr int TN = 32 * NI * WN, TM = 32 * MI * WM;
     static constexpr int WPS = NW > 4 ? 2 : 1;  // waves per SIMD of one workgroup
     static constexpr int SA = TM * 64, SW = TN * 64, STAGE = SA + SW;  // bytes per K step of 16
-    static constexpr int NPA = 4 * (TM / 64), NPW = 4 * (TN / 64), NP = NPA + NPW;
-    static constexpr int PPW = NP / NW;  // DMA pieces (1 KiB) per wave per step
+    // DMA pieces of 1 KiB per K step.  TM >= 64: one piece = (plane, k group) of a 64-row block.  TM == 32 (r06, small calls):
+    // one piece = one plane of the tile's 32 rows, lanes 0..31 k group 0, lanes 32..63 k group 1 (the source address of a
+    // global_load_lds is per lane, only the LDS side is contiguous) -- the same [plane][k group][TM rows][16 B] image in LDS.
+    static constexpr int NPA = TM >= 64 ? 4 * (TM / 64) : 2, NPW = 4 * (TN / 64), NP = NPA + NPW;
+    static constexpr int PPW = (NP + NW - 1) / NW;  // DMA pieces per wave per step; RAGGED: waves >= NP % NW issue one fewer
+    static constexpr bool RAGGED = NP % NW != 0;
     static constexpr int LDS = R * STAGE;
     static constexpr bool EPI_T = NW == 8;  // fp32 epilogues go through a 4 KiB LDS block per wave (row-major global accesses)
-    static_assert(NP % NW == 0, "pieces per wave");
-    static_assert(PPW <= NI_ * MI_ && (D_ - 1) * PPW < 48, "vmcnt bookkeeping: at most two pieces per MFMA-pair slot, vmcnt < 64");
-    static_assert(D_ >= 2 && D_ <= 3 && D_ < R_, "prefetch distance");
+    static_assert((TM % 64 == 0 || TM == 32) && TN % 64 == 0, "tile shape");
+    static_assert((D_ - 1) * PPW < 48, "vmcnt bookkeeping: vmcnt < 64");
+    static_assert(D_ >= 2 && D_ < R_, "prefetch distance");
+    // PL_ROWLN, thin tiles (r06): the row-major epilogue block of the 8 waves (32 KiB) lives in the ONE ring stage the DMA cursor
+    // does not own during an epilogue (R - D == 1: the stage of the last K step, all of whose fragment reads are behind that
+    // step's barrier) instead of behind the ring -- what lets a 4-stage ring of 34 / 36 KiB stages fit the CU's 160 KiB
+    static constexpr bool SCR_IN_RING = NW == 8 && R_ - D_ == 1 && MI_ <= 2 && STAGE >= NW * 4096;
 };
 
 // The fp32 epilogue's arithmetic, in two halves with contraction off: the row factors are applied in the accumulator
@@ -148,12 +173,12 @@ __device__ __forceinline__ float pl_row_part(float a, float sa, float frs, bool 
 #pragma clang fp contract(off)
     float t = a * sa;
     if (fold) t = frs * t;
-    return t;
+    return no_fuse(t);
 }
 __device__ __forceinline__ float pl_col_part(float t, float sw, float fmu, float fg, bool unfold, float fb) {
 #pragma clang fp contract(off)
-    t = t * sw;
-    if (unfold) t = t + fmu * fg;
+    t = no_fuse(t * sw);   // every product rounded on its own in every instantiation (common.h no_fuse)
+    if (unfold) t = t + no_fuse(fmu * fg);
     return t + fb;
 }
 __device__ __forceinline__ float pl_add(float a, float b) {
@@ -192,18 +217,26 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     unsigned pv_off[PPW];   // byte offset inside the tile's operand panel (+ lane * 16)
     int pl_dst[PPW];        // byte offset inside a stage
     bool p_is_w[PPW];
+    // RAGGED configurations: the last piece slot exists only for the first NP % NW waves (wave-uniform)
+    const bool full = !C::RAGGED || wave < C::NP % NW;
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int q = wave + NW * j;
+        int q = wave + NW * j;
+        if (C::RAGGED && q >= C::NP) q = wave;  // never issued (guarded by `full`); keeps the arithmetic in range
         const bool is_w = q >= C::NPA;
         const int qq = is_w ? q - C::NPA : q;
-        const int rowsb = is_w ? TN / 64 : TM / 64;
-        const int plkg = qq / rowsb, rb = qq % rowsb;
         p_is_w[j] = is_w;
-        pv_off[j] = (unsigned)rb * (unsigned)kblocks * 8192u + (unsigned)(plkg >> 1) * 4096u + (unsigned)(plkg & 1) * 1024u +
-                    (unsigned)lane * 16u;
         pl_dst[j] = (is_w ? C::SA : 0) + qq * 1024;
+        if (TM == 32 && !is_w) {  // piece = plane qq of the tile's 32 rows: lanes 0..31 k group 0, lanes 32..63 k group 1
+            pv_off[j] = (unsigned)qq * 4096u + (unsigned)(lane >> 5) * 1024u + (unsigned)(lane & 31) * 16u;
+        } else {
+            const int rowsb = is_w ? TN / 64 : TM / 64;
+            const int plkg = qq / rowsb, rb = qq % rowsb;
+            pv_off[j] = (unsigned)rb * (unsigned)kblocks * 8192u + (unsigned)(plkg >> 1) * 4096u + (unsigned)(plkg & 1) * 1024u +
+                        (unsigned)lane * 16u;
+        }
     }
+    auto piece_live = [&](int j) { return !C::RAGGED || j < PPW - 1 || full; };
     // the DMA cursor runs two steps ahead of the MFMAs, across tile boundaries
     const unsigned char *d_a = nullptr, *d_w = nullptr;  // panel bases of the cursor's tile (wave-uniform)
     int d_tile = -1, d_k = 0, d_stage = 0;
@@ -212,10 +245,11 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
         int64_t bm;
         int bn;
         tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            bm += p.bm0;
         const unsigned char *ab = (p.a_split_n > 0 && bn * TN >= p.a_split_n) ? p.a2 : p.a;
         int64_t arow = bm * TM;
         if (p.a_rpg > 0) arow = (arow / p.a_rpg) * p.a_gstride + p.a_goff + arow % p.a_rpg;  // whole tiles: a_rpg % TM == 0
-        d_a = ab + (arow >> 6) * (int64_t)kblocks * 8192;
+        d_a = ab + (arow >> 6) * (int64_t)kblocks * 8192 + (TM == 32 ? (arow & 63) * 16 : 0);
         d_w = p.w + (int64_t)bn * (TN / 64) * (int64_t)kblocks * 8192;
         d_tile = ti;
         d_k = 0;
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
         const unsigned koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
+            if (!piece_live(j)) continue;
             const unsigned char *src = (p_is_w[j] ? d_w : d_a) + koff + pv_off[j];
             __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + d_stage * C::STAGE + pl_dst[j]), 16, 0, 0);
         }
@@ -282,8 +317,9 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     // ---- prologue ----------------------------------------------------------------------------------------------
     d_set_tile(0);
     dma_step();
-    if (total > 1) dma_step();
-    if (D > 2 && total > 2) dma_step();
+#pragma unroll
+    for (int d = 1; d < D; ++d)
+        if (total > d) dma_step();
     int st = 0;  // stage of the current step
     PL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
@@ -299,6 +335,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             int64_t bm;
             int bn;
             tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            bm += p.bm0;
             int r32 = r32_, hi = hi_;
             asm volatile("" : "+v"(r32), "+v"(hi));
             const bool second = p.a_split_n > 0 && bn * TN >= p.a_split_n;
@@ -325,6 +362,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             int64_t bm;
             int bn;
             tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            bm += p.bm0;
             int r32 = r32_, hi = hi_;
             asm volatile("" : "+v"(r32), "+v"(hi));
             const int64_t m_w0 = bm * TM + wm * (32 * MI);
@@ -365,19 +403,16 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             const int cst = d_stage;
             if (more) koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
             auto dma_piece = [&](int j) {
-                if (j < PPW) {
+                if (j < PPW && piece_live(j)) {
                     const unsigned char *src = (p_is_w[j] ? cw : ca) + koff + pv_off[j];
                     __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + cst * C::STAGE + pl_dst[j]), 16, 0,
                                                      0);
                 }
             };
             auto dma_slot = [&](int i) {  // slot i of SLOTS: the pieces are spread over the MFMA gaps of a group
-                if constexpr (PPW <= SLOTS) {
-                    dma_piece(i);
-                } else {
-                    dma_piece(2 * i);
-                    dma_piece(2 * i + 1);
-                }
+                constexpr int PPS = (PPW + SLOTS - 1) / SLOTS;  // 1 or 2 for the big tiles; thin wave tiles (r06) take more
+#pragma unroll
+                for (int u = 0; u < PPS; ++u) dma_piece(PPS * i + u);
             };
             // G1: W lo . A hi   | after the first MFMA pair: reads W hi, A lo of this step (their wait then sits in front
             //                     of G2 and the wait in front of G1 covers only the fragments prefetched by the last G3)
@@ -398,14 +433,13 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                 if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
             }
             // this wave's share of step s + 1 has landed: everything but the pieces of steps s + 2 .. s + D
+            // (steps s + 2 .. min(s + D, total - 1) may stay in flight: min(D - 1, total - 2 - s) of them)
             if constexpr ((DBG & 1) == 0) {
-                if (more) {
-                    PL_WAIT_VM((D - 1) * PPW);
-                } else if (D > 2 && s + D - 1 < total) {
-                    PL_WAIT_VM((D - 2) * PPW);
-                } else {
-                    PL_WAIT_VM(0);
-                }
+                const int ahead = total - 2 - s;
+                if (full)
+                    pl_wait_steps<PPW, D - 1>(ahead);
+                else
+                    pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), D - 1>(ahead);
             }
             if constexpr ((DBG & 2) == 0) lds_barrier();
             // G3: W hi . A lo   | reads A hi, W lo of the next step
@@ -423,6 +457,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             int64_t bm;
             int bn;
             tile_coords(lid, p.nbm, p.nbn, p.gn, bm, bn);
+            bm += p.bm0;
             // the epilogue's lane-dependent address arithmetic must not be hoisted out of the tile loop (loop-invariant
             // code motion would keep dozens of addresses alive across the K loop: spills, and with them a vmcnt(0) in
             // front of every scratch reload): launder the lane coordinates here
@@ -753,7 +788,8 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     // residual in and fp32 out both go row-major through the wave's LDS block (see PL_F32): the residual is
                     // loaded as full lines, re-read in the accumulator layout, and the sum (kept in the accumulators for
                     // the statistics) takes the same way back out
-                    unsigned char *scr = pl_smem + C::LDS + 2 * C::WN * TM * 4 + wave * 4096;
+                    unsigned char *scr = C::SCR_IN_RING ? pl_smem + d_stage * C::STAGE + wave * 4096
+                                                        : pl_smem + C::LDS + 2 * C::WN * TM * 4 + wave * 4096;
                     const int rrow = hi * 4 + (r32 >> 3), rch = r32 & 7;
                     const int rd0 = rrow * 128 + ((rch ^ rrow) * 16);
                     const int wr0 = r32 * 128, wsw = r32 & 7;

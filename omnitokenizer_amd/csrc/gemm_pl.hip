@@ -7,7 +7,7 @@ extern int g_gemm_gn;
 int g_pl_stagger = 0;  // "pl_stagger": start delay step of persistent workgroups (~1 us units), 0 = off
 // "temporal_kernel": the fused temporal stage's GEMMs (epilogues 6 / 7) on 1 = gemm_plt_kernel (two workgroups per CU), 0 = gemm_pl_kernel
 int g_temporal_kernel = 1;
-int g_pl_cfg = 0;  // "pl_cfg": 0 auto | 1 256x256 (8 waves, 1 workgroup per CU) | 2 128(n)x256(m) (4 waves, 2 per CU)
+int g_pl_cfg = 0;  // "pl_cfg": 0 by size (pl_auto_plan) | 1 256x256 | 2 128(n)x256(m) | 5 128x128 | 6 128x64 (see launch_pl)
 
 // ---- weight rows -> scaled fp16 planes, rows permuted inside groups of 32 (pl_perm) ------------------------------
 // w' = w * 2^(14 - x) with max|w_n| = m 2^x (m in [0.5, 1)); scale[n] = 2^(x - 14) (by LOGICAL row).  Rows beyond N up
@@ -94,20 +94,25 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     int n_cu = 0;
     if (int rc = current_device_cus(&n_cu)) return rc;
     constexpr int LDS = C::LDS + (EPI == PL_ROWLN ? 2 * C::WN * C::TM * 4 : 0) +
-                        ((EPI == PL_ROWLN || EPI == PL_F32 || EPI == PL_UNPATCH) && C::EPI_T ? C::NW * 4096 : 0);
+                        ((EPI == PL_ROWLN || EPI == PL_F32 || EPI == PL_UNPATCH) && C::EPI_T && !(EPI == PL_ROWLN && C::SCR_IN_RING)
+                             ? C::NW * 4096 : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(gemm_pl_kernel<EPI, SWAP, C>), LDS)) return rc;
-    const int64_t nbm = (p.M + C::TM - 1) / C::TM;
+    const int64_t r_end = p.row_end > 0 ? p.row_end : p.M;
+    OT_CHECK_ARG(p.row_begin % C::TM == 0 && p.row_begin < r_end && r_end <= p.M, "gemm_pl: row range [%lld, %lld) of %lld rows on %d-row tiles",
+                 (long long)p.row_begin, (long long)r_end, (long long)p.M, C::TM);
+    const int64_t nbm = (r_end - p.row_begin + C::TM - 1) / C::TM;
     const int nbn = (p.N + C::TN - 1) / C::TN;
     const int64_t nt = nbm * nbn;
     OT_CHECK_ARG(nt < (1ll << 31), "gemm_pl: grid too large");
+    p.bm0 = (int)(p.row_begin / C::TM);
     p.nbm = (int)nbm;
     p.nbn = nbn;
     p.ntiles = (int)nt;
     p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
     p.stagger = g_pl_stagger;
     int wg_per_cu = (160 * 1024) / LDS;
-    const int by_waves = (C::NI * C::MI > 8) ? 1 : 8 / C::NW;
+    const int by_waves = (C::NI * C::MI > 8) ? 1 : (C::NI * C::MI <= 2 ? 16 : 8) / C::NW;
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
     if (wg_per_cu < 1) wg_per_cu = 1;
     // two small workgroups per CU: one tile each (the hardware dispatcher overlaps one's epilogue with the other's K loop);
@@ -122,14 +127,85 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
 int launch_plt_tscore(PlParams p, hipStream_t stream);  // gemm_plt.hip
 int launch_plt_tpv(PlParams p, hipStream_t stream);
 
+// Tile configurations ("pl_cfg" / omnitok_pl_gemm.cfg; 0 = by size, pl_auto_cfg below).  Every configuration runs the same
+// per-accumulator product order (K steps of 16, three plane products per step), so results do not depend on it bit for bit
+// (tests/test_gpu_gemm_pl.py); what changes is how many workgroups a launch has and how much of a CU one of them owns:
+//   1  256 x 256 (n x m), 8 waves, persistent, one workgroup per CU    -- calls that fill the chip with such tiles
+//   2  128 x 256, 4 waves, two per CU                                  -- (A/B arm)
+//   5  128 x 128, 4 waves of 64 x 64, two per CU                       -- r06: mid-size calls (4x the tiles of 1)
+//   6  128 x  64, 4 waves of 64 x 32, up to four per CU                -- r06: small calls (16x the tiles of 1)
+// PL_ROWLN owns whole rows (TN = 512, 8 waves x 64 columns in every configuration: the row statistics are summed in one
+// order): 1 -> 128 rows, 6 -> 64 rows, 7 -> 32 rows.  PL_UNPATCH needs the 8-wave row-major epilogue: 1 -> 256 x 256, 6 -> 256 x 64.
+using PlBig = PlCfg<4, 2, 4>;
+// Thin tiles behind the same 2-step ring as the big ones: 64 / 48 KiB of LDS, so two / three workgroups share a CU and fill each
+// other's barrier and fragment-read bubbles.  Deeper rings (DMA 4 / 6 steps ahead, 96 KiB, one workgroup per CU) measured SLOWER
+// at every size from 5120 rows up and equal at 1024 (profiles/r06_pl_small_tiles.txt): a thin wave tile has 2 MFMAs per
+// group to cover an LDS round trip with, co-resident workgroups are what hides it, not prefetch distance.
+using PlMid = PlCfg<2, 2, 4, 2, 0, 2, 2>;      // 128 x 128
+using PlSmall = PlCfg<2, 2, 4, 2, 0, 2, 1>;    // 128 x  64
+
+// Which configuration(s) a launch takes (results do not depend on it).  From the sweeps in profiles/r06_pl_small_tiles.txt:
+//  * 256 x 256 tiles win once they fill >= 3/4 of the CUs; below that 128 x 128 while there are >= n_cu of those, else 128 x 64
+//    (PL_ROWLN: the tallest of 128 / 64 / 32 rows that still gives every CU a tile; its full-row workgroups stream the whole weight,
+//    so the tall tile stays ahead down to half a round -- 20 480 rows: 64 us on 160 tiles of 128 rows against 72 us on 320 of 64);
+//  * TAIL SCHEDULE: when the big tiles make r >= 1 full rounds and a last round that leaves >= 5 % of the launch's CU-rounds idle
+//    (N = 512 at 40 960 rows: 320 tiles = 1.25 rounds; C5's 69 632 rows: 2.125), the full rounds run on big tiles and the rows of
+//    the last round on thin ones in a second launch behind it ("pl_tail" 1, default).  Per-tile K order is the same in every
+//    configuration, so the split is invisible in the bits.
+struct PlPlan {
+    int cfg;             // configuration of rows [0, split) (all rows when split == 0)
+    int64_t split;       // 0: one launch
+    int tail_cfg;
+};
+int g_pl_tail = 1;
+
+static int pl_thin_cfg(int epi, int64_t M, int N, int n_cu) {
+    auto tiles = [&](int tm, int tn) { return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn); };
+    if (epi == PL_ROWLN) return (tiles(64, 512) > n_cu || tiles(32, 512) > n_cu) ? 6 : 7;
+    if (epi == PL_UNPATCH) return 6;
+    return tiles(128, 128) >= n_cu ? 5 : 6;
+}
+
+static PlPlan pl_auto_plan(int epi, int64_t M, int N, int64_t row_align) {
+    int n_cu = 0;
+    if (current_device_cus(&n_cu) != OMNITOK_OK || n_cu <= 0) n_cu = 256;
+    const int tm = epi == PL_ROWLN ? 128 : 256, tn = epi == PL_ROWLN ? 512 : 256;
+    const int64_t nbm = (M + tm - 1) / tm;
+    const int nbn = (N + tn - 1) / tn;
+    const int64_t t = nbm * nbn;
+    const bool enough = epi == PL_ROWLN ? t * 2 >= n_cu : t * 4 >= 3 * (int64_t)n_cu;
+    if (!enough) return PlPlan{pl_thin_cfg(epi, M, N, n_cu), 0, 0};
+    const int64_t r = t / n_cu, rem = t % n_cu;
+    if (g_pl_tail && r >= 1 && rem > 0 && (n_cu - rem) * 20 >= (int64_t)n_cu * (r + 1)) {
+        // rows of the full rounds: whole row tiles, and whole units of `row_align` rows (sequences / clips / videos an epilogue
+        // addresses by division: a launch boundary inside one is fine for the arithmetic but keeps the checks simple)
+        int64_t rows_main = (r * n_cu / nbn) * tm;
+        if (row_align > 1) rows_main -= rows_main % row_align;
+        if (rows_main >= tm && rows_main % tm == 0 && rows_main < M)
+            return PlPlan{1, rows_main, pl_thin_cfg(epi, M - rows_main, N, n_cu)};
+    }
+    return PlPlan{1, 0, 0};
+}
+
 template <int EPI>
 static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
     if constexpr (EPI == PL_VPACK) {
-        return launch_pl_cfg<EPI, true, PlCfg<4, 2, 4>>(p, stream);
+        switch (cfg) {
+            case 5: return launch_pl_cfg<EPI, true, PlMid>(p, stream);
+            case 6: return launch_pl_cfg<EPI, true, PlSmall>(p, stream);
+            default: return launch_pl_cfg<EPI, true, PlBig>(p, stream);
+        }
     } else if constexpr (EPI == PL_QKPACK) {
-        return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+        switch (cfg) {
+            case 5: return launch_pl_cfg<EPI, false, PlMid>(p, stream);
+            case 6: return launch_pl_cfg<EPI, false, PlSmall>(p, stream);
+            default: return launch_pl_cfg<EPI, false, PlBig>(p, stream);
+        }
     } else if constexpr (EPI == PL_UNPATCH) {
-        return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+        switch (cfg) {
+            case 6: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 3, 2, 0, 2, 1>>(p, stream);
+            default: return launch_pl_cfg<EPI, false, PlBig>(p, stream);
+        }
     } else if constexpr (EPI == PL_TSCORE || EPI == PL_TPV) {
         // 320 x 128 tiles, 4 waves of (2 x 5 blocks): one wave per SIMD, 160 accumulator registers, 7 DMA pieces per wave and step
         // (the first form, 320 x 256 tiles with 4 x 5 blocks per wave, needed 320 accumulator registers and 9 pieces: 2.6x slower,
@@ -140,10 +216,16 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
         if (g_temporal_kernel >= 1 && fits32) return EPI == PL_TSCORE ? launch_plt_tscore(p, stream) : launch_plt_tpv(p, stream);
         return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 2, 5>>(p, stream);
     } else if constexpr (EPI == PL_ROWLN) {
-        return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);  // 512 (= N) x 128 tiles: a workgroup owns whole rows
+        switch (cfg) {  // 512 (= N) columns: a workgroup owns whole rows
+            case 6: return launch_pl_cfg<EPI, false, PlCfg<8, 1, 4, 3, 0, 2, 2>>(p, stream);  // 64 rows
+            case 7: return launch_pl_cfg<EPI, false, PlCfg<8, 1, 4, 3, 0, 2, 1>>(p, stream);  // 32 rows
+            default: return launch_pl_cfg<EPI, false, PlCfg<8, 1, 3>>(p, stream);             // 128 rows
+        }
     } else {
         switch (cfg) {
             case 2: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3>>(p, stream);
+            case 5: return launch_pl_cfg<EPI, false, PlMid>(p, stream);
+            case 6: return launch_pl_cfg<EPI, false, PlSmall>(p, stream);
 #ifdef OMNITOK_PL_MEASUREMENT_BUILDS  // wrong-result ablation builds of profiles/r03_gemm_limiter_probe.txt
             case 3: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3>>(p, stream);
             case 4: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 4>>(p, stream);
@@ -156,9 +238,24 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
             case 19: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 16>>(p, stream);
             case 20: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 32>>(p, stream);
 #endif
-            default: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4>>(p, stream);
+            default: return launch_pl_cfg<EPI, false, PlBig>(p, stream);
         }
     }
+}
+
+// forced_cfg > 0: that configuration for every row; 0: the plan of pl_auto_plan (one launch, or full rounds + tail)
+template <int EPI>
+static int pl_run(const PlParams &p, int forced_cfg, hipStream_t stream) {
+    if (forced_cfg > 0) return launch_pl<EPI>(p, forced_cfg, stream);
+    const PlPlan plan = pl_auto_plan(EPI, p.M, p.N, 1);
+    if (plan.split == 0) return launch_pl<EPI>(p, plan.cfg, stream);
+    PlParams a = p, b = p;
+    a.row_begin = 0;
+    a.row_end = plan.split;
+    b.row_begin = plan.split;
+    b.row_end = p.M;
+    if (int rc = launch_pl<EPI>(a, plan.cfg, stream)) return rc;
+    return launch_pl<EPI>(b, plan.tail_cfg, stream);
 }
 
 }  // namespace omnitok
@@ -250,17 +347,17 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
         p.a_gstride = g->a_gstride;
         p.a_goff = g->a_goff;
     }
-    const int cfg = g->cfg > 0 ? g->cfg : (g_pl_cfg > 0 ? g_pl_cfg : 1);
+    const int cfg = g->cfg > 0 ? g->cfg : (g_pl_cfg > 0 ? g_pl_cfg : 0);   // 0: by size (pl_auto_plan)
     OT_CHECK_ARG(p.a_split_n % 256 == 0 && p.c_split_n % 256 == 0, "gemm_pl: split columns must be multiples of 256");
     switch (g->epilogue) {
         case PL_F32:
             OT_CHECK_ARG(g->c && g->ldc % 4 == 0 && aligned16(g->c) && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))),
                          "gemm_pl: fp32 output must be 16-byte aligned with ldc %% 4 == 0");
-            return launch_pl<PL_F32>(p, cfg, stream);
+            return pl_run<PL_F32>(p, cfg, stream);
         case PL_GEGLU:
             OT_CHECK_ARG(g->out_planes && g->N % 64 == 0 && g->out_planes_k == g->N / 2 && g->out_bound > 0.0f,
                          "gemm_pl: GEGLU needs out_planes with out_planes_k == N / 2 and a bound of the hidden");
-            return launch_pl<PL_GEGLU>(p, cfg, stream);
+            return pl_run<PL_GEGLU>(p, cfg, stream);
         case PL_VPACK:
             OT_CHECK_ARG(g->vp && aligned16(g->vp) && g->heads > 0 && g->N == g->heads * 64 && g->n_tokens > 0 &&
                              g->n_tokens % 32 == 0 && g->M % g->n_tokens == 0 && g->v_bound > 0.0f && !g->a2 &&
@@ -274,7 +371,7 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             p.v_bound_dev = g->v_bound_dev;
             p.v_bound_stride = g->v_bound_stride > 0 ? g->v_bound_stride : 1;
             p.v_rpc = g->v_bound_dev ? g->rows_per_clip : 0;
-            return launch_pl<PL_VPACK>(p, cfg, stream);
+            return pl_run<PL_VPACK>(p, cfg, stream);
         case PL_QKPACK:
             OT_CHECK_ARG(g->qp && g->kp && aligned16(g->qp) && aligned16(g->kp) && g->heads > 0 && g->qk_k0 == g->heads * 64 &&
                              g->N == 2 * g->qk_k0 && g->n_tokens > 0 && g->n_tokens % 32 == 0 && g->M % g->n_tokens == 0 &&
@@ -294,7 +391,7 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             p.q_mul = g->q_mul;
             p.sq = h2_scale_of_bound(g->q_bound);
             p.sk = h2_scale_of_bound(g->k_bound);
-            return launch_pl<PL_QKPACK>(p, cfg, stream);
+            return pl_run<PL_QKPACK>(p, cfg, stream);
         case PL_UNPATCH:
             OT_CHECK_ARG(g->c && aligned16(g->c) && g->up_p == 8 && g->up_pt > 0 && g->up_t > 0 && g->up_C > 0 &&
                              g->up_H % g->up_p == 0 && g->up_W % (32 * g->up_p) == 0 &&
@@ -304,7 +401,7 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
                          "gemm_pl: the un-patchify epilogue needs p == 8, W %% 256 == 0, N == C pt p p and whole videos of t x (H / p) x (W / p) patches");
             p.up_C = g->up_C; p.up_F = g->up_F; p.up_H = g->up_H; p.up_W = g->up_W; p.up_f0 = g->up_f0; p.up_t = g->up_t;
             p.up_pt = g->up_pt; p.up_p = g->up_p;
-            return launch_pl<PL_UNPATCH>(p, 1, stream);
+            return pl_run<PL_UNPATCH>(p, cfg, stream);
         case PL_ROWLN:
             OT_CHECK_ARG(g->N == 512 && g->c && g->ldc % 4 == 0 && aligned16(g->c) && g->out_planes && g->out_planes_k == g->N &&
                              g->out_bound > 0.0f && g->ln_gamma && (!g->residual || (g->ldr % 4 == 0 && aligned16(g->residual))) &&
@@ -313,7 +410,7 @@ extern "C" int omnitok_gemm_pl(const omnitok_pl_gemm *g, omnitok_stream_t stream
             p.ln_gamma = g->ln_gamma;
             p.ln_beta = g->ln_beta;
             p.ln_eps = g->ln_eps;
-            return launch_pl<PL_ROWLN>(p, cfg, stream);
+            return pl_run<PL_ROWLN>(p, cfg, stream);
         case PL_TSCORE:
         case PL_TPV: {
             // rows: [tile of 64 sequences][32-sequence half][5 time steps][32 sequences] (omnitok_stats_pack_temporal)

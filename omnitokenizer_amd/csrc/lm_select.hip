@@ -44,7 +44,8 @@ __device__ __forceinline__ float sel_value(const SelParams &p, int64_t b, int i)
     const float lc = __fdiv_rn(p.logits[b * p.V + i], p.temperature);
     if (!p.logits_u) return lc;
     const float lu = __fdiv_rn(p.logits_u[b * p.V + i], p.temperature);
-    return __fsub_rn(__fmul_rn(p.c1, lc), __fmul_rn(p.c2, lu));
+    // __fmul_rn / __fsub_rn are plain operators in this HIP: each product is rounded on its own only behind no_fuse
+    return no_fuse(p.c1 * lc) - no_fuse(p.c2 * lu);
 }
 
 // exclusive prefix sum of one float per thread over the workgroup (deterministic), total in *total

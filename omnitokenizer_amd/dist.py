@@ -27,7 +27,8 @@ def data_flow_for(n_total: int, tokens_per_item: int, world: int, min_tokens: in
     shard would take on its own: 0 (plane flow everywhere) when ceil(n_total / world) items reach the threshold, else a
     value no call reaches (small-call flow everywhere).  The two flows round differently (include/omnitok.h
     "pl_min_tokens"), so without this a ragged shard -- or 2 clips per rank against 4 -- could give the same clip
-    different latent bits on different ranks."""
+    different latent bits on different ranks.  With the default threshold 0 (r06: one data flow at every size) this is
+    always 0; it matters only for a process that sets the option."""
     largest = -(-int(n_total) // max(int(world), 1)) * int(tokens_per_item)
     return 0 if largest >= int(min_tokens) else (1 << 30)
 

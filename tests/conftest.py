@@ -28,17 +28,14 @@ def pytest_sessionstart(session):
 
 @pytest.fixture(scope="session", autouse=True)
 def plane_data_flow_at_every_size():
-    """The engine routes calls below "pl_min_tokens" (12288 tokens) to the fp32-activation data flow (include/omnitok.h);
-    the golden fixtures are all smaller than that, so the GPU session pins the threshold to 0 -- the tests then exercise
-    the plane data flow the full-size workloads run, next to the explicit gemm_pl 0 parametrisations.  The rule itself is
-    tested in tests/test_gpu_e2e.py::test_small_calls_take_the_fp32_activation_flow, which sets and restores it."""
+    """"pl_min_tokens" is 0 by default since r06 (one data flow at every call size; the thin-tile family of the plane GEMM).  The
+    fixture keeps the process on that default and lets OMNITOK_TEST_PL_MIN_TOKENS=12288 run the whole suite with small calls on
+    the fp32-activation flow instead (the A/B arm the option still selects)."""
     import torch
     if not torch.cuda.is_available():
         yield
         return
     from omnitokenizer_amd import _lib
-    # OMNITOK_TEST_PL_MIN_TOKENS=12288 runs the whole suite on the flow small calls take by default instead
-    # (profiles/r04_gpu_tests_small_call_flow.txt)
     _lib.set_option("pl_min_tokens", int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")))
     yield
-    _lib.set_option("pl_min_tokens", 12288)
+    _lib.set_option("pl_min_tokens", 0)

@@ -112,8 +112,9 @@ def test_sharded_job_pins_one_data_flow_for_all_ranks():
     batch; pin_data_flow applies it through the per-engine option and reads the process default through the C ABI."""
     from omnitokenizer_amd import _lib
     from omnitokenizer_amd.dist import data_flow_for, pin_data_flow
-    thr = _lib.get_option("pl_min_tokens")
-    assert thr == 12288
+    assert _lib.get_option("pl_min_tokens") == 0   # r06: one data flow at every size is the default ...
+    assert data_flow_for(9, 5120, 8, 0) == 0 and data_flow_for(1, 1024, 1, 0) == 0
+    thr = 12288                                    # ... and the rule still holds for whoever sets a threshold (rounds 4-5: 12288)
     # C4: 256 clips of 5120 tokens on 8 ranks -> planes; 9 clips on 8 ranks: largest shard 2 clips = 10240 < 12288 -> the
     # small-call flow on EVERY rank (also the ranks that hold 1 clip); 17 clips on 8 ranks: largest 3 clips -> planes everywhere
     assert data_flow_for(256, 5120, 8, thr) == 0
@@ -125,12 +126,12 @@ def test_sharded_job_pins_one_data_flow_for_all_ranks():
         def set_option(self, name, value):
             self.got = (name, value)
     m = FakeModel()
-    assert pin_data_flow(m, 2, 5120) == 1 << 30 and m.got == ("pl_min_tokens", 1 << 30)
+    assert pin_data_flow(m, 2, 5120) == 0 and m.got == ("pl_min_tokens", 0)
     try:
-        _lib.set_option("pl_min_tokens", 0)
-        assert pin_data_flow(m, 2, 5120) == 0
-    finally:
         _lib.set_option("pl_min_tokens", 12288)
+        assert pin_data_flow(m, 2, 5120) == 1 << 30 and m.got == ("pl_min_tokens", 1 << 30)
+    finally:
+        _lib.set_option("pl_min_tokens", 0)
     with pytest.raises(ValueError):
         _lib.get_option("no_such_option")
 

@@ -250,14 +250,16 @@ def test_window_attention_paths_agree(models, name):
     assert (res[0][1] - res[1][1]).abs().max().item() < 2 * tol
 
 
-def test_small_calls_take_the_fp32_activation_flow(models):
-    """"pl_min_tokens" (include/omnitok.h, default 12288): a call with fewer tokens runs the gemm_pl 0 data flow (one image:
-    2.0 ms instead of 4.1 ms, profiles/r04_small_batch_latency.txt), a call at or above it the plane data flow -- checked
-    bit for bit against the two flows selected explicitly, on 2 clips (10240 tokens) and 3 clips (15360 tokens)."""
+def test_one_data_flow_at_every_size_and_the_option_still_selects_the_other(models):
+    """r06: "pl_min_tokens" defaults to 0 -- calls of every size run the plane data flow (thin tiles for small calls, same bits as
+    the 256 x 256 tiles), so 2 clips (10240 tokens) and 3 clips (15360) both equal an explicit plane-flow run bit for bit.  The
+    option still routes calls below a threshold to the fp32-activation flow (12288 = what rounds 4-5 shipped): checked against
+    that flow selected explicitly."""
     from omnitokenizer_amd import _lib
     c = GoldenCase(HEAVY_BATCH_CASE)
     m = models(c)
     x = c.x.cuda()
+    assert _lib.get_option("pl_min_tokens") == int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0"))
 
     def run(n, pl, min_tokens):
         try:
@@ -269,6 +271,13 @@ def test_small_calls_take_the_fp32_activation_flow(models):
             _lib.set_option("gemm_pl", 1)
             _lib.set_option("pl_min_tokens", int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")))  # tests/conftest.py
 
+    for n in (2, 3):   # the default: planes at both sizes
+        d, e = run(n, 1, 0), run(n, 1, 0)
+        for a_, b_ in zip(d, e):
+            assert torch.equal(a_, b_)
+    one, three = run(1, 1, 0), run(3, 1, 0)   # ... and a clip gets the same bits alone and inside a batch
+    for a_, b_ in zip(one, three):
+        assert torch.equal(a_, b_[:1])
     for n, planes in ((2, False), (3, True)):
         tokens = c.ids[:n].numel()
         assert (tokens >= 12288) == planes
@@ -637,8 +646,8 @@ def test_full_size_properties(models, is_image, batch):
     assert rec.shape == ((batch, 3, 256, 256) if is_image else (batch, 3, 17, 256, 256))
     assert torch.isfinite(rec).all()
     assert torch.equal(rec[4:8], rec[:4])
-    # a 2-item call sits below "pl_min_tokens" when the session runs on the default threshold (tests/conftest.py): it then
-    # takes the other data flow, whose pixels agree to rounding instead of bit for bit (ids are equal either way, above)
+    # one data flow at every call size (r06): a 2-item call decodes to the same bits as those items inside the full batch
+    # (OMNITOK_TEST_PL_MIN_TOKENS=12288, the A/B arm, puts the small call on the other flow: pixels then agree to rounding)
     min_tokens = int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0"))
     rec2 = m.decode(ids[:2].contiguous(), is_image)
     if (ids[:2].numel() >= min_tokens) == (ids.numel() >= min_tokens):

@@ -33,7 +33,7 @@ SHAPES = [(1024, 512, 512), (1000, 192, 512), (4096 + 33, 1536, 512), (257, 512,
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("cfg", [1, 2], ids=["256x256", "128x256"])
+@pytest.mark.parametrize("cfg", [1, 2, 5, 6, 0], ids=["256x256", "128x256", "128x128", "128x64", "auto"])
 def test_pl_gemm_fp32_epilogue_vs_fp64(ops, M, N, K, cfg):
     x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
     bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
@@ -70,13 +70,88 @@ def test_pl_gemm_results_do_not_depend_on_tiling_or_batch(ops):
     ap, asc = ops.pl_pack_rows(x)
     wp = ops.pl_pack_weight(w)
     full1 = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=1)
-    full2 = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=2)
-    assert torch.equal(full1, full2)
+    for cfg in (2, 5, 6, 0):   # 128x256, 128x128, 128x64 tiles, and the size rule: same bits
+        assert torch.equal(full1, ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=cfg)), cfg
+    bias, res = rnd(N, seed=70), rnd(M, N, seed=71)
+    fr = ops.linear_pl(ap, wp, M, N, K, a_scale=asc, bias=bias, residual=res, cfg=1)
+    for cfg in (5, 6):
+        assert torch.equal(fr, ops.linear_pl(ap, wp, M, N, K, a_scale=asc, bias=bias, residual=res, cfg=cfg)), cfg
     # the first 512 rows alone (another grid, other tiles per workgroup): bit-identical rows
     ap3, asc3 = ops.pl_pack_rows(x[:512].contiguous())
     assert torch.equal(ops.linear_pl(ap3, wp, 512, N, K, a_scale=asc3, cfg=1), full1[:512])
     # determinism across launches
     assert torch.equal(ops.linear_pl(ap, wp, M, N, K, a_scale=asc, cfg=1), full1)
+
+
+def test_pl_gemm_tail_schedule_is_bit_identical(ops):
+    """r06 tail schedule (gemm_pl.hip pl_auto_plan): when the 256 x 256 tiles make full rounds over the CUs plus a mostly idle last
+    round, the size rule runs the full rounds on them and the remaining rows on thin tiles in a second launch.  Same bits as one
+    launch of either configuration, for every epilogue; "pl_tail" 0 switches it off."""
+    from omnitokenizer_amd import _lib
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    K = 512
+    # N = 512: 2 column tiles -> (n_cu / 2 + 1) row tiles = one full round + 2 tiles
+    M = 256 * (n_cu // 2 + 1) - 37
+    Mx = 128 * (n_cu + 3)                                   # the largest row count used below
+    x, w = rnd(Mx, K, seed=80), rnd(512, K, seed=81, scale=0.05)
+    bias, res_all = rnd(512, seed=82), rnd(Mx, 512, seed=83)
+    res = res_all[:M].contiguous()
+    ap, asc = ops.pl_pack_rows(x[:M].contiguous())
+    wp = ops.pl_pack_weight(w)
+    auto = ops.linear_pl(ap, wp, M, 512, K, a_scale=asc, bias=bias, residual=res, cfg=0)
+    assert torch.equal(auto, ops.linear_pl(ap, wp, M, 512, K, a_scale=asc, bias=bias, residual=res, cfg=1))
+    assert torch.equal(auto, ops.linear_pl(ap, wp, M, 512, K, a_scale=asc, bias=bias, residual=res, cfg=6))
+    try:
+        _lib.set_option("pl_tail", 0)
+        assert torch.equal(auto, ops.linear_pl(ap, wp, M, 512, K, a_scale=asc, bias=bias, residual=res, cfg=0))
+    finally:
+        _lib.set_option("pl_tail", 1)
+    # LayerNorm epilogue: 128-row tiles, n_cu + 3 of them
+    M2 = 128 * (n_cu + 3) - 11
+    assert M2 <= Mx
+    gamma, beta = 1.0 + 0.2 * rnd(512, seed=84), 0.1 * rnd(512, seed=85)
+    bound = 1.01 * (math.sqrt(512) * float(gamma.abs().max()) + float(beta.abs().max()))
+    ap2, asc2 = ops.pl_pack_rows(x[:M2].contiguous())
+    kw = dict(a_scale=asc2, bias=bias, residual=res_all[:M2].contiguous(), epilogue=2, out_bound=bound, ln=(gamma, beta, 1e-5))
+    c0, l0 = ops.linear_pl(ap2, wp, M2, 512, K, cfg=0, **kw)
+    c1, l1 = ops.linear_pl(ap2, wp, M2, 512, K, cfg=1, **kw)
+    if not torch.equal(c0, c1):   # say which rows, and which of the two is off the fp64 product
+        ref2 = x[:M2].double() @ w.double().t() + bias.double() + res_all[:M2].double()
+        rows = torch.nonzero((c0 != c1).any(1)).flatten()
+        e0, e1 = (c0.double() - ref2).abs().max(1).values, (c1.double() - ref2).abs().max(1).values
+        raise AssertionError(f"tail schedule vs one launch: {rows.numel()} rows differ, first {rows[:8].tolist()} last {rows[-4:].tolist()}; "
+                             f"max err cfg 0 {float(e0.max()):.3e} (rows > 1e-4: {int((e0 > 1e-4).sum())}), cfg 1 {float(e1.max()):.3e} "
+                             f"(rows > 1e-4: {int((e1 > 1e-4).sum())}); options {[(n, _lib.get_option(n)) for n in ('pl_cfg', 'pl_tail', 'gemm_pl', 'gemm_mode')]}")
+    assert torch.equal(ops.pl_unpack_planes(l0, M2, 512), ops.pl_unpack_planes(l1, M2, 512))
+    # GEGLU: N = 2816 -> 11 column tiles; 24 row tiles = 264 tiles on 256 CUs
+    nbn = 11
+    M3 = 256 * (n_cu // nbn + 1) - 5
+    assert M3 <= Mx
+    w1p = ops.pack_geglu_weight(rnd(2 * 1365, K, seed=86, scale=0.05), 1408)
+    ap3, _ = ops.pl_pack_rows(x[:M3].contiguous(), static_bound=8.0)
+    kw = dict(a_scale_const=ops.pl_unscale(8.0), epilogue=1, out_bound=64.0)
+    h0 = ops.linear_pl(ap3, ops.pl_pack_weight(w1p), M3, 2816, K, cfg=0, **kw)
+    h1 = ops.linear_pl(ap3, ops.pl_pack_weight(w1p), M3, 2816, K, cfg=1, **kw)
+    assert torch.equal(ops.pl_unpack_planes(h0, M3, 1408), ops.pl_unpack_planes(h1, M3, 1408))
+    # packed Q | K and V (N = 1024 / 512), whole sequences of 256 tokens
+    heads, D, Ntok = 8, 512, 256
+    M4 = Ntok * ((256 * (n_cu // 4 + 1)) // Ntok + 1)   # (its own operand below)
+    x4 = rnd(M4, D, seed=87, scale=1.5) + 0.2
+    wq = rnd(3 * D, D, seed=88, scale=0.05)
+    gam4 = 1.0 + 0.2 * rnd(D, seed=89)
+    qs, ks = 1.0 + 0.1 * rnd(64, seed=90), 1.0 + 0.1 * rnd(64, seed=91)
+    cos, sin = (t.cuda() for t in ops.rope_table(Ntok))
+    planes, scales, stats = ops.stats_pack(x4, center=True)
+    w2, b, u = ops.fold_layernorm_weight(wq, gam4, None, rows_fold=D)
+    attn = dict(n_tokens=Ntok, heads=heads, q_scale=qs, k_scale=ks, cos=cos, sin=sin, q_mul=8.0, q_bound=64.0, k_bound=8.0, v_bound=64.0)
+    wpq, wv = ops.pl_pack_weight(w2), ops.pl_pack_weight(w2[2 * D:].contiguous())
+    outs = []
+    for cfg in (0, 1):
+        qp, kp = ops.linear_pl(planes, wpq, M4, 2 * D, D, a_scale=scales, fold=(stats, b, u, D), epilogue=4, attn=attn, cfg=cfg)
+        vp = ops.linear_pl(planes, wv, M4, D, D, a_scale=scales, fold=(stats, None, u[2 * D:].contiguous(), 0), epilogue=3, attn=attn, cfg=cfg)
+        outs.append((qp, kp, vp))
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
 
 
 def test_pl_gemm_two_operands_and_two_outputs(ops):
@@ -102,6 +177,10 @@ def test_pl_gemm_geglu_epilogue_writes_hidden_planes(ops):
     ap, _ = ops.pl_pack_rows(x, static_bound=8.0)
     hid = ops.linear_pl(ap, ops.pl_pack_weight(w1p), M, 2 * inner_pad, K, a_scale_const=ops.pl_unscale(8.0), epilogue=1,
                         out_bound=64.0)
+    for cfg in (5, 6):   # the small-call tiles write the same planes bit for bit
+        hid_c = ops.linear_pl(ap, ops.pl_pack_weight(w1p), M, 2 * inner_pad, K, a_scale_const=ops.pl_unscale(8.0), epilogue=1,
+                              out_bound=64.0, cfg=cfg)
+        assert torch.equal(ops.pl_unpack_planes(hid_c, M, inner_pad), ops.pl_unpack_planes(hid, M, inner_pad)), cfg
     h = (x.double() @ w1.double().t())
     ref = F.gelu(h[:, inner:]) * h[:, :inner]
     got = ops.pl_unpack_planes(hid, M, inner_pad) * ops.pl_unscale(64.0)
@@ -113,6 +192,9 @@ def test_pl_gemm_geglu_epilogue_writes_hidden_planes(ops):
     w2p[:, :inner] = w2
     res = rnd(M, 512, seed=14)
     out = ops.linear_pl(hid, ops.pl_pack_weight(w2p), M, 512, inner_pad, a_scale_const=ops.pl_unscale(64.0), residual=res)
+    for cfg in (1, 5, 6):
+        assert torch.equal(out, ops.linear_pl(hid, ops.pl_pack_weight(w2p), M, 512, inner_pad, a_scale_const=ops.pl_unscale(64.0),
+                                              residual=res, cfg=cfg, k_valid=inner)), cfg
     ref2 = ref @ w2.double().t() + res.double()
     assert maxerr(out, ref2) < 1e-5 * max(1.0, ref2.abs().max().item())
 
@@ -140,6 +222,12 @@ def test_pl_gemm_layernorm_epilogue(ops, M, with_beta):
                              epilogue=2, out_bound=bound, ln=(gamma, beta, 1e-5))
     assert torch.equal(c1, c[:128])
     assert torch.equal(ops.pl_unpack_planes(lnp1, 128, 512), ops.pl_unpack_planes(lnp, 128, 512))
+    # 128-, 64- and 32-row tiles (r06: small calls) write the same rows and the same LayerNorm planes
+    for cfg in (1, 6, 7):
+        cc, lc = ops.linear_pl(ap, ops.pl_pack_weight(w), M, 512, K, a_scale=asc, bias=bias, residual=res, epilogue=2,
+                               out_bound=bound, ln=(gamma, beta, 1e-5), cfg=cfg)
+        assert torch.equal(cc, c), cfg
+        assert torch.equal(ops.pl_unpack_planes(lc, M, 512), ops.pl_unpack_planes(lnp, M, 512)), cfg
 
 
 def test_stats_pack_matches_row_stats_and_pack_rows(ops):
@@ -204,6 +292,12 @@ def test_pl_gemm_packs_attention_operands(ops, rope):
     qp, kp = ops.linear_pl(planes, wp, M, 2 * D, D, a_scale=scales, fold=(stats, b, u, D), epilogue=4, attn=attn)
     wv = ops.pl_pack_weight(w2[2 * D:].contiguous())
     vp = ops.linear_pl(planes, wv, M, D, D, a_scale=scales, fold=(stats, None, u[2 * D:].contiguous(), 0), epilogue=3, attn=attn)
+
+    for cfg in (1, 5, 6):   # every tile configuration packs the same bytes
+        q2, k2 = ops.linear_pl(planes, wp, M, 2 * D, D, a_scale=scales, fold=(stats, b, u, D), epilogue=4, attn=attn, cfg=cfg)
+        v2 = ops.linear_pl(planes, wv, M, D, D, a_scale=scales, fold=(stats, None, u[2 * D:].contiguous(), 0), epilogue=3, attn=attn,
+                           cfg=cfg)
+        assert torch.equal(q2, qp) and torch.equal(k2, kp) and torch.equal(v2, vp), cfg
 
     def unpack(buf):   # hi + lo of every packed element, position by position
         h = buf.view(torch.float16).view(-1, 2, 4096 // 2)  # [32-token block of a head][plane][2048 halfs]
@@ -387,3 +481,8 @@ def test_pl_gemm_unpatchify_store_and_operand_row_map(ops):
     ops.unpatchify(ref_rows, ref, 1, T - 1, pt, p)
     assert torch.equal(video[:, :, 0], ref[:, :, 0])          # frame 0 belongs to the other launch
     assert maxerr(video, ref) < 3e-5
+    for cfg in (1, 6):   # 256 x 256 and 256 x 64 tiles (r06) scatter the same pixels
+        v2 = torch.full_like(video, 7.0)
+        ops.linear_pl(planes, wp, M, C * pt * p * p, D, a_scale_const=ops.pl_unscale(bound), bias=bias, epilogue=5, cfg=cfg,
+                      a_rows=((T - 1) * S, T * S, S), unpatch=dict(video=v2, f0=1, t=T - 1, pt=pt, p=p))
+        assert torch.equal(v2, video), cfg

@@ -2,7 +2,8 @@
 """Small-batch latency of encode+decode, eager launches vs one captured HIP graph replay (torch.cuda.CUDAGraph =
 hipGraph on ROCm; asserts that the replay's ids and pixels equal the eager ones).  One 256^2 image: ~2.0 ms either way on
 the MI355X -- the ~170 launches are queued faster than the GPU drains them, so these sizes are bound by kernel latency, not
-by launch overhead; calls below "pl_min_tokens" run the fp32-activation data flow (profiles/r04_small_batch_latency.txt).
+by launch overhead.  Since r06 every call size runs the plane data flow (thin GEMM tiles for small calls); --pl-min-tokens N
+routes calls below N tokens to the fp32-activation flow for A/B (profiles/r06_small_calls.txt).
     python tools/latency.py [--frames 1|17] [--batch 1] [--resolution 256]"""
 import argparse
 import os
@@ -32,7 +33,11 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--pl-min-tokens", type=int, default=None)
     a = ap.parse_args()
+    if a.pl_min_tokens is not None:
+        from omnitokenizer_amd import _lib
+        _lib.set_option("pl_min_tokens", a.pl_min_tokens)
     args = make_args(2, resolution=a.resolution)
     cfg = OmniTokConfig.from_args(args)
     m = OmniTokenizer_VQGAN(args)
