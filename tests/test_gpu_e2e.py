@@ -46,8 +46,9 @@ def assert_ids_match_or_near_tie(ids, ids_ref, z_ours, codebook, name):
     bad = (ids != ids_ref).nonzero().flatten()
     if bad.numel() == 0:
         return 0
-    # allowance: the observed order of magnitude (3 of 163 840 on the full bench batch = 1.8e-5), not a percentage
-    assert bad.numel() <= max(1, ids.numel() // 10000), f"{name}: {bad.numel()} of {ids.numel()} ids differ"
+    # allowance: the observed order of magnitude (2-3 of 163 840 on the full bench batch = 1.8e-5; VERDICT r05: N // 50000), and
+    # every one of them must be a provable near-tie below
+    assert bad.numel() <= max(1, ids.numel() // 50000), f"{name}: {bad.numel()} of {ids.numel()} ids differ"
     z = z_ours.reshape(-1, z_ours.shape[-1]).cpu().double()[bad]
     E = codebook.double()
     d_ours = ((z - E[ids[bad]]) ** 2).sum(1)
