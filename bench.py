@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--frames", type=int, default=17)
     ap.add_argument("--resolution", type=int, default=256)
     ap.add_argument("--n-codes", type=int, default=0, help="codebook size (default: the stage-2 8192; C5: 16384)")
+    ap.add_argument("--stage", type=int, default=2, choices=[1, 2],
+                    help="architecture of the released configurations: 2 = imagenet_k600 (rope, pt = 4; the headline), 1 = imagenet_only "
+                         "(relative-position bias + legacy attention, pt = 2; BASELINE config 1's architecture, images)")
     ap.add_argument("--gemm-mode", type=int, default=2, choices=[0, 1, 2],
                     help="engine GEMM arithmetic: 2 fp16x2 split (default), 1 bf16x3 split, 0 fp32-input MFMA")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=INT",
@@ -93,10 +96,11 @@ def run(a):
         over["n_codes"] = a.n_codes
     if a.frames > 17:
         over["sequence_length"] = a.frames
-    args = make_args(2, **over)
-    cfg = OmniTokConfig.from_args(args)
+    args = make_args(a.stage, **over)
+    att_mode = "legacy" if a.stage == 1 else "sdpa"   # README.md:58: imagenet_only.ckpt runs the legacy attention
+    cfg = OmniTokConfig.from_args(args, attention_mode=att_mode)
     sd = synth.synth_state_dict(cfg, seed=0)
-    model = OmniTokenizer_VQGAN(args)
+    model = OmniTokenizer_VQGAN(args, attention_mode=att_mode)
     model.load_state_dict(sd, strict=True)
     model = model.cuda().eval()
 
@@ -198,7 +202,7 @@ def run(a):
                 pmc_state = (f"stale: profiles/pmc_traffic.json was measured on csrc {str(stamp.get('csrc_sha256'))[:12]} "
                              f"(HEAD {str(stamp.get('git_head'))[:10]}), this tree is {csrc_digest(ROOT)[:12]}")
             elif not (B == 32 and a.frames == 17 and a.resolution == 256 and cfg.n_codes == 8192 and a.gemm_mode == 2
-                      and not a.option):
+                      and a.stage == 2 and not a.option):
                 pmc_state = "the committed PMC passes cover the default C3 command only"
             else:
                 pmc = pj.get(f"gemm_mode_{a.gemm_mode}", {})
@@ -269,8 +273,9 @@ def run(a):
             "gemm_mode": a.gemm_mode, "data": "synthetic",
             "config": {"workload": wl_name + f": B={B}/GPU " + (f"{a.resolution}x{a.resolution} images" if is_image
                                     else f"{a.frames}x{a.resolution}x{a.resolution} clips")
-                                   + f", stage-2 (imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes={cfg.n_codes}), encode + "
-                                   f"{'RCCL id all-gather + ' if world > 1 else ''}decode; {B} distinct clips per rank",
+                                   + (f", stage-2 (imagenet_k600 arch: ttww/tttt, pt=4, rope, n_codes={cfg.n_codes}), encode + " if a.stage == 2 else
+                                      f", stage-1 (imagenet_only arch: ttww/tttt, pt=2, relative-position bias, legacy attention, n_codes={cfg.n_codes}), encode + ")
+                                   + f"{'RCCL id all-gather + ' if world > 1 else ''}decode; {B} distinct clips per rank",
                        "global_batch": n_total, "tokens_per_clip": tokens_per_clip,
                        "parallelism": f"clip-sharded x{world}", **({"options": a.option} if a.option else {})},
             "rccl_world_size": res.world_seen, "ids_crc32": res.ids_crc, "allgather_ms": res.allgather_ms,
@@ -428,7 +433,7 @@ def run(a):
                              "oracle_encode_all_clips_s": round(t_or, 1)}
             parity_ref_ids = ids_ref_all
         # ---- driver-observed extras of the default C3 line ------------------------------
-        if world == 1 and wl_name == "C3" and B == 32 and a.gemm_mode == 2 and not a.option and not a.no_also:
+        if world == 1 and wl_name == "C3" and B == 32 and a.gemm_mode == 2 and a.stage == 2 and not a.option and not a.no_also:
             out["also"] = also_extras(model, x, sd, a, locals().get("parity_ref_ids"))
         print(json.dumps(out), flush=True)
     launch.finish(info, native_timed=bool(a.native_gather))

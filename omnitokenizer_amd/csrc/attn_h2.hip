@@ -153,6 +153,7 @@ struct AttnH2Params {
     float v_bound; const float *v_bound_dev; int v_bound_stride; int seq_per_clip;
     const float *bias_table;  // [(2gh-1)*(2gw-1), heads] or null
     int gh, gw;
+    int lg_gw;   // log2(gw) when the 64-query kernels stage the head's bias table in LDS (gw a power of two >= 8), else -1
     // optional: the output as fp16 hi|lo planes, the A operand of the to_out GEMM (gemm_pl.h), instead of fp32 rows;
     // scaled per clip by the power of two of the V bound (|O| <= max |V|), whose inverse goes to out_scale[row]
     unsigned char *out_planes;
@@ -841,15 +842,31 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 4 ? 2 : 1) void attn_spatial_h
             for (int ks = 0; ks < 4; ++ks)
                 qf[i][pl][ks] = *reinterpret_cast<const u32x4 *>(qb_ + (pl * 4 + ks) * 1024);
     }
-    int qy[2] = {0, 0}, qx[2] = {0, 0};
-    const float *btab = nullptr;
+    // Legacy relative-position bias (reference attention.py:453-483, ContinuousPositionBias :535-583): bias[dy][dx] of THIS head,
+    // (2 gh - 1) x (2 gw - 1) floats, staged ONCE per workgroup in LDS behind the K / V ring (32 x 32 grid: 15.9 KiB).  A score's
+    // bias address is then   table + qpos(lane) - base(t) - c(r)   bytes with
+    //   qpos = the query's (qy + gh - 1, qx + gw - 1) position minus this lane half's 4 key columns   (per lane and query block)
+    //   base = position of the tile's first key (ky, kx)                                             (wave-uniform, per key tile)
+    //   c    = position of accumulator register r's key row inside the tile                           (wave-uniform, 16 scalars)
+    // -- one v_sub and one ds_read_b32 per score.  r02-r05 gathered the table from global memory with a division per score and
+    // 64-bit addresses: the 64-query kernels spilled on it and the bias configurations stayed on the 32-query variant 3.
+    int qpos[2] = {0, 0};
+    int c_r[16];
+    const unsigned char *tabp = smem_h2 + 2 * TILE;
     if constexpr (HAS_BIAS) {
+        const int pitch = 2 * p.gw - 1, P = (2 * p.gh - 1) * pitch;
+        float *tab = reinterpret_cast<float *>(smem_h2 + 2 * TILE);
+        for (int idx = tid; idx < P; idx += 64 * NWAVE) tab[idx] = p.bias_table[(int64_t)idx * p.heads + head];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            qy[i] = q_local[i] / p.gw;
-            qx[i] = q_local[i] % p.gw;
+            const int qy = q_local[i] >> p.lg_gw, qx = q_local[i] & (p.gw - 1);
+            qpos[i] = ((qy + p.gh - 1) * pitch + qx + p.gw - 1 - 4 * hi) * 4;
         }
-        btab = p.bias_table + head;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row8 = 8 * (r >> 2);   // key row of register r inside the 32-key tile, without the lane half's + 4 hi
+            c_r[r] = __builtin_amdgcn_readfirstlane(((row8 >> p.lg_gw) * pitch + (row8 & (p.gw - 1)) + (r & 3)) * 4);
+        }
     }
 
     const unsigned char *kg = p.kp + unit0 * 8192 + wave * 1024 + lane * 16;
@@ -898,13 +915,11 @@ __global__ __launch_bounds__(64 * NWAVE, NWAVE == 4 ? 2 : 1) void attn_spatial_h
                 st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, __builtin_bit_cast(f16x8, qf[i][0][ks]), st, 0, 0, 0);
             }
             if constexpr (HAS_BIAS) {
+                const int k0 = t * 32;
+                const int base_t = __builtin_amdgcn_readfirstlane(((k0 >> p.lg_gw) * (2 * p.gw - 1) + (k0 & (p.gw - 1))) * 4);
+                const unsigned char *tq = tabp + (qpos[i] - base_t);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kv = t * 32 + mfma32_row(r, hi);
-                    const int ky = kv / p.gw, kx = kv % p.gw;
-                    st[r] = fmaf(st[r], p.s_unscale,
-                                 btab[((qy[i] - ky + p.gh - 1) * (2 * p.gw - 1) + (qx[i] - kx + p.gw - 1)) * p.heads]);
-                }
+                for (int r = 0; r < 16; ++r) st[r] = fmaf(st[r], p.s_unscale, *reinterpret_cast<const float *>(tq - c_r[r]));
             }
             return st;
         };
@@ -1286,8 +1301,18 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
     dim3 grid((unsigned)((int64_t)ngrp * p.nqb));
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<false>), AH_LDS_BYTES)) return rc;
     if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2p_kernel<true>), AH_LDS_BYTES)) return rc;
-    // the legacy-bias builds of the 64-query kernels spill registers: the bias path (stage-1 / legacy configurations) stays on variant 3
-    const int variant = (bias_table && g_attn_h2_variant >= 4) ? 3 : g_attn_h2_variant;
+    // legacy bias on the 64-query kernels (variants 4 - 7): the head's table lives in LDS (see attn_spatial_h2w_kernel), which needs
+    // a power-of-two grid width >= 8 (position by shift / mask) and a table of at most 32 KiB (grids up to 32 x 64: two workgroups
+    // per CU keep fitting); anything else -- and variant 7's 512-query form, not built with a bias -- takes variant 3's global gather
+    int lg = -1;
+    if (bias_table && gw >= 8 && (gw & (gw - 1)) == 0 && (int64_t)(2 * gh - 1) * (2 * gw - 1) * 4 <= 32768) {
+        lg = 0;
+        while ((1 << lg) < gw) ++lg;
+    }
+    p.lg_gw = lg;
+    const int bias_lds = lg >= 0 ? (((2 * gh - 1) * (2 * gw - 1) * 4 + 15) & ~15) : 0;
+    int variant = g_attn_h2_variant;
+    if (bias_table && variant >= 4) variant = lg >= 0 ? (variant == 7 ? 6 : variant) : 3;
     if (variant == 7 && N % 512 == 0) {
         p.nqb = N / 512;
         dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
@@ -1295,8 +1320,10 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
     } else if (variant == 6 || variant == 7) {
         p.nqb = (N + 255) / 256;
         dim3 gridw((unsigned)((int64_t)ngrp * p.nqb));
-        if (bias_table) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false, true>), gridw, dim3(256), 2 * 16384, stream, p);
-        else hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false, true>), gridw, dim3(256), 2 * 16384, stream, p);
+        if (bias_table) {
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2w_kernel<true, false, true>), 2 * 16384 + bias_lds)) return rc;
+            hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false, true>), gridw, dim3(256), 2 * 16384 + bias_lds, stream, p);
+        } else hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false, true>), gridw, dim3(256), 2 * 16384, stream, p);
     } else if (variant == 4 || variant == 5) {
         // 256 queries per workgroup
         p.nqb = (N + 255) / 256;
@@ -1304,8 +1331,10 @@ extern "C" int omnitok_attn_spatial_h2_planes(const void *qp, const void *kp, co
         const int lds = 2 * 16384;
         const bool ilv = variant == 4;
         if (bias_table) {
-            if (ilv) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, true>), gridw, dim3(256), lds, stream, p);
-            else hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false>), gridw, dim3(256), lds, stream, p);
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2w_kernel<true, true>), lds + bias_lds)) return rc;
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(attn_spatial_h2w_kernel<true, false>), lds + bias_lds)) return rc;
+            if (ilv) hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, true>), gridw, dim3(256), lds + bias_lds, stream, p);
+            else hipLaunchKernelGGL((attn_spatial_h2w_kernel<true, false>), gridw, dim3(256), lds + bias_lds, stream, p);
         } else {
             if (ilv) hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, true>), gridw, dim3(256), lds, stream, p);
             else hipLaunchKernelGGL((attn_spatial_h2w_kernel<false, false>), gridw, dim3(256), lds, stream, p);

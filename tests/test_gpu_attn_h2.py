@@ -165,6 +165,34 @@ def test_attn_h2_legacy_bias(ops, variant):
     assert maxerr(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("gh,gw", [(16, 16), (32, 32), (8, 16), (16, 8), (16, 12), (64, 32)])
+def test_attn_h2_legacy_bias_grids(ops, variant, gh, gw):
+    """r06: the 64-query kernels (variants 4 - 7) read the legacy relative-position bias (reference attention.py:453-483, 535-583) from
+    a per-head table staged in LDS -- power-of-two grid widths >= 8 with tables up to 32 KiB; other grids (16 x 12: width not a power
+    of two; 64 x 32: 127 x 63 floats > 32 KiB) keep the global gather of variant 3.  Every variant and grid against fp64 with the
+    dense bias of the oracle's ContinuousPositionBias."""
+    c = GoldenCase("s1_legacy_r64_img")
+    p = "encoder.enc_spatial_transformer.layers.0.1.spatial_rel_pos_bias"
+    N = gh * gw
+    Bn, h, d = (1 if N > 1024 else 2), 8, 64
+    full = orc.continuous_position_bias(c.sd, p, gh, gw)                  # h, N, N
+    tab = orc.continuous_position_bias_table(c.sd, p, gh, gw)             # h, 2gh-1, 2gw-1
+    tab_dev = dev(tab.permute(1, 2, 0).reshape(-1, h))
+    q, k, v = rnd(Bn, N, h, d, seed=167), rnd(Bn, N, h, d, seed=168), rnd(Bn, N, h, d, seed=169)
+    qs, ks = rnd(d, seed=170) * 0.1 + 1, rnd(d, seed=171) * 0.1 + 1
+    qp, kp = prepared(q, k, qs, ks, N, False)
+    ref = ref_attention(qp, kp, v, bias=full[None])
+    qd = dev(q.reshape(Bn * N, h * d))
+    kd, vd = dev(k.reshape(Bn * N, h * d)), dev(v.reshape(Bn * N, h * d))
+    packed, bounds = ops.attn_pack(qd, kd, vd, N, h, dev(qs), dev(ks))
+    out = ops.attn_spatial_h2(packed, bounds, Bn, N, h, tab_dev, gh, gw)
+    assert torch.isfinite(out).all()
+    assert maxerr(out, ref) < 2e-5, (variant, gh, gw, maxerr(out, ref))
+    planes, scales = ops.attn_spatial_h2_planes(packed, bounds, Bn, N, h, tab_dev, gh, gw)   # the engine's form: planes out
+    got = ops.pl_unpack_planes(planes, Bn * N, h * d) * scales.double()[:, None]
+    assert maxerr(got, out) <= bounds[2] * 2.0 ** -21
+
+
 def test_attn_h2_per_clip_ranges_and_batch_independence(ops, variant):
     """v of very different magnitude per clip with device-side per-clip bounds: every clip keeps its relative
     accuracy, and a clip's result does not depend on what else is in the batch (bitwise)."""
