@@ -85,6 +85,8 @@ extern int g_vq_screen_split;
 extern int g_lm_wide_u;
 extern int g_lm_balance;
 extern int g_lm_ksliced;
+extern int g_lm_mfma;
+extern int g_lm_mfma_mult;
 extern int g_lm_ks_deep;
 extern int g_lm_attn_short;
 extern int g_lm_attn_waves;
@@ -120,6 +122,8 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "lm_wide_u")) omnitok::g_lm_wide_u = value;
     else if (!strcmp(name, "lm_balance")) omnitok::g_lm_balance = value;
     else if (!strcmp(name, "lm_ksliced")) omnitok::g_lm_ksliced = value;
+    else if (!strcmp(name, "lm_mfma")) omnitok::g_lm_mfma = value;
+    else if (!strcmp(name, "lm_mfma_mult")) omnitok::g_lm_mfma_mult = value;
     else if (!strcmp(name, "lm_ks_deep")) omnitok::g_lm_ks_deep = value;
     else if (!strcmp(name, "lm_attn_short")) omnitok::g_lm_attn_short = value;
     else if (!strcmp(name, "lm_attn_waves")) omnitok::g_lm_attn_waves = value;

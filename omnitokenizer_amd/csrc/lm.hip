@@ -74,6 +74,7 @@ struct LmMerge {
     const int32_t *cache_len;  // [B]
     int n_head, hd, nchunk;
     int chunk;                 // keys per attention chunk (LM_CHUNK, or LM_CHUNK_SHORT for caches of up to 4096 tokens)
+    float *merged = nullptr;   // [B][n_head * hd] scratch: where the multi-stream MFMA path materialises the merged attention output
 };
 
 template <int BQ, int ROWS, int U, int ACT, bool LN, bool XM, int NW>
@@ -890,6 +891,203 @@ __global__ void lm_concat3_kernel(const float *a, const float *b, const float *c
     out[i] = i < n ? a[i] : (i < 2 * n ? b[i - n] : c[i - 2 * n]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-stream decode GEMV on the matrix cores (r06): y[b][n] = act(LN(x_b) . w_n + bias_n) (+ residual) for 4 .. 8 streams in ONE
+// pass over the weights.  The K-sliced VALU kernel above spends, per weight float4, 4 FMAs per stream plus a cross-lane
+// transpose-sum per row and stream: 8 streams cost 1.43 ms per decode step against 0.85 ms for one, although the weight bytes are
+// the same.  Here v_mfma_f32_4x4x1_16B_f32 does the work: 16 independent 4 x 4 outer products per instruction, fp32 in, fp32
+// accumulate -- block b of a lane group holds k = k0 + 4 b + e, so one instruction multiplies 4 weight rows x 16 k by 16 k x 4 streams.
+//   * workgroup = 8 waves = a contiguous slice of the weight rows (grid = a multiple of the CUs: every CU streams the same bytes,
+//     as in lm_gemv_ks_kernel), in quads of 4 rows; lane (blk = lane / 4, r = lane % 4) loads w[row 4 q + r][k0 + 64 c + 4 blk .. + 3]:
+//     256 contiguous bytes per row and instruction.  Wave w owns k in [w K / 8, (w + 1) K / 8) = CH chunks of 64;
+//   * ALL of the workgroup's weights (<= 24 loads of 16 B per lane = 24 KiB per wave) are requested in one burst at the start --
+//     rows beyond the slice are cut off by the buffer descriptor -- and land while the LayerNorm statistics are computed.
+//     (A first form on 16-row v_mfma_f32_16x16x4_f32 tiles kept one 1536-k pass of a 16-row group in flight per wave: with 6 live
+//     rows of 16 per workgroup at N = 1536 it streamed 1.3 TB/s, 2.2 ms per step -- profiles/r06_lm_mfma.txt);
+//   * activations: lane (blk, c) holds x[stream 4 sq + c][the same k] for sq = 0, 1; with a LayerNorm (K = 1536: 24 registers) they
+//     are loaded BEFORE the weights, normalised in registers (two-pass statistics across the workgroup) and kept; without one they
+//     are read chunk by chunk (L2) behind the weights;
+//   * per row quad and stream quad one 4-register accumulator; at the end the 16 k blocks are summed across lanes (4 xor steps),
+//     the 8 waves through LDS in wave order (deterministic), then bias / GELU / residual.
+// Same fp32 products as the VALU kernels, another summation order (tests/test_gpu_lm.py::test_gemv_mfma_path_equals_valu_path).
+constexpr int LMM_NW = 8;
+int g_lm_mfma_mult = 1;  // "lm_mfma_mult": workgroups per CU of lm_gemm4_kernel (at least; more when a slice would exceed QMAX quads)
+// "lm_mfma": 0 (default) = the VALU kernels | 1 = groups of 4 .. 8 streams take lm_gemm4_kernel when K / 512 is 3, 4, 12 or 16.
+// Measured (profiles/r06_lm_mfma.txt): 8 streams 1.73 - 1.83 ms per decode step against 1.42 ms for the VALU kernels -- the one-burst
+// form pays transfer + compute in series (13 - 14 us per GEMV whatever its bytes) where the K-sliced VALU kernel overlaps them, and
+// the merged attention output costs a launch of its own; correct (tests) and kept as an A/B arm, not the default.
+int g_lm_mfma = 0;
+
+template <int ACT, bool LN, int CH, int QMAX>
+__global__ __launch_bounds__(LMM_NW * 64, 2) void lm_gemm4_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                                  const float *__restrict__ bias, const float *residual,
+                                                                  const float *__restrict__ g, const float *__restrict__ beta,
+                                                                  float *y, int B, int N, int K) {
+    static_assert(CH * QMAX <= 24 && (!LN || CH <= 4), "registers: weights in one burst, LayerNorm activations resident");
+    // LDS: [NW * 4 lane rows][QMAX * 4 weight rows][8 streams] partial sums | [NW * 4][8] LayerNorm partials
+    extern __shared__ float mm_lds[];
+    constexpr int NP = LMM_NW * 4;               // partial sums per output: 8 waves x the 4 sixteen-lane rows of a wave
+    float *part = mm_lds, *red = mm_lds + NP * QMAX * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = lane >> 2, r = lane & 3, lrow = lane >> 4;
+    const int r_begin = (int)((int64_t)blockIdx.x * N / gridDim.x), r_end = (int)((int64_t)(blockIdx.x + 1) * N / gridDim.x);
+    const int nrows = r_end - r_begin, Q = (nrows + 3) >> 2;   // <= QMAX by the launcher's grid
+    const int k0 = wave * (CH * 64) + blk * 4;                 // this lane's first k
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    // streams of this lane: r and r + 4 (those beyond B repeat the last one and are never stored)
+    const float *x0 = x + (int64_t)(r < B ? r : B - 1) * K + k0, *x1 = x + (int64_t)(r + 4 < B ? r + 4 : B - 1) * K + k0;
+    // every load of the kernel goes out here, activations and LayerNorm constants first (they are needed first)
+    f32x4v xa[CH][2], gv[LN ? CH : 1], bv[LN ? CH : 1];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        xa[c][0] = *reinterpret_cast<const f32x4v *>(x0 + c * 64);
+        xa[c][1] = *reinterpret_cast<const f32x4v *>(x1 + c * 64);
+        if constexpr (LN) {
+            gv[c] = *reinterpret_cast<const f32x4v *>(g + k0 + c * 64);
+            bv[c] = *reinterpret_cast<const f32x4v *>(beta + k0 + c * 64);
+        }
+    }
+    // weights: rows beyond the workgroup's slice (and whole quads beyond Q) lie outside the descriptor -- zeros, no traffic, no branch
+    const auto w_rs = x3_rsrc(w + (int64_t)r_begin * K, nrows * K * 4);
+    f32x4v wv[QMAX][CH];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+            wv[q][c] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(w_rs, ((q * 4 + r) * K + k0 + c * 64) * 4, 0, 2));
+    __builtin_amdgcn_sched_barrier(0);   // the burst stays a burst: the scheduler otherwise sinks each load to its first use
+    if constexpr (LN) {
+        // two-pass statistics of streams r, r + 4 over all K: the 4 blocks of a 16-lane row by DPP, the 32 rows of the workgroup
+        // through LDS.  lds_barrier (lgkmcnt only): __syncthreads() would drain vmcnt -- the weight burst -- in front of the first one
+        float s[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int sq = 0; sq < 2; ++sq) s[sq] += (xa[c][sq][0] + xa[c][sq][1]) + (xa[c][sq][2] + xa[c][sq][3]);
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+            s[sq] += dpp_f32<0x128>(s[sq]);   // row_ror:8, row_ror:4
+            s[sq] += dpp_f32<0x124>(s[sq]);
+            if ((lane & 12) == 0) red[(wave * 4 + lrow) * 8 + sq * 4 + r] = s[sq];
+        }
+        lds_barrier();
+        float mean[2], rstd[2];
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) t += red[i * 8 + sq * 4 + r];
+            mean[sq] = t / (float)K;
+        }
+        lds_barrier();
+        float qs[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = xa[c][sq][e] - mean[sq];
+                    qs[sq] = fmaf(d, d, qs[sq]);
+                }
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+            qs[sq] += dpp_f32<0x128>(qs[sq]);
+            qs[sq] += dpp_f32<0x124>(qs[sq]);
+            if ((lane & 12) == 0) red[(wave * 4 + lrow) * 8 + sq * 4 + r] = qs[sq];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) {
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NP; ++i) t += red[i * 8 + sq * 4 + r];
+            rstd[sq] = 1.0f / sqrtf(t / (float)K + 1e-5f);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xa[c][sq][e] = (xa[c][sq][e] - mean[sq]) * rstd[sq] * gv[c][e] + bv[c][e];
+    }
+    f32x4v acc[QMAX][2];
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q)
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq) acc[q][sq] = f32x4v{0.0f, 0.0f, 0.0f, 0.0f};
+    // (e before q: consecutive MFMAs go to the 2 QMAX different accumulators, none waits for its predecessor's result;
+    //  quads beyond Q multiply zeros -- cheaper than a branch per pair of MFMAs)
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int q = 0; q < QMAX; ++q)
+#pragma unroll
+                for (int sq = 0; sq < 2; ++sq)
+                    acc[q][sq] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[q][c][e], xa[c][sq][e], acc[q][sq], 0, 0, 0);
+    // acc[q][sq][v] (lane = (blk, c)): row 4 q + v, stream 4 sq + c, partial over the k = 4 blk + e (mod 64) of this wave's slice.
+    // The 4 blocks of each 16-lane row are summed by DPP; the 4 rows of the wave and the 8 waves meet in LDS.
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q)
+#pragma unroll
+        for (int sq = 0; sq < 2; ++sq)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                float t = acc[q][sq][v];
+                t += dpp_f32<0x128>(t);
+                t += dpp_f32<0x124>(t);
+                if ((lane & 12) == 0) part[((wave * 4 + lrow) * QMAX * 4 + q * 4 + v) * 8 + sq * 4 + r] = t;
+            }
+    lds_barrier();
+    for (int o = tid; o < Q * 32; o += LMM_NW * 64) {
+        const int row = o >> 3, st = o & 7, n = r_begin + row;
+        float v = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v += part[i * QMAX * 32 + o];
+        if (st < B && n < r_end) {
+            if (bias) v += bias[n];
+            if (ACT == 1) v = gelu_erf(v);
+            if (residual) v += residual[(int64_t)st * N + n];
+            y[(int64_t)st * N + n] = v;
+        }
+    }
+}
+
+template <int ACT, bool LN, int CH, int QMAX>
+static void launch_gemm4_cfg(const float *x, const float *w, const float *bias, const float *residual, const float *g, const float *beta,
+                             float *y, int B, int N, int K, hipStream_t stream) {
+    int n_cu = 256;
+    (void)current_device_cus(&n_cu);
+    const int per = QMAX * 4;                               // rows a workgroup can own
+    int mult = g_lm_mfma_mult > 1 ? g_lm_mfma_mult : 1;
+    while ((int64_t)n_cu * mult * per < (int64_t)N + n_cu * mult) ++mult;   // ceil(N / grid) <= per
+    int grid = n_cu * mult;
+    if (grid > N) grid = N;
+    hipLaunchKernelGGL((lm_gemm4_kernel<ACT, LN, CH, QMAX>), dim3(grid), dim3(LMM_NW * 64), (LMM_NW * 4 * QMAX * 32 + LMM_NW * 4 * 8) * 4, stream,
+                       x, w, bias, residual, g, beta, y, B, N, K);
+}
+
+// K / 512 chunks of 64 k per wave: 3 (K = 1536), 4 (2048), 12 (6144), 16 (8192); false: no MFMA form for this call
+template <int ACT, bool LN>
+static bool launch_gemm4(const float *x, const float *w, const float *bias, const float *residual, const float *g, const float *beta,
+                         float *y, int B, int N, int K, hipStream_t stream) {
+    switch (K) {
+        case 1536: launch_gemm4_cfg<ACT, LN, 3, 8>(x, w, bias, residual, g, beta, y, B, N, K, stream); return true;
+        case 2048: launch_gemm4_cfg<ACT, LN, 4, 6>(x, w, bias, residual, g, beta, y, B, N, K, stream); return true;
+        default: break;
+    }
+    if constexpr (!LN) {   // (the wide inputs -- FC2's 4 C -- carry no LayerNorm)
+        switch (K) {
+            case 6144: launch_gemm4_cfg<ACT, false, 12, 2>(x, w, bias, residual, g, beta, y, B, N, K, stream); return true;
+            case 8192: launch_gemm4_cfg<ACT, false, 16, 1>(x, w, bias, residual, g, beta, y, B, N, K, stream); return true;
+            default: break;
+        }
+    }
+    return false;
+}
+
 int g_lm_attn_waves = 8;  // "lm_attn_waves": 8 = a wave owns 32 keys of the 256-key chunk (one batch of loads) | 4 = 64 keys, two batches
 int g_lm_attn_short = 1;  // "lm_attn_short": 1 = 128-key attention chunks for caches of up to 4096 tokens (read at omnitok_lm_alloc_cache) | 0 = 256
 int g_lm_ks_deep = 0;   // "lm_ks_deep": weights in flight per wave of the K-sliced GEMV: 1 = 16 KiB | 0 = 8 KiB
@@ -1007,9 +1205,30 @@ static int lm_gemv_any(const float *x, const float *w, const float *bias, const 
                        const float *beta, float *y, int B, int N, int K, int act, const LmMerge *mg, hipStream_t stream) {
     for (int b0 = 0; b0 < B;) {
         const int left = B - b0;
-        const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
         const float *xb = x ? x + (int64_t)b0 * K : nullptr, *rb = residual ? residual + (int64_t)b0 * N : nullptr;
         float *yb = y + (int64_t)b0 * N;
+        const bool mfma_k = K == 1536 || K == 2048 || (!g && (K == 6144 || K == 8192));
+        if (g_lm_mfma && left >= 4 && mfma_k && N >= 16 && (int64_t)N * K < (1ll << 29) && (!mg || mg->merged)) {
+            // 4 .. 8 streams in one pass over the weights on the matrix cores (lm_gemm4_kernel)
+            const int bq = left > 8 ? 8 : left;
+            if (mg) {   // the merged attention output as a tensor first (the VALU path merges inside its prologue)
+                hipLaunchKernelGGL(lm_attn_merge_kernel, dim3(mg->n_head, bq), dim3(128), 0, stream,
+                                   mg->part + (int64_t)b0 * mg->n_head * mg->nchunk * (2 + mg->hd), mg->cache_len + b0, mg->n_head, mg->hd,
+                                   mg->nchunk, 0, mg->merged + (int64_t)b0 * K, mg->chunk);
+                xb = mg->merged + (int64_t)b0 * K;
+            }
+            bool ok;
+            if (g) ok = act ? launch_gemm4<1, true>(xb, w, bias, rb, g, beta, yb, bq, N, K, stream)
+                            : launch_gemm4<0, true>(xb, w, bias, rb, g, beta, yb, bq, N, K, stream);
+            else ok = act ? launch_gemm4<1, false>(xb, w, bias, rb, g, beta, yb, bq, N, K, stream)
+                          : launch_gemm4<0, false>(xb, w, bias, rb, g, beta, yb, bq, N, K, stream);
+            if (ok) {
+                OT_LAUNCH_CHECK("lm_gemm4");
+                b0 += bq;
+                continue;
+            }
+        }
+        const int bq = left >= 8 ? 8 : (left >= 4 ? 4 : (left >= 2 ? 2 : 1));
         LmMerge m2{nullptr, nullptr, 0, 0, 0, LM_CHUNK};
         if (mg) {
             m2 = *mg;
@@ -1347,7 +1566,7 @@ extern "C" int omnitok_lm_step_ex(omnitok_lm *lm, const int64_t *idx, const floa
         if (int rc = lm_attn_partials(lm->qkv, kc, vc, cache_len, B, c.n_head, hd, lm->max_len, lm->part, stream, 0,
                                       lm->err_flag, lm->chunk))
             return rc;
-        const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + lm->chunk - 1) / lm->chunk, lm->chunk};
+        const LmMerge mg{lm->part, cache_len, c.n_head, hd, (lm->max_len + lm->chunk - 1) / lm->chunk, lm->chunk, lm->qkv};   // (qkv is free once the partials exist)
         if (int rc = lm_gemv_any(nullptr, L.wproj, L.bproj, lm->x, nullptr, nullptr, lm->x, B, C, C, 0, &mg, stream))
             return rc;
         // x + mlp(ln2(x))          (reference gpt.py:162, 150-155)

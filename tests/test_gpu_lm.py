@@ -94,6 +94,7 @@ def test_gemv_forms_agree(lib, B, N, K):
     s = torch.cuda.current_stream().cuda_stream
     out = {}
     try:
+        _lib.set_option("lm_mfma", 0)   # (the default; with 1, groups of >= 4 streams take the MFMA kernel whatever "lm_ksliced" says)
         for form in (2, 0):
             _lib.set_option("lm_ksliced", form)
             y = torch.empty(B, N, device="cuda")
@@ -103,6 +104,42 @@ def test_gemv_forms_agree(lib, B, N, K):
         _lib.set_option("lm_ksliced", 2)
     assert not torch.equal(out[0], out[2])  # the option is live
     assert float((out[0] - out[2]).abs().max()) < 1e-5 * math.sqrt(K / 1536)
+
+
+@pytest.mark.parametrize("B", [4, 7, 8, 13, 16])
+@pytest.mark.parametrize("N,K", [(1536, 1536), (4608, 1536), (1536, 6144), (8192, 1536), (1000, 1536), (20000, 1536), (2048, 2048), (1000, 8192),
+                                 (4000, 6144)])
+def test_gemv_mfma_path_equals_valu_path(lib, B, N, K):
+    """r06: with "lm_mfma" 1 groups of 4 .. 8 streams take the fp32-MFMA kernel (lm_gemm4_kernel) -- one pass over the weights for all
+    of them; the VALU kernels ("lm_mfma" 0, the default: faster, profiles/r06_lm_mfma.txt) serve the same call in groups of 8 / 4 / 2 / 1.  Same fp32 products, another summation
+    order: both within the GEMV tolerance of torch and of each other, for every prologue / epilogue form the decode step uses."""
+    from omnitokenizer_amd import _lib
+    x, w, bias, res = rnd(B, K, seed=11), rnd(N, K, seed=12, scale=0.05), rnd(N, seed=13), rnd(B, N, seed=14)
+    g, beta = rnd(K, seed=15, scale=0.1) + 1.0, rnd(K, seed=16, scale=0.1)
+    s = torch.cuda.current_stream().cuda_stream
+    xd, wd, bd, rd, gd, betad = (t.cuda() for t in (x, w, bias, res, g, beta))
+    tol = 2e-5 * math.sqrt(K / 1536)
+    refs = {"plain": F.linear(x, w, bias), "ln_gelu": F.gelu(F.linear(F.layer_norm(x, (K,), g, beta), w, bias)),
+            "residual": F.linear(x, w) + res}
+    outs = {}
+    try:
+        for mode in (1, 0):
+            _lib.set_option("lm_mfma", mode)
+            y = torch.empty(B, N, device="cuda")
+            assert lib.omnitok_lm_gemv(_p(xd), _p(wd), _p(bd), None, None, None, _p(y), B, N, K, 0, s) == 0
+            outs[mode, "plain"] = y.clone()
+            assert lib.omnitok_lm_gemv(_p(xd), _p(wd), _p(bd), None, _p(gd), _p(betad), _p(y), B, N, K, 1, s) == 0
+            outs[mode, "ln_gelu"] = y.clone()
+            y = rd.clone()
+            assert lib.omnitok_lm_gemv(_p(xd), _p(wd), None, _p(y), None, None, _p(y), B, N, K, 0, s) == 0
+            outs[mode, "residual"] = y.clone()
+    finally:
+        _lib.set_option("lm_mfma", 0)
+    for form, ref in refs.items():
+        for mode in (1, 0):
+            assert (outs[mode, form].cpu() - ref).abs().max().item() < tol, (form, mode)
+        assert (outs[1, form] - outs[0, form]).abs().max().item() < tol, form
+    assert not torch.equal(outs[1, "plain"], outs[0, "plain"])   # the option is live (another summation order)
 
 
 @pytest.fixture(scope="module")
