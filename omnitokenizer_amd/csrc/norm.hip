@@ -375,8 +375,11 @@ struct SpArgs {
 };
 enum { SP_PLAIN = 0, SP_WINDOWS = 1, SP_LAYERNORM = 2, SP_TEMPORAL = 3 };
 
-template <int H, int MODE>
+// RW = rows per wave: 16 (a workgroup = one 64-row plane block), or 4 for small calls (r06: a workgroup = 16 rows, four times the
+// workgroups -- one image's 1024 rows are 64 workgroups instead of 16, each a quarter as long; every row's arithmetic is the same)
+template <int H, int MODE, int RW = 16>
 __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
+    constexpr int CST = RW * 16 + 16;  // LDS stride of an RW-row chunk column (16 B pad: bank spread)
     extern __shared__ __attribute__((aligned(16))) unsigned char sp_lds[];
     constexpr int K = 256 * H;
     const float *__restrict__ x = a.x;
@@ -388,11 +391,11 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
     float *__restrict__ stats = a.stats;
     const int win_gh = a.win_gh, win_gw = a.win_gw, win_ws = a.win_ws;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t row0 = (int64_t)blockIdx.x * 64 + wave * 16;
-    unsigned char *lds = sp_lds + wave * (2 * 32 * SP_CSTRIDE);  // [plane][32 chunks][16 rows][16 B] (padded)
-    f32x4 v[16][H];
+    const int64_t row0 = (int64_t)blockIdx.x * (4 * RW) + wave * RW;
+    unsigned char *lds = sp_lds + wave * (2 * 32 * CST);  // [plane][32 chunks][RW rows][16 B] (padded)
+    f32x4 v[RW][H];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < RW; ++r) {
         const int64_t row = row0 + r;
         int64_t src = row < rows ? row : rows - 1;
         bool pad = row >= rows;
@@ -427,9 +430,9 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
             lb[h] = a.ln_b ? reinterpret_cast<const f32x4 *>(a.ln_b)[lane + 64 * h] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
         }
     }
-    float scl[16];
+    float scl[RW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < RW; ++r) {
         float s = 0.0f, mx = 0.0f;
 #pragma unroll
         for (int h = 0; h < H; ++h) s += (v[r][h][0] + v[r][h][1]) + (v[r][h][2] + v[r][h][3]);
@@ -472,25 +475,25 @@ __global__ __launch_bounds__(256, 2) void stats_pack_kernel(SpArgs a) {
     for (int h = 0; h < H; ++h) {
         // this half's 32 chunks of 8 k: lane pair (2 j, 2 j + 1) holds chunk j
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < RW; ++r) {
             const f32x4 t = v[r][h] * scl[r];  // exact (power of two)
             const f16x4 hh = __builtin_convertvector(t, f16x4);
             const f16x4 ll = __builtin_convertvector(t - __builtin_convertvector(hh, f32x4), f16x4);
-            unsigned char *dst = lds + (lane >> 1) * SP_CSTRIDE + r * 16 + (lane & 1) * 8;
+            unsigned char *dst = lds + (lane >> 1) * CST + r * 16 + (lane & 1) * 8;
             *reinterpret_cast<u32x2 *>(dst) = __builtin_bit_cast(u32x2, hh);
-            *reinterpret_cast<u32x2 *>(dst + 32 * SP_CSTRIDE) = __builtin_bit_cast(u32x2, ll);
+            *reinterpret_cast<u32x2 *>(dst + 32 * CST) = __builtin_bit_cast(u32x2, ll);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the wave's own LDS writes (no other wave touches this region)
         __builtin_amdgcn_wave_barrier();
-        // stores: lane -> (chunk column cc = lane / 16, row r = lane % 16); 4 chunk columns per instruction
-        const int cc = lane >> 4, r = lane & 15;
+        // stores: lane -> (chunk column cc = lane / RW, row r = lane % RW); 64 / RW chunk columns per instruction
+        const int cc = lane / RW, r = lane % RW;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int c0 = 0; c0 < 32; c0 += 4) {
+            for (int c0 = 0; c0 < 32; c0 += 64 / RW) {
                 const int c = c0 + cc;             // chunk inside this half
                 const int cg = h * 32 + c;         // chunk of the row: k block cg / 4, k group cg % 4
-                const u32x4 w = *reinterpret_cast<const u32x4 *>(lds + (p * 32 + c) * SP_CSTRIDE + r * 16);
+                const u32x4 w = *reinterpret_cast<const u32x4 *>(lds + (p * 32 + c) * CST + r * 16);
                 *reinterpret_cast<u32x4 *>(planes + pl_chunk_offset(row0 + r, cg >> 2, cg & 3, kblocks) + p * 4096) = w;
             }
         __builtin_amdgcn_wave_barrier();
@@ -608,12 +611,20 @@ template <int MODE>
 static int stats_pack_launch(SpArgs a, int dim, int64_t m_pad, hipStream_t stream) {
     OT_CHECK_ARG(dim > 0 && dim % 256 == 0 && dim <= 1024, "stats_pack: dim=%d (multiples of 256 up to 1024)", dim);
     if (m_pad == 0) return OMNITOK_OK;
-    const int lds = 4 * 2 * 32 * SP_CSTRIDE;
-    const dim3 grid((unsigned)(m_pad / 64));
-#define OT_SP(Hh)                                                                                                      \
-    do {                                                                                                               \
-        if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh, MODE>), lds)) return rc; \
-        hipLaunchKernelGGL((stats_pack_kernel<Hh, MODE>), grid, dim3(256), lds, stream, a);                            \
+    // small calls: 4 rows per wave (16-row workgroups) while 64-row workgroups would leave CUs without one
+    int n_cu = 256;
+    (void)current_device_cus(&n_cu);
+    const bool small = m_pad / 64 < 2 * n_cu;
+    const int lds = small ? 4 * 2 * 32 * (4 * 16 + 16) : 4 * 2 * 32 * SP_CSTRIDE;
+    const dim3 grid((unsigned)(small ? m_pad / 16 : m_pad / 64));
+#define OT_SP(Hh)                                                                                                          \
+    do {                                                                                                                   \
+        if (small) {                                                                                                       \
+            hipLaunchKernelGGL((stats_pack_kernel<Hh, MODE, 4>), grid, dim3(256), lds, stream, a);                         \
+        } else {                                                                                                           \
+            if (int rc = set_max_dynamic_lds(reinterpret_cast<const void *>(stats_pack_kernel<Hh, MODE>), lds)) return rc; \
+            hipLaunchKernelGGL((stats_pack_kernel<Hh, MODE>), grid, dim3(256), lds, stream, a);                            \
+        }                                                                                                                  \
     } while (0)
     switch (dim / 256) {
         case 1: OT_SP(1); break;
