@@ -77,6 +77,7 @@ extern int g_temporal_kernel;
 extern int g_qkv_pl;
 extern int g_attn_window_mode;
 extern int g_pl_cfg;
+extern int g_sp_small_blocks;
 extern int g_pl_tail;
 extern int g_pl_stagger;
 extern int g_vq_variant;
@@ -116,6 +117,7 @@ extern "C" int omnitok_set_option(const char *name, int value) {
     else if (!strcmp(name, "temporal_kernel")) omnitok::g_temporal_kernel = value;
     else if (!strcmp(name, "pl_cfg")) omnitok::g_pl_cfg = value;
     else if (!strcmp(name, "pl_tail")) omnitok::g_pl_tail = value;
+    else if (!strcmp(name, "sp_small_blocks")) omnitok::g_sp_small_blocks = value;
     else if (!strcmp(name, "pl_stagger")) omnitok::g_pl_stagger = value;
     else if (!strcmp(name, "qkv_pl")) omnitok::g_qkv_pl = value;
     else if (!strcmp(name, "attn_window_mode")) omnitok::g_attn_window_mode = value;

@@ -607,14 +607,18 @@ extern "C" int omnitok_stats_pack_windows(const float *x, int64_t rows, int dim,
     return stats_pack_impl(x, rows, dim, eps, center, planes, m_pad, a_scale, stats, nullptr, 0, gh, gw, ws, stream_);
 }
 
+namespace omnitok {
+int g_sp_small_blocks = 0;  // "sp_small_blocks": 0 = stats_pack in its 4-rows-per-wave form at every size | n: only below n 64-row blocks
+}  // namespace omnitok
+
 template <int MODE>
 static int stats_pack_launch(SpArgs a, int dim, int64_t m_pad, hipStream_t stream) {
     OT_CHECK_ARG(dim > 0 && dim % 256 == 0 && dim <= 1024, "stats_pack: dim=%d (multiples of 256 up to 1024)", dim);
     if (m_pad == 0) return OMNITOK_OK;
-    // small calls: 4 rows per wave (16-row workgroups) while 64-row workgroups would leave CUs without one
-    int n_cu = 256;
-    (void)current_device_cus(&n_cu);
-    const bool small = m_pad / 64 < 2 * n_cu;
+    // 4 rows per wave (16-row workgroups) at every size since r06: written for small calls (one image: 19 -> 9 us per launch), it also
+    // wins where 64-row workgroups make ragged rounds -- 8 clips 0.84 -> 0.54 ms per step, C5 1.30 -> 1.00, C3 2.15 -> 1.89
+    // (profiles/r06_small_calls.txt).  "sp_small_blocks" n > 0: only below n 64-row blocks (1 = the 16-rows-per-wave form everywhere).
+    const bool small = g_sp_small_blocks > 0 ? m_pad / 64 < g_sp_small_blocks : true;
     const int lds = small ? 4 * 2 * 32 * (4 * 16 + 16) : 4 * 2 * 32 * SP_CSTRIDE;
     const dim3 grid((unsigned)(small ? m_pad / 16 : m_pad / 64));
 #define OT_SP(Hh)                                                                                                          \
