@@ -142,9 +142,16 @@ __device__ __forceinline__ void pl_wait_steps(int ahead) {
 // Wave tile = NI x MI accumulator blocks of 32 x 32 (n x m): 2 x 4 at two waves per SIMD (256 registers), 4 x 4 at one
 // wave per SIMD (512 registers; a third fewer fragment bytes read from LDS per MFMA -- the kernel is power-bound, so
 // bytes moved per flop, not stalls, set its rate: profiles/r03_pl_ablation.txt).
-template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4>
+// LOOP_ = 1 (r06, thin wave tiles, ONE tile per workgroup): a K loop built for a wave tile with 2-MFMA groups.  Ablation of the
+// default loop on the 128 x 64 tile (profiles/r06_pl_small_tiles.txt): 930 cycles per K step, of which MFMAs + fragment reads alone
+// are 570 (192 cycles of matrix issue + two exposed LDS round trips: the default loop hides them behind 8-MFMA groups), the DMA
+// issue 220, waits and barrier the rest.  Here step s + 1's fragments are ALL read right behind the barrier, under step s's MFMAs
+// (two register sets, loop unrolled by two), and the DMA of step s + R -- into the stage step s just vacated, so the ring runs
+// R - 1 steps ahead with the same LDS -- is spread over the MFMA gaps.  Same products in the same order per accumulator.
+template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4, int LOOP_ = 0>
 struct PlCfg {
-    static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_;
+    static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_, LOOP = LOOP_;
+    static_assert(LOOP_ == 0 || (DBG_ == 0 && NI_ * MI_ <= 4 && R_ >= 3), "the pipelined loop is for thin wave tiles (fragment double buffer: registers)");
     static constexpr int NW = WN * WM, NT = 64 * NW;
     static constexpr int TN = 32 * NI * WN, TM = 32 * MI * WM;
     static constexpr int WPS = NW > 4 ? 2 : 1;  // waves per SIMD of one workgroup
@@ -318,13 +325,19 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
     d_set_tile(0);
     dma_step();
 #pragma unroll
-    for (int d = 1; d < D; ++d)
+    for (int d = 1; d < (C::LOOP == 1 ? R : D); ++d)   // LOOP 1: every stage is filled, the cursor then runs R steps ahead
         if (total > d) dma_step();
     int st = 0;  // stage of the current step
     PL_WAIT_VM(0);
     __builtin_amdgcn_s_barrier();
     rdA(X, 0, 0);
     rdW(Pl, 0, 1);
+    // LOOP == 1: second fragment set (the loop alternates between the two) and the rest of step 0's fragments
+    u32x4 X2[MI], Y2[MI], Ph2[NI], Pl2[NI];
+    if constexpr (C::LOOP == 1) {
+        rdW(Ph, 0, 0);
+        rdA(Y, 0, 1);
+    }
 
     for (int ti = 0; ti < my_tiles; ++ti) {
         // PL_GEGLU: the tile's per-row operand scales and the wave's 64 weight-row scales (one per lane) are requested HERE,
@@ -393,6 +406,72 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                 for (int q = 0; q < 10; ++q) pt_p[q] = *reinterpret_cast<const f32x4 *>(pp + q * 4);
             }
         }
+        if constexpr (C::LOOP == 1) {
+            // pipelined loop: [step s + 1 landed: vmcnt, barrier] [read ALL fragments of s + 1] [MFMAs of s, the DMA pieces of step
+            // s + R (into the stage s came from) in their gaps]
+            auto kstep = [&](u32x4 (&cX)[MI], u32x4 (&cY)[MI], u32x4 (&cPh)[NI], u32x4 (&cPl)[NI], u32x4 (&nX)[MI], u32x4 (&nY)[MI],
+                             u32x4 (&nPh)[NI], u32x4 (&nPl)[NI], int s) {
+                const int st1 = st + 1 == R ? 0 : st + 1;
+                {   // steps s + 2 .. min(s + R - 1, total - 1) may stay in flight
+                    const int ahead = total - 2 - s;
+                    if (full)
+                        pl_wait_steps<PPW, R - 2>(ahead);
+                    else
+                        pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), R - 2>(ahead);
+                }
+                lds_barrier();
+                if (s + 1 < total) {
+                    rdA(nX, st1, 0);
+                    rdW(nPl, st1, 1);
+                    rdW(nPh, st1, 0);
+                    rdA(nY, st1, 1);
+                }
+                const bool more = s + R < total;   // wave-uniform; the cursor stands on step s + R, stage == st
+                unsigned koff = 0;
+                const unsigned char *ca = d_a, *cw = d_w;
+                const int cst = d_stage;
+                if (more) koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
+                constexpr int HOOKS = 3 * SLOTS, PPH = (PPW + HOOKS - 1) / HOOKS;
+                auto dma_hook = [&](int h) {
+#pragma unroll
+                    for (int u = 0; u < PPH; ++u) {
+                        const int j = PPH * h + u;
+                        if (more && j < PPW && piece_live(j)) {
+                            const unsigned char *src = (p_is_w[j] ? cw : ca) + koff + pv_off[j];
+                            __builtin_amdgcn_global_load_lds((pl_glob_t *)src, (pl_lds_t *)(pl_smem + cst * C::STAGE + pl_dst[j]), 16, 0, 0);
+                        }
+                    }
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                group(cPl, cX, [&](int i) { dma_hook(i); });               // W lo . A hi
+                group(cPh, cX, [&](int i) { dma_hook(SLOTS + i); });       // W hi . A hi
+                group(cPh, cY, [&](int i) { dma_hook(2 * SLOTS + i); });   // W hi . A lo
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) {
+                    d_stage = d_stage + 1 == R ? 0 : d_stage + 1;
+                    if (++d_k == nk && d_tile + 1 < my_tiles) d_set_tile(d_tile + 1);
+                }
+                st = st1;
+            };
+            int k = 0;
+            for (; k + 1 < nk; k += 2) {
+                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k);
+                kstep(X2, Y2, Ph2, Pl2, X, Y, Ph, Pl, ti * nk + k + 1);
+            }
+            if (k < nk) {   // odd step count: the next tile starts from the first set again
+                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    X[mi] = X2[mi];
+                    Y[mi] = Y2[mi];
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    Ph[ni] = Ph2[ni];
+                    Pl[ni] = Pl2[ni];
+                }
+            }
+        } else
         for (int k = 0; k < nk; ++k) {
             const int s = ti * nk + k;
             const bool more = (DBG & 4) ? false : s + D < total;  // wave-uniform

@@ -112,12 +112,12 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     p.gn = g_gemm_gn > 0 ? g_gemm_gn : 8;
     p.stagger = g_pl_stagger;
     int wg_per_cu = (160 * 1024) / LDS;
-    const int by_waves = (C::NI * C::MI > 8) ? 1 : (C::NI * C::MI <= 2 ? 16 : 8) / C::NW;
+    const int by_waves = (C::NI * C::MI > 8) ? 1 : (C::NI * C::MI <= 2 ? 16 : 8) / C::NW;   // (only decides persistent vs one tile per workgroup)
     if (wg_per_cu > by_waves) wg_per_cu = by_waves;
     if (wg_per_cu < 1) wg_per_cu = 1;
     // two small workgroups per CU: one tile each (the hardware dispatcher overlaps one's epilogue with the other's K loop);
     // one big workgroup per CU: persistent
-    const int64_t cap = wg_per_cu > 1 ? nt : (int64_t)n_cu;
+    const int64_t cap = (wg_per_cu > 1 || C::LOOP == 1) ? nt : (int64_t)n_cu;   // (the pipelined loop is a one-tile-per-workgroup loop)
     const int grid = (int)(nt < cap ? nt : cap);
     hipLaunchKernelGGL((gemm_pl_kernel<EPI, SWAP, C>), dim3(grid), dim3(C::NT), LDS, stream, p);
     OT_LAUNCH_CHECK("gemm_pl");
@@ -143,6 +143,20 @@ using PlBig = PlCfg<4, 2, 4>;
 // group to cover an LDS round trip with, co-resident workgroups are what hides it, not prefetch distance.
 using PlMid = PlCfg<2, 2, 4, 2, 0, 2, 2>;      // 128 x 128
 using PlSmall = PlCfg<2, 2, 4, 2, 0, 2, 1>;    // 128 x  64
+// Closed by measurement this round (profiles/r06_pl_small_tiles.txt; the arms stay in measurement builds, -DOMNITOK_PL_MEASUREMENT_BUILDS):
+//  * a lone 128 x 64 workgroup runs its K loop at ~900 cycles per 16-k step for 192 cycles of MFMA issue.  Ablation: MFMAs + fragment
+//    reads alone 570, DMA issue 220, waits + barrier the rest.  Neither a deeper ring (DMA 4 / 6 steps ahead: arms 9 / 8), nor a loop
+//    that reads all of step s + 1's fragments under step s's MFMAs and spreads the DMA of step s + R over their gaps (PlCfg LOOP_ = 1:
+//    arms 35 / 36), nor smaller tiles that give every CU a workgroup (128 x 32, 64 x 32: arms 10 / 11) moved a 1024-row launch by more
+//    than 5 % -- all bit-identical, none faster.  What does help a thin tile is a second / third workgroup on its CU.
+#ifdef OMNITOK_PL_MEASUREMENT_BUILDS
+using PlMidD = PlCfg<2, 2, 6, 4, 0, 2, 2, 1>;
+using PlSmallD = PlCfg<2, 2, 8, 6, 0, 2, 1, 1>;
+using PlMid1 = PlCfg<2, 2, 4, 2, 0, 2, 2, 1>;
+using PlSmall1 = PlCfg<2, 2, 4, 2, 0, 2, 1, 1>;
+using PlTiny = PlCfg<2, 1, 4, 2, 0, 2, 1>;     // 128 x 32, two waves
+using PlTiny64 = PlCfg<1, 1, 4, 2, 0, 2, 1>;   //  64 x 32, one wave
+#endif
 
 // Which configuration(s) a launch takes (results do not depend on it).  From the sweeps in profiles/r06_pl_small_tiles.txt:
 //  * 256 x 256 tiles win once they fill >= 3/4 of the CUs; below that 128 x 128 while there are >= n_cu of those, else 128 x 64
@@ -226,13 +240,25 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
             case 2: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 3>>(p, stream);
             case 5: return launch_pl_cfg<EPI, false, PlMid>(p, stream);
             case 6: return launch_pl_cfg<EPI, false, PlSmall>(p, stream);
-#ifdef OMNITOK_PL_MEASUREMENT_BUILDS  // wrong-result ablation builds of profiles/r03_gemm_limiter_probe.txt
+#ifdef OMNITOK_PL_MEASUREMENT_BUILDS
+            case 10: return launch_pl_cfg<EPI, false, PlTiny>(p, stream);
+            case 11: return launch_pl_cfg<EPI, false, PlTiny64>(p, stream);
+            case 8: return launch_pl_cfg<EPI, false, PlSmallD>(p, stream);
+            case 9: return launch_pl_cfg<EPI, false, PlMidD>(p, stream);
+            case 35: return launch_pl_cfg<EPI, false, PlMid1>(p, stream);
+            case 36: return launch_pl_cfg<EPI, false, PlSmall1>(p, stream);
+            case 21: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 1, 2, 1>>(p, stream);   // 128 x 64: no vmcnt wait
+            case 22: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 2, 2, 1>>(p, stream);   // no barrier
+            case 23: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 3, 2, 1>>(p, stream);   // neither
+            case 24: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 2, 1>>(p, stream);   // no DMA in the K loop
+            case 27: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 7, 2, 1>>(p, stream);   // MFMAs + fragment reads only
+            case 28: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 8, 2, 1>>(p, stream);   // no epilogue  // wrong-result ablation builds of profiles/r03_gemm_limiter_probe.txt
             case 3: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3>>(p, stream);
             case 4: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 0, 4, 4>>(p, stream);
-            case 11: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 1>>(p, stream);
+            case 31: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 1>>(p, stream);
             case 13: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 3>>(p, stream);
             case 14: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 4, 4, 4>>(p, stream);
-            case 15: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
+            case 33: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 5>>(p, stream);
             case 17: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 3, 7>>(p, stream);
             case 18: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 8>>(p, stream);
             case 19: return launch_pl_cfg<EPI, false, PlCfg<4, 2, 4, 2, 16>>(p, stream);

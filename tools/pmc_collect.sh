@@ -4,7 +4,7 @@
 # from, then tools/pmc_to_json.py turns the per-kernel means into profiles/pmc_traffic.json stamped with the sha256 of
 # the csrc/ tree the library was built from.  bash tools/pmc_collect.sh <tag> [bench args...]
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 cd /tmp; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out; mkdir -p $OUT
 BENCH="python bench.py --no-cpu-baseline --no-clock-probe --no-also --steps 1 --warmup 1 $*"
