@@ -148,10 +148,18 @@ __device__ __forceinline__ void pl_wait_steps(int ahead) {
 // issue 220, waits and barrier the rest.  Here step s + 1's fragments are ALL read right behind the barrier, under step s's MFMAs
 // (two register sets, loop unrolled by two), and the DMA of step s + R -- into the stage step s just vacated, so the ring runs
 // R - 1 steps ahead with the same LDS -- is spread over the MFMA gaps.  Same products in the same order per accumulator.
+// LOOP_ = 3 (r06, thin tiles, one tile per workgroup): the operands travel global -> REGISTERS -> LDS instead of by LDS-DMA.  Every
+// restructuring of the LDS-DMA loop measured the same ~900 cycles per K step for a lone thin workgroup, whatever the ring depth: a
+// wave keeps only a few global_load_lds in flight (6 pieces = 6 KiB per wave at two steps of prefetch; issuing more steps ahead did
+// not raise it), so one CU fetches ~24 KiB per memory round trip (~25 - 30 GB/s) and the K loop waits for memory.  Plain
+// global_load_dwordx4 into registers has the full vmcnt depth: D steps (D x PPW x 16 B per lane) are in flight per wave, written to
+// a two-stage LDS ring one step ahead of their use.  Same pieces, same LDS image, same fragment reads, same MFMA order: same bits.
 template <int WN_, int WM_, int R_, int D_ = 2, int DBG_ = 0, int NI_ = 2, int MI_ = 4, int LOOP_ = 0>
 struct PlCfg {
     static constexpr int WN = WN_, WM = WM_, R = R_, D = D_, DBG = DBG_, NI = NI_, MI = MI_, LOOP = LOOP_;
-    static_assert(LOOP_ == 0 || (DBG_ == 0 && NI_ * MI_ <= 4 && R_ >= 3), "the pipelined loop is for thin wave tiles (fragment double buffer: registers)");
+    static_assert(LOOP_ == 0 || LOOP_ == 3 || (DBG_ == 0 && NI_ * MI_ <= 4 && R_ >= 3), "the pipelined loop is for thin wave tiles (fragment double buffer: registers)");
+    static_assert(LOOP_ != 3 || (DBG_ == 0 && NI_ * MI_ <= 4), "the register-staged loop is for thin wave tiles");
+    static_assert(LOOP_ != 2 || R_ >= 5, "LOOP 2 (one barrier per two steps) needs R >= 5: R - 4 steps stay in flight across a barrier");
     static constexpr int NW = WN * WM, NT = 64 * NW;
     static constexpr int TN = 32 * NI * WN, TM = 32 * MI * WM;
     static constexpr int WPS = NW > 4 ? 2 : 1;  // waves per SIMD of one workgroup
@@ -166,7 +174,7 @@ struct PlCfg {
     static constexpr bool EPI_T = NW == 8;  // fp32 epilogues go through a 4 KiB LDS block per wave (row-major global accesses)
     static_assert((TM % 64 == 0 || TM == 32) && TN % 64 == 0, "tile shape");
     static_assert((D_ - 1) * PPW < 48, "vmcnt bookkeeping: vmcnt < 64");
-    static_assert(D_ >= 2 && D_ < R_, "prefetch distance");
+    static_assert(LOOP_ == 3 ? (D_ >= 2 && R_ == 2) : (D_ >= 2 && D_ < R_), "prefetch distance (LOOP 3: D register slots, two LDS stages)");
     // PL_ROWLN, thin tiles (r06): the row-major epilogue block of the 8 waves (32 KiB) lives in the ONE ring stage the DMA cursor
     // does not own during an epilogue (R - D == 1: the stage of the last K step, all of whose fragment reads are behind that
     // step's barrier) instead of behind the ring -- what lets a 4-stage ring of 34 / 36 KiB stages fit the CU's 160 KiB
@@ -323,18 +331,42 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
 
     // ---- prologue ----------------------------------------------------------------------------------------------
     d_set_tile(0);
-    dma_step();
+    // LOOP 3: register staging -- slot u of stg holds the pieces of step (u mod D); the cursor (d_k) is the next step to load
+    u32x4 stg[C::LOOP == 3 ? D : 1][PPW];
+    auto ld_step = [&](int slot) {   // (slot is a constant after unrolling)
+        const unsigned koff = (unsigned)(d_k >> 1) * 8192u + (unsigned)(d_k & 1) * 2048u;
 #pragma unroll
-    for (int d = 1; d < (C::LOOP == 1 ? R : D); ++d)   // LOOP 1: every stage is filled, the cursor then runs R steps ahead
-        if (total > d) dma_step();
+        for (int j = 0; j < PPW; ++j)
+            if (piece_live(j)) stg[slot][j] = *reinterpret_cast<const u32x4 *>((p_is_w[j] ? d_w : d_a) + koff + pv_off[j]);
+        ++d_k;
+    };
+    auto st_step = [&](int slot, int stage) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            if (piece_live(j)) *reinterpret_cast<u32x4 *>(pl_smem + stage * C::STAGE + pl_dst[j] + lane * 16) = stg[slot][j];
+    };
     int st = 0;  // stage of the current step
-    PL_WAIT_VM(0);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (C::LOOP == 3) {
+#pragma unroll
+        for (int u = 0; u < D; ++u)
+            if (u < total) ld_step(u);
+        PL_WAIT_VM(0);
+        st_step(0, 0);
+        if (D < total) ld_step(0);
+        lds_barrier();
+    } else {
+        dma_step();
+#pragma unroll
+        for (int d = 1; d < (C::LOOP == 1 ? R : (C::LOOP == 2 ? R - 1 : D)); ++d)   // LOOP 1: every stage is filled, the cursor then runs R steps ahead (LOOP 2: R - 1)
+            if (total > d) dma_step();
+        PL_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+    }
     rdA(X, 0, 0);
     rdW(Pl, 0, 1);
     // LOOP == 1: second fragment set (the loop alternates between the two) and the rest of step 0's fragments
     u32x4 X2[MI], Y2[MI], Ph2[NI], Pl2[NI];
-    if constexpr (C::LOOP == 1) {
+    if constexpr (C::LOOP >= 1) {
         rdW(Ph, 0, 0);
         rdA(Y, 0, 1);
     }
@@ -406,27 +438,78 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                 for (int q = 0; q < 10; ++q) pt_p[q] = *reinterpret_cast<const f32x4 *>(pp + q * 4);
             }
         }
-        if constexpr (C::LOOP == 1) {
+        if constexpr (C::LOOP == 3) {
+            // register-staged loop (single tile: total == nk).  At the top of step s the registers of step s + 1 have landed: they go
+            // to the stage step s - 1 was read from (every wave finished with it before barrier(s - 1)) and the loads of step
+            // s + 1 + D take their place; then the plain loop's three groups with its fragment timing.
+            for (int k0 = 0; k0 < nk; k0 += D) {
+#pragma unroll
+                for (int u = 0; u < D; ++u) {
+                    const int s = k0 + u;
+                    if (s < nk) {   // wave-uniform
+                        const int st1 = st ^ 1;
+                        if (s + 1 < total) {
+                            const int ahead = total - 2 - s;   // steps s + 2 .. min(s + D, total - 1) stay in flight
+                            if (full)
+                                pl_wait_steps<PPW, D - 1>(ahead);
+                            else
+                                pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), D - 1>(ahead);
+                            st_step((u + 1) % D, st1);
+                            if (s + 1 + D < total) ld_step((u + 1) % D);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        group(Pl, X, [&](int i) {
+                            if (i == 0) {
+                                rdW(Ph, st, 0);
+                                rdA(Y, st, 1);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                        group(Ph, X, nohook);
+                        lds_barrier();
+                        if (s + 1 < total) {
+                            rdA(X, st1, 0);
+                            rdW(Pl, st1, 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        group(Ph, Y, nohook);
+                        st = st1;
+                    }
+                }
+            }
+        } else if constexpr (C::LOOP >= 1) {
             // pipelined loop: [step s + 1 landed: vmcnt, barrier] [read ALL fragments of s + 1] [MFMAs of s, the DMA pieces of step
             // s + R (into the stage s came from) in their gaps]
+            // LOOP 2: ONE wait + barrier per TWO steps (even steps only; a tile's step count is even or its last step syncs alone).
+            // At the barrier of even step s the steps s + 1 and s + 2 have landed and every wave is done reading the stages of steps
+            // <= s; step s then issues step s - 1 + R (into the stage of s - 1), step s + 1 issues s + R: the cursor runs R - 1 ahead.
             auto kstep = [&](u32x4 (&cX)[MI], u32x4 (&cY)[MI], u32x4 (&cPh)[NI], u32x4 (&cPl)[NI], u32x4 (&nX)[MI], u32x4 (&nY)[MI],
-                             u32x4 (&nPh)[NI], u32x4 (&nPl)[NI], int s) {
+                             u32x4 (&nPh)[NI], u32x4 (&nPl)[NI], int s, bool sync) {
                 const int st1 = st + 1 == R ? 0 : st + 1;
-                {   // steps s + 2 .. min(s + R - 1, total - 1) may stay in flight
-                    const int ahead = total - 2 - s;
-                    if (full)
-                        pl_wait_steps<PPW, R - 2>(ahead);
-                    else
-                        pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), R - 2>(ahead);
+                if (C::LOOP == 1 || sync) {
+                    if constexpr (C::LOOP == 1) {   // steps s + 2 .. min(s + R - 1, total - 1) may stay in flight
+                        const int ahead = total - 2 - s;
+                        if (full)
+                            pl_wait_steps<PPW, R - 2>(ahead);
+                        else
+                            pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), R - 2>(ahead);
+                    } else {                        // steps s + 3 .. min(s - 2 + R, total - 1) may stay in flight
+                        const int ahead = total - 3 - s;
+                        if (full)
+                            pl_wait_steps<PPW, (R > 4 ? R - 4 : 0)>(ahead);
+                        else
+                            pl_wait_steps<(PPW > 1 ? PPW - 1 : 0), (R > 4 ? R - 4 : 0)>(ahead);
+                    }
+                    lds_barrier();
                 }
-                lds_barrier();
                 if (s + 1 < total) {
                     rdA(nX, st1, 0);
                     rdW(nPl, st1, 1);
                     rdW(nPh, st1, 0);
                     rdA(nY, st1, 1);
                 }
-                const bool more = s + R < total;   // wave-uniform; the cursor stands on step s + R, stage == st
+                // wave-uniform; the cursor stands on step s + R (stage == st) or, LOOP 2, s - 1 + R (the stage before st)
+                const bool more = C::LOOP == 1 ? s + R < total : s - 1 + R < total;
                 unsigned koff = 0;
                 const unsigned char *ca = d_a, *cw = d_w;
                 const int cst = d_stage;
@@ -455,11 +538,11 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
             };
             int k = 0;
             for (; k + 1 < nk; k += 2) {
-                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k);
-                kstep(X2, Y2, Ph2, Pl2, X, Y, Ph, Pl, ti * nk + k + 1);
+                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k, true);
+                kstep(X2, Y2, Ph2, Pl2, X, Y, Ph, Pl, ti * nk + k + 1, false);
             }
             if (k < nk) {   // odd step count: the next tile starts from the first set again
-                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k);
+                kstep(X, Y, Ph, Pl, X2, Y2, Ph2, Pl2, ti * nk + k, true);
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     X[mi] = X2[mi];
@@ -1276,7 +1359,7 @@ __global__ __launch_bounds__(C::NT, (C::NI * C::MI > 8) ? 1 : 2) void gemm_pl_ke
                     // bank conflicts.  Before: every lane fetched its own 8-byte pieces from the [n_tokens][32] tables in
                     // global memory, 128 uncoalesced loads per lane and tile, four waves the same rows -- 0.13 ms of the
                     // 0.66 ms launch.  All waves take part (and meet at the two barriers) whether their columns exist or not.
-                    static_assert(EPI != PL_QKPACK || (C::STAGE >= TM * 128 && R - D >= 2 && TM % (8 * NW) == 0),
+                    static_assert(EPI != PL_QKPACK || (C::STAGE >= TM * 128 && (C::LOOP == 3 ? R >= 2 : R - D >= 2) && TM % (8 * NW) == 0),
                                   "RoPE rows of a tile fit the two free ring stages");
                     // per-column constants by lane (column n_w0 + lane of the wave's 64), requested before the RoPE rows so that
                     // one memory round trip per tile covers both; chunks fetch theirs with ds_bpermute in one batch

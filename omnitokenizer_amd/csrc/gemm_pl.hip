@@ -117,7 +117,7 @@ static int launch_pl_cfg(PlParams p, hipStream_t stream) {
     if (wg_per_cu < 1) wg_per_cu = 1;
     // two small workgroups per CU: one tile each (the hardware dispatcher overlaps one's epilogue with the other's K loop);
     // one big workgroup per CU: persistent
-    const int64_t cap = (wg_per_cu > 1 || C::LOOP == 1) ? nt : (int64_t)n_cu;   // (the pipelined loop is a one-tile-per-workgroup loop)
+    const int64_t cap = (wg_per_cu > 1 || C::LOOP >= 1) ? nt : (int64_t)n_cu;   // (the pipelined loop is a one-tile-per-workgroup loop)
     const int grid = (int)(nt < cap ? nt : cap);
     hipLaunchKernelGGL((gemm_pl_kernel<EPI, SWAP, C>), dim3(grid), dim3(C::NT), LDS, stream, p);
     OT_LAUNCH_CHECK("gemm_pl");
@@ -144,16 +144,23 @@ using PlBig = PlCfg<4, 2, 4>;
 using PlMid = PlCfg<2, 2, 4, 2, 0, 2, 2>;      // 128 x 128
 using PlSmall = PlCfg<2, 2, 4, 2, 0, 2, 1>;    // 128 x  64
 // Closed by measurement this round (profiles/r06_pl_small_tiles.txt; the arms stay in measurement builds, -DOMNITOK_PL_MEASUREMENT_BUILDS):
-//  * a lone 128 x 64 workgroup runs its K loop at ~900 cycles per 16-k step for 192 cycles of MFMA issue.  Ablation: MFMAs + fragment
-//    reads alone 570, DMA issue 220, waits + barrier the rest.  Neither a deeper ring (DMA 4 / 6 steps ahead: arms 9 / 8), nor a loop
-//    that reads all of step s + 1's fragments under step s's MFMAs and spreads the DMA of step s + R over their gaps (PlCfg LOOP_ = 1:
-//    arms 35 / 36), nor smaller tiles that give every CU a workgroup (128 x 32, 64 x 32: arms 10 / 11) moved a 1024-row launch by more
-//    than 5 % -- all bit-identical, none faster.  What does help a thin tile is a second / third workgroup on its CU.
+// a lone 128 x 64 workgroup runs its K loop at ~900 cycles per 16-k step for 192 cycles of MFMA issue (ablation: MFMAs + fragment reads
+// alone 570, DMA issue 220, waits + barrier the rest).  FIVE restructurings, all bit-identical to the shipped tiles, all within 5 % of
+// the same time at 1024 rows:  deeper rings (DMA 4 / 6 steps ahead: arms 9 / 8);  a loop that reads all of step s + 1's fragments under
+// step s's MFMAs and spreads the DMA of step s + R over their gaps (PlCfg LOOP_ = 1: 35 / 36);  one barrier per TWO steps (LOOP_ = 2:
+// 37 / 38);  operands through registers instead of LDS-DMA, 4 / 6 steps in flight per wave (LOOP_ = 3: 39 / 40 / 41);  tiles small
+// enough that every CU gets one (128 x 32, 64 x 32: 10 / 11).  So it is neither LDS latency, nor barrier count, nor memory-level
+// parallelism, nor fetch rate per CU alone; what does help a thin tile is a second / third workgroup on its CU.
 #ifdef OMNITOK_PL_MEASUREMENT_BUILDS
 using PlMidD = PlCfg<2, 2, 6, 4, 0, 2, 2, 1>;
 using PlSmallD = PlCfg<2, 2, 8, 6, 0, 2, 1, 1>;
 using PlMid1 = PlCfg<2, 2, 4, 2, 0, 2, 2, 1>;
 using PlSmall1 = PlCfg<2, 2, 4, 2, 0, 2, 1, 1>;
+using PlSmall3 = PlCfg<2, 2, 2, 4, 0, 2, 1, 3>;   // 128 x 64, operands through registers, 4 steps in flight (arm 39); 40: 6 steps; 41: 128 x 128
+using PlSmall3b = PlCfg<2, 2, 2, 6, 0, 2, 1, 3>;
+using PlMid3 = PlCfg<2, 2, 2, 3, 0, 2, 2, 3>;
+using PlSmall2 = PlCfg<2, 2, 8, 2, 0, 2, 1, 2>;   // 128 x 64, ring of 8, one barrier per two K steps (arm 37); 38: ring of 6
+using PlSmall2b = PlCfg<2, 2, 6, 2, 0, 2, 1, 2>;
 using PlTiny = PlCfg<2, 1, 4, 2, 0, 2, 1>;     // 128 x 32, two waves
 using PlTiny64 = PlCfg<1, 1, 4, 2, 0, 2, 1>;   //  64 x 32, one wave
 #endif
@@ -247,6 +254,11 @@ static int launch_pl(const PlParams &p, int cfg, hipStream_t stream) {
             case 9: return launch_pl_cfg<EPI, false, PlMidD>(p, stream);
             case 35: return launch_pl_cfg<EPI, false, PlMid1>(p, stream);
             case 36: return launch_pl_cfg<EPI, false, PlSmall1>(p, stream);
+            case 39: return launch_pl_cfg<EPI, false, PlSmall3>(p, stream);
+            case 40: return launch_pl_cfg<EPI, false, PlSmall3b>(p, stream);
+            case 41: return launch_pl_cfg<EPI, false, PlMid3>(p, stream);
+            case 37: return launch_pl_cfg<EPI, false, PlSmall2>(p, stream);
+            case 38: return launch_pl_cfg<EPI, false, PlSmall2b>(p, stream);
             case 21: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 1, 2, 1>>(p, stream);   // 128 x 64: no vmcnt wait
             case 22: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 2, 2, 1>>(p, stream);   // no barrier
             case 23: return launch_pl_cfg<EPI, false, PlCfg<2, 2, 4, 2, 3, 2, 1>>(p, stream);   // neither
