@@ -47,7 +47,28 @@ static void run(int threads, const char *tag) {
     hipFree(out); hipFree(cyc);
 }
 
+// chip-wide sustained rate: `blocks` workgroups of `threads` threads, NACC accumulators, hipEvent time
+template <int NACC>
+static void chip(int threads, int blocks) {
+    float *out; long long *cyc;
+    hipMalloc(&out, (size_t)blocks * threads * 4); hipMalloc(&cyc, (size_t)blocks * 8);
+    const int iters = 20000;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((chain<NACC, false>), dim3(blocks), dim3(threads), 0, 0, out, cyc, 200);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((chain<NACC, false>), dim3(blocks), dim3(threads), 0, 0, out, cyc, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flop = (double)blocks * (threads / 64) * iters * 3.0 * NACC * 32768.0;
+    printf("chip: %4d workgroups x %d waves, NACC %d: %.2f ms, %.0f TFLOP/s of v_mfma_f32_32x32x16_f16\n", blocks, threads / 64, NACC, ms, flop / ms / 1e9);
+    hipFree(out); hipFree(cyc);
+}
+
 int main() {
+    chip<4>(256, 256);    // one wave per SIMD
+    chip<4>(512, 256);    // two
+    chip<4>(1024, 256);   // four
+    chip<2>(512, 512);
     for (int thr : {256, 512}) {
         run<1, false>(thr, "mfma only");
         run<2, false>(thr, "mfma only");
