@@ -176,7 +176,11 @@ def test_engine_with_the_fused_temporal_stage_vs_reference_golden(name):
         _lib.set_option("temporal_fused", 1)
         _lib.set_option("temporal_kernel", 1)
     assert torch.equal(z1, z2) and torch.equal(ids1, ids2)
-    assert not torch.equal(z0, z1)   # the option is live (the two forms round differently)
+    # the option is live (the two forms round differently) -- wherever the call runs the plane flow the fused stage belongs to: always
+    # by default; under OMNITOK_TEST_PL_MIN_TOKENS=12288 (the A/B arm of tests/conftest.py) a one-clip call takes the other flow
+    import os
+    if c.ids.numel() >= int(os.environ.get("OMNITOK_TEST_PL_MIN_TOKENS", "0")):
+        assert not torch.equal(z0, z1)
     noise = max(c.fp32_noise_z, 0.0)
     ztol = max(Z_TOL, 8.0 * noise)
     zerr, zdiff = float((z1.cpu() - c.z).abs().max()), float((z1 - z0).abs().max())
