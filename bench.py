@@ -18,7 +18,10 @@ Extra objects on the JSON line (rank 0):
   kernels       per-family ms / achieved rate of that pass (spatial attention, VQ, ...)
   cpu_baseline  the CPU oracle (a port of the reference's arithmetic on ATen/MKL) timed on this
                 host on a bounded sample (N = 1 only)
-  parity        id flips / pixel error / PSNR of the GPU path vs the oracle on that sample
+  parity        the TIMED batch against the oracle: `flow` (data flow the timed step ran), id flips over all B clips
+                (`flips_all_clips`), latent / pixel error and PSNR of clip 0 taken out of full-batch calls
+  also          (default C3 line only) strict-fp32 arithmetic with its own `flips_all_clips`, C2, 8 clips, C5 shape, one-image /
+                one-clip latency, the heavy-statistics reference fixture per arithmetic / data-flow arm
 """
 import argparse
 import json
@@ -483,6 +486,12 @@ def also_extras(model, x, sd, a, ids_ref_all=None):
         del xi
     except Exception as e:  # noqa: BLE001
         also["c2"] = {"error": repr(e)}
+    try:   # mid-size call: 8 of the timed clips in one call (tail schedule of the plane GEMM)
+        ms, ids = _time_steps(model, x[:8].contiguous(), False, steps=5)
+        also["clips8"] = {"workload": "8 clips 17x256x256 (the first 8 of the timed batch)", "ms_per_step": round(ms, 3),
+                          "patches_s": round(ids.numel() / ms * 1e3, 1), "steps": 5}
+    except Exception as e:  # noqa: BLE001
+        also["clips8"] = {"error": repr(e)}
     try:
         args5 = make_args(2, resolution=512, n_codes=16384, sequence_length=65)
         cfg5 = OmniTokConfig.from_args(args5)
