@@ -74,8 +74,9 @@ const char *omnitok_version(void);
  *                round-2 form (row_stats -> gemm_h2 with in-loop LayerNorm -> attn_pack)
  * Tuning knobs of the stand-alone kernel entry points for A/B measurements (process-wide; results do not depend on them --
  * tests check bitwise independence of the tile shape): "gemm_variant", "gemm_small", "gemm_gn", "gemm_lds_pad_kb",
- * "x3_tile", "h2_tile" (0 auto | 1 256x256 | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "pl_cfg" (0 auto | 1 256x256 |
- * 2 128x256, two workgroups per CU), "attn_h2_variant", "vq_split", "vq_screen" (1 default: omnitok_encode uses the screened search omnitok_vq_argmin_screened | 0 the exact sweep), "vq_screen_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
+ * "x3_tile", "h2_tile" (0 auto | 1 256x256 | 3 128x128 | 4 64x64 | 5 256x128 | 6 128x256), "pl_cfg" (above), "pl_tail" (1 default:
+ * full rounds of 256x256 tiles + the last round's rows on thin tiles in a second launch | 0 one launch), "sp_small_blocks" (0 default:
+ * omnitok_stats_pack in 16-row workgroups at every size | n: only below n 64-row blocks), "attn_h2_variant", "vq_split", "vq_screen" (1 default: omnitok_encode uses the screened search omnitok_vq_argmin_screened | 0 the exact sweep), "vq_screen_split", "vq_variant" (1 default: distance finished on the matrix pipe | 0 VALU epilogue | 2 codebook
  * staged in LDS; all bit-exact, profiles/r03_vq_variants.txt), "pl_stagger" (start delay step of persistent GEMM workgroups in
  * ~1 us units, 0 = off: a measured no-gain knob), "peg_variant" (1 default: LDS-tiled -- the 64-channel kernel of peg_wide.h for
  * 2..8 planes on grids with W % 16 == 0, H % 4 == 0, D % 64 == 0, its one-plane form (9 taps, four workgroups per CU) for images,
@@ -84,7 +85,8 @@ const char *omnitok_version(void);
  * (default) K-sliced GEMV for B <= 2 and K in {1536, 2048, 6144, 8192} | 0 row GEMV; "lm_balance" 1 (default) 6 waves per workgroup
  * where that makes the row GEMV's grid a whole number of workgroups per CU | 0 four; "lm_attn_waves" 8 (default) | 4 waves per
  * 256-key attention chunk; "lm_attn_short" 1 (default, read by omnitok_lm_alloc_cache) 128-key chunks for caches of up to 4096
- * tokens | 0 always 256; "lm_ks_deep" 0 (default) 8 KiB | 1 16 KiB of weights in flight per wave of the K-sliced GEMV; "x3_dbg" / "h2_dbg" select
+ * tokens | 0 always 256; "lm_ks_deep" 0 (default) 8 KiB | 1 16 KiB of weights in flight per wave of the K-sliced GEMV; "lm_mfma" 0 (default) | 1 groups of
+ * 4 .. 8 streams on the fp32-MFMA GEMV (measured slower, profiles/r06_lm_mfma.txt); "x3_dbg" / "h2_dbg" select
  * wrong-result ablation builds (tools/x3_ablate.py, tools/h2_bench.py).  Unknown names return OMNITOK_ERR_INVALID. */
 int omnitok_set_option(const char *name, int value);
 /* Reads the process default of a data-flow option ("gemm_mode", "attn_mode", "gemm_pl", "pl_min_tokens", "temporal_chunk",
