@@ -290,6 +290,36 @@ def test_one_data_flow_at_every_size_and_the_option_still_selects_the_other(mode
         assert (auto[1] - other[1]).abs().max().item() < 2 * max(Z_TOL, 8.0 * c.fp32_noise_z)
 
 
+def test_tile_schedule_does_not_show_in_the_engine_outputs(models):
+    """r06: at 8 clips (40 960 tokens) the plane GEMM's size rule runs full rounds of 256 x 256 tiles plus a tail of thin tiles for the
+    N = 512 / 1024 launches ("pl_tail" 1) and 16-row stats_pack workgroups; forcing one big-tile launch ("pl_tail" 0), thin tiles
+    everywhere ("pl_cfg" 5 / 6) or the 64-row stats_pack form ("sp_small_blocks" 1) changes no bit of ids, latents or pixels."""
+    from omnitokenizer_amd import _lib
+    c = GoldenCase(HEAVY_BATCH_CASE)
+    m = models(c)
+    x = c.x.cuda()
+
+    def run(**opts):
+        try:
+            for k, v in opts.items():
+                _lib.set_option(k, v)
+            ids, z = m.encode(x, c.is_image, return_latents=True)
+            return ids.clone(), z.clone(), m.decode(ids, c.is_image).clone()
+        finally:
+            _lib.set_option("pl_tail", 1)
+            _lib.set_option("pl_cfg", 0)
+            _lib.set_option("sp_small_blocks", 0)
+    base = run()
+    for opts in (dict(pl_tail=0), dict(pl_cfg=5), dict(pl_cfg=6), dict(pl_cfg=1), dict(sp_small_blocks=1)):
+        got = run(**opts)
+        for a_, b_ in zip(base, got):
+            assert torch.equal(a_, b_), opts
+    # ... and one clip alone gets the bits it has inside the batch (another grid for every launch)
+    ids1, z1 = m.encode(x[:1].contiguous(), c.is_image, return_latents=True)
+    assert torch.equal(ids1, base[0][:1]) and torch.equal(z1, base[1][:1])
+    assert torch.equal(m.decode(ids1, c.is_image), base[2][:1])
+
+
 def test_prevq_fusion_and_temporal_chunks_are_bit_identical(models):
     """Three r05 changes that must not change a bit: "prevq_fuse" (pre_vq inside the encoder's last LayerNorm pass),
     "vq_screen" (the fp16-screened nearest-code search) and "temporal_chunk" (the temporal q|k|v GEMM + attention run chunk by chunk through an Infinity-Cache-sized buffer;
