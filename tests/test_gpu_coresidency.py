@@ -18,7 +18,8 @@ from tests.helpers import GoldenCase
 from tests.test_oracle_gpt import load_gpt_case
 
 pytestmark = pytest.mark.gpu
-STEPS = 200
+import os  # noqa: E402
+STEPS = int(os.environ.get("OMNITOK_CORESIDENCY_STEPS", "200"))   # (profiles/r06_no_packed_fp32.txt: one 3000-step run per pair)
 
 
 def _model(case):
